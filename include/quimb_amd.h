@@ -1,0 +1,146 @@
+/*
+ * quimb_amd.h -- C-ABI of libquimb_amd.so, the MI355X (gfx950) contraction
+ * backend that sits underneath quimb's array-backend boundary.
+ *
+ * Every entry point replaces an L0 array-library call that the reference's
+ * hot path bottoms out in.  Citations are to
+ * /root/reference (quimb) -- the arithmetic itself lives in numpy/cotengra,
+ * which quimb reaches through these call sites:
+ *
+ *   qamd_contract_pair   <- do("tensordot", ...) quimb/tensor/tensor_core.py:3793
+ *                           ctg.array_contract   quimb/tensor/contraction.py:285
+ *                           (cotengra lowers every pairwise step to
+ *                            permute/reshape + (batched) matmul; here the
+ *                            permutes are folded into the operand addressing)
+ *   qamd_permute         <- do("transpose")/do("reshape") in the composed
+ *                           `fuse`  quimb/tensor/array_ops.py:148-182,
+ *                           Tensor.transpose tensor_core.py:2743,
+ *                           Tensor.isel (take / getitem) tensor_core.py:2260-2348
+ *   qamd_strip_exponent  <- strip_exponent=True contract semantics,
+ *                           tensor_core.py:330-340, tests/test_tensor/test_contract.py:8-19
+ *   qamd_reduce_sum      <- single-operand einsum terms ("ab->a") that
+ *                           cotengra preprocesses before a pairwise step
+ *   qamd_binary          <- do("multiply") for pure hyper-index steps,
+ *                           slice accumulation (sum over sliced indices)
+ *   qamd_scale / qamd_conj / qamd_cast
+ *                        <- Tensor.__mul__/__truediv__ (tensor_core.py:3771,3813),
+ *                           Tensor.conj, Tensor.astype (tensor_core.py:2716)
+ *
+ * Conventions: plain pointers and sizes only, no C++/torch types.  All
+ * extents/strides are int64 in units of ELEMENTS.  Every call is
+ * stream-ordered on the hipStream_t passed (as void*), never synchronises,
+ * never allocates device memory: the caller owns every buffer.  Return value:
+ * 0 on success, negative QAMD_E* code otherwise (no exceptions cross the ABI).
+ */
+#ifndef QUIMB_AMD_H
+#define QUIMB_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define QAMD_ABI_VERSION 1
+#define QAMD_MAX_GROUPS 8   /* fused index groups per bundle            */
+#define QAMD_MAX_NDIM 32    /* max rank accepted by permute/binary/reduce */
+
+typedef enum {
+  QAMD_F32 = 0,
+  QAMD_F64 = 1,
+  QAMD_C64 = 2,
+  QAMD_C128 = 3
+} qamd_dtype;
+
+enum {
+  QAMD_OK = 0,
+  QAMD_EINVAL = -1,    /* malformed plan / argument                    */
+  QAMD_EUNSUPPORTED = -2,
+  QAMD_EWORKSPACE = -3, /* workspace too small                          */
+  QAMD_ELAUNCH = -4    /* hipGetLastError() != success after launch     */
+};
+
+/*
+ * Pairwise contraction plan ("GETT" form: GEMM with tensor addressing).
+ *
+ *   C[b, m, n] = sum_k A[b, m, k] * B[b, k, n]
+ *
+ * b, m, n, k are *bundles* of fused index groups.  A linear bundle index is
+ * decomposed mixed-radix over dim_x[0..nx-1] (group nx-1 fastest) and dotted
+ * with the per-operand strides to give an element offset.  No operand is ever
+ * physically permuted.
+ */
+typedef struct {
+  int32_t dtype;     /* qamd_dtype                                       */
+  int32_t nb, nm, nn, nk;
+  int32_t conj_a, conj_b; /* complex only                                */
+  int32_t reserved;
+  int64_t dim_b[QAMD_MAX_GROUPS], sa_b[QAMD_MAX_GROUPS], sb_b[QAMD_MAX_GROUPS], sc_b[QAMD_MAX_GROUPS];
+  int64_t dim_m[QAMD_MAX_GROUPS], sa_m[QAMD_MAX_GROUPS], sc_m[QAMD_MAX_GROUPS];
+  int64_t dim_n[QAMD_MAX_GROUPS], sb_n[QAMD_MAX_GROUPS], sc_n[QAMD_MAX_GROUPS];
+  int64_t dim_k[QAMD_MAX_GROUPS], sa_k[QAMD_MAX_GROUPS], sb_k[QAMD_MAX_GROUPS];
+  /* tuning hints filled by qamd_pair_plan_finalize (may be overridden)   */
+  int32_t tile_cfg;  /* index into the kernel table, -1 = auto           */
+  int32_t split_k;   /* >=1                                              */
+  int32_t vec_a, vec_b; /* 1,2,4: elements per contiguous global load    */
+  int32_t a_kcontig, b_kcontig; /* 1: stride-1 index lives in the K bundle */
+  int32_t c_ncontig; /* 1: C's stride-1 index lives in the N bundle      */
+  int32_t reserved2;
+} qamd_pair_plan;
+
+int qamd_abi_version(void);
+const char* qamd_build_info(void);
+
+/* Validate the plan, pick tile config / split-K / vector widths. */
+int qamd_pair_plan_finalize(qamd_pair_plan* plan, int64_t align_a_bytes, int64_t align_b_bytes);
+/* Number of int64 entries the K-offset table needs (2 * padded K). */
+int64_t qamd_pair_ktab_len(const qamd_pair_plan* plan);
+/* Fill the K-offset table (device memory, int64[qamd_pair_ktab_len]). */
+int qamd_pair_build_ktab(const qamd_pair_plan* plan, void* ktab_dev, void* stream);
+/* Bytes of scratch needed by qamd_contract_pair (split-K slabs), may be 0. */
+int64_t qamd_pair_workspace_bytes(const qamd_pair_plan* plan);
+/* C = A . B (overwrites C). */
+int qamd_contract_pair(const qamd_pair_plan* plan, const void* A, const void* B, void* C,
+                       const void* ktab_dev, void* workspace, int64_t workspace_bytes, void* stream);
+
+/*
+ * dst (C-contiguous, given shape) <- src viewed with arbitrary element
+ * strides + element offset.  Covers transpose, index fusion (transpose +
+ * reshape), isel/take slices, diagonals (summed strides), broadcast (stride 0).
+ */
+int qamd_permute(void* dst, const void* src, int32_t ndim, const int64_t* shape,
+                 const int64_t* src_strides, int64_t src_offset, int32_t dtype, void* stream);
+
+/* out[o] = sum_r x[off_o(o) + off_r(r)];  out is C-contiguous over the kept dims. */
+int qamd_reduce_sum(void* out, const void* x, int32_t ndim_keep, const int64_t* shape_keep,
+                    const int64_t* strides_keep, int32_t ndim_red, const int64_t* shape_red,
+                    const int64_t* strides_red, int32_t dtype, void* stream);
+
+/* out (C-contiguous, shape) = a[view] (op) b[view];  op: 0 add, 1 mul, 2 sub. */
+int qamd_binary(void* out, const void* a, const int64_t* a_strides, const void* b,
+                const int64_t* b_strides, int32_t ndim, const int64_t* shape, int32_t op,
+                int32_t dtype, void* stream);
+
+/* x *= (re + i im)   (im ignored for real dtypes) */
+int qamd_scale(void* x, int64_t n, double re, double im, int32_t dtype, void* stream);
+/* y = y * fy + x * fx  with real factors (slice accumulation). */
+int qamd_axpby(void* y, const void* x, int64_t n, double fy, double fx, int32_t dtype, void* stream);
+int qamd_conj(void* dst, const void* src, int64_t n, int32_t dtype, void* stream);
+int qamd_cast(void* dst, int32_t dst_dtype, const void* src, int32_t src_dtype, int64_t n, void* stream);
+int qamd_fill(void* dst, int64_t n, double re, double im, int32_t dtype, void* stream);
+
+/*
+ * Exponent stripping: x /= max|x|; *exponent_dev (double, device) +=
+ * log10(max|x|).  scratch_dev: >= 8 bytes of device memory, zeroed by the
+ * call itself.  If max|x| == 0 the data is left untouched and exponent
+ * unchanged (cotengra's check_zero is handled by the host).
+ */
+int qamd_strip_exponent(void* x, int64_t n, int32_t dtype, void* scratch_dev,
+                        void* exponent_dev, void* stream);
+/* out_dev (double, device) = max|x| */
+int qamd_absmax(void* out_dev, const void* x, int64_t n, int32_t dtype, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* QUIMB_AMD_H */

@@ -1,0 +1,299 @@
+"""CPU oracle: a numpy restatement of the reference's contraction path.
+
+TEST INFRASTRUCTURE ONLY.  Nothing under ``quimb_amd/`` imports this file; only
+``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg
+may -- and there only as the checker / timed baseline, never as the product.
+
+What is restated (file:line under /root/reference unless stated):
+
+* ``gen_output_inds``            quimb/tensor/tensor_core.py:158-170
+* ``oracle_array_contract``      the arithmetic of ``ctg.array_contract`` as called at
+                                 quimb/tensor/contraction.py:285.  cotengra==0.8.2 (pixi.lock:70)
+                                 and autoray==0.10.1 (pixi.lock:67) are NOT vendored in the
+                                 reference tree; their published algorithm is restated: walk the
+                                 contraction path, one pairwise ``einsum`` (== tensordot + transpose,
+                                 or batched matmul for hyper indices) per step, optional
+                                 ``strip_exponent`` (after every step divide by max|x| and accumulate
+                                 log10), slices summed.
+* ``oracle_tensor_contract``     quimb/tensor/tensor_core.py:224-358 (output-index inference,
+                                 scalar unwrapping, tag union, exponent handling)
+* ``oracle_fuse``                quimb/tensor/array_ops.py:95-182
+* builders                       TN2D_from_fill_fn quimb/tensor/tensor_builder.py:1345-1369 (index order
+                                 l, r, u, d); classical Ising tensors tensor_builder.py:2318-2466 and
+                                 TN2D_classical_ising_partition_function :2687-2811; MPS order l, r, p
+                                 quimb/tensor/tn1d/core.py:1881-1901
+
+Pinning: the restatement is checked in ``tests/test_oracle.py`` against (a) the
+reference's only fixed-number known-answer test on this path -- the 16x16 Ising
+partition function 8.459419593253275e100
+(tests/test_tensor/test_tn2d/test_core.py:309-335) -- via an independent exact
+transfer-matrix evaluation, (b) ``numpy.einsum`` over the whole network, and (c)
+golden vectors produced by importing the real quimb from /root/reference
+(``tests/golden/make_golden.py``).
+"""
+
+import itertools
+import math
+
+import numpy as np
+
+_SYMS = [chr(c) for c in range(ord("a"), ord("z") + 1)] + [chr(c) for c in range(ord("A"), ord("Z") + 1)]
+_SYMS += [chr(c) for c in range(192, 192 + 5000)]
+
+
+def gen_output_inds(all_inds):
+    from collections import Counter
+
+    freq = Counter(all_inds)
+    out = []
+    for ind, f in freq.items():
+        if f > 2:
+            raise ValueError(f"The index {ind} appears more than twice!")
+        if f == 1:
+            out.append(ind)
+    return tuple(out)
+
+
+def _pair_result_inds(ia, ib, others, output):
+    keep = []
+    rest = set(output)
+    for t in others:
+        rest.update(t)
+    for ix in tuple(ia) + tuple(ib):
+        if ix in rest and ix not in keep:
+            keep.append(ix)
+    return tuple(keep)
+
+
+def _einsum_inds(arrays, inds_list, out_inds):
+    sym = {}
+    for t in list(inds_list) + [out_inds]:
+        for ix in t:
+            if ix not in sym:
+                sym[ix] = _SYMS[len(sym)]
+    eq = ",".join("".join(sym[ix] for ix in t) for t in inds_list) + "->" + "".join(sym[ix] for ix in out_inds)
+    return np.einsum(eq, *arrays)
+
+
+def oracle_contract_core(arrays, inputs, output, path, strip_exponent=False):
+    """Pairwise evaluation along a linear (opt_einsum style) path."""
+    arrays = list(arrays)
+    inputs = [tuple(t) for t in inputs]
+    exponent = 0.0
+    for con in path:
+        con = tuple(sorted(con, reverse=True))
+        ops = [arrays.pop(p) for p in con][::-1]
+        tis = [inputs.pop(p) for p in con][::-1]
+        if len(ops) == 1:
+            keep = _pair_result_inds(tis[0], (), inputs, output)
+        else:
+            keep = _pair_result_inds(tis[0], tis[1], inputs, output)
+        x = _einsum_inds(ops, tis, keep)
+        if strip_exponent:
+            f = np.max(np.abs(x))
+            if f > 0:
+                x = x / f
+                exponent += math.log10(f)
+        arrays.append(x)
+        inputs.append(keep)
+    if len(arrays) != 1:
+        # leftover disconnected pieces: multiply them out
+        x = _einsum_inds(arrays, inputs, tuple(output))
+    else:
+        x = _einsum_inds(arrays, inputs, tuple(output))
+    return (x, exponent) if strip_exponent else x
+
+
+def naive_path(n):
+    return [(0, 1)] * (n - 1)
+
+
+def oracle_array_contract(arrays, inputs, output=None, path=None, strip_exponent=False, sliced_inds=(),
+                          size_dict=None, dtype=None):
+    """The reference arithmetic: numpy pairwise contraction in path order,
+    optionally sliced (slices are summed) and exponent-stripped."""
+    arrays = [np.asarray(a) if dtype is None else np.asarray(a, dtype=dtype) for a in arrays]
+    inputs = [tuple(t) for t in inputs]
+    if output is None:
+        output = gen_output_inds(ix for t in inputs for ix in t)
+    if path is None:
+        path = naive_path(len(arrays))
+    if not sliced_inds:
+        return oracle_contract_core(arrays, inputs, output, path, strip_exponent)
+    if size_dict is None:
+        size_dict = {ix: d for t, a in zip(inputs, arrays) for ix, d in zip(t, a.shape)}
+    total, total_e = None, None
+    for vals in itertools.product(*[range(size_dict[ix]) for ix in sliced_inds]):
+        fix = dict(zip(sliced_inds, vals))
+        arrs, ins = [], []
+        for a, t in zip(arrays, inputs):
+            key = tuple(fix[ix] if ix in fix else slice(None) for ix in t)
+            arrs.append(a[key])
+            ins.append(tuple(ix for ix in t if ix not in fix))
+        r = oracle_contract_core(arrs, ins, output, path, strip_exponent)
+        if strip_exponent:
+            x, e = r
+            if total is None:
+                total, total_e = x, e
+            else:
+                en = max(total_e, e)
+                total = total * 10 ** (total_e - en) + x * 10 ** (e - en)
+                total_e = en
+        else:
+            total = r if total is None else total + r
+    return (total, total_e) if strip_exponent else total
+
+
+def realify_scalar(x, imag_tol=1e-12):
+    if isinstance(x, complex):
+        return x.real if abs(x.imag) < abs(x.real) * imag_tol else x
+    return x
+
+
+def oracle_tensor_contract(tensors, output_inds=None, path=None, strip_exponent=False, exponent=None,
+                           preserve_tensor=False):
+    """``tensors``: sequence of (data, inds, tags).  Returns scalar or
+    (data, inds, tags); with ``strip_exponent`` a pair (result, exponent)."""
+    arrays = [np.asarray(t[0]) for t in tensors]
+    inds = [tuple(t[1]) for t in tensors]
+    if output_inds is None:
+        out = gen_output_inds(ix for t in inds for ix in t)
+    else:
+        out = tuple(output_inds)
+    data = oracle_array_contract(arrays, inds, out, path, strip_exponent)
+    e = None
+    if strip_exponent:
+        data, e = data
+        if exponent is not None:
+            e = e + exponent
+    elif exponent is not None:
+        data = data * 10**exponent
+    if not out and not preserve_tensor:
+        res = realify_scalar(np.asarray(data).item())
+    else:
+        tags = tuple(dict.fromkeys(tg for t in tensors for tg in (t[2] if len(t) > 2 and t[2] else ())))
+        res = (data, out, tags)
+    return (res, e) if strip_exponent else res
+
+
+def oracle_fuse(x, *axes_groups):
+    x = np.asarray(x)
+    groups = tuple(tuple(g) for g in axes_groups)
+    if not any(groups):
+        return x
+    ndim = x.ndim
+    ax2g = {ax: g for g, axes in enumerate(groups) for ax in axes}
+    pos = min(a for g in groups for a in g)
+    before = [ax for ax in range(pos) if ax not in ax2g]
+    after = [ax for ax in range(pos, ndim) if ax not in ax2g]
+    perm = before + [ax for g in groups for ax in g] + after
+    new_shape = [x.shape[a] for a in before] + [int(np.prod([x.shape[a] for a in g])) for g in groups]
+    new_shape += [x.shape[a] for a in after]
+    return np.transpose(x, perm).reshape(new_shape)
+
+
+# ---------------------------------------------------------------------------
+# builders (restated input generators)
+# ---------------------------------------------------------------------------
+def tn2d_inds(Lx, Ly):
+    """Index labels of an open Lx x Ly lattice, per site in row-major order,
+    each in the reference's l, r, u, d order (u = towards row i+1)."""
+
+    def bond(a, b):
+        a, b = sorted((a, b))
+        return ("b", a, b)
+
+    inputs = []
+    for i, j in itertools.product(range(Lx), range(Ly)):
+        inds = []
+        if j > 0:
+            inds.append(bond((i, j), (i, j - 1)))
+        if j < Ly - 1:
+            inds.append(bond((i, j), (i, j + 1)))
+        if i < Lx - 1:
+            inds.append(bond((i, j), (i + 1, j)))
+        if i > 0:
+            inds.append(bond((i, j), (i - 1, j)))
+        inputs.append(tuple(inds))
+    return inputs
+
+
+def tn2d_from_fill_fn(fill_fn, Lx, Ly, D):
+    inputs = tn2d_inds(Lx, Ly)
+    arrays = [fill_fn((D,) * len(t)) for t in inputs]
+    return arrays, inputs
+
+
+def tn2d_rand(Lx, Ly, D, seed=0, low=-0.1, high=1.0, dtype="float32", normalize=True):
+    """'Mostly positive' uniform fill as the reference's own 2D accuracy tests use
+    (tests/test_tensor/test_tn2d/test_core.py:243-247).  ``normalize`` rescales
+    every tensor by 1/(mean * D^(deg/2)) so the network value stays O(1)-ish in
+    fp32 instead of ~1e105 (SURVEY.md section 7 'fp32 dynamic range')."""
+    rng = np.random.default_rng(seed)
+    mean = 0.5 * (low + high)
+
+    def fill(shape):
+        x = rng.uniform(low, high, size=shape)
+        if normalize:
+            x = x / (mean * D ** (len(shape) / 2.0))
+        return x.astype(dtype)
+
+    return tn2d_from_fill_fn(fill, Lx, Ly, D)
+
+
+def ising_sqrtS(beta, j=1.0):
+    c, s = math.cosh(j * beta) ** 0.5, math.sinh(j * beta) ** 0.5
+    return np.array([[c + s, c - s], [c - s, c + s]]) / 2**0.5
+
+
+def ising_T(beta, ndir, h=0.0):
+    """T[d1..dn] = sum_i prod_k sqrtS[i, d_k] * H[i]"""
+    S = ising_sqrtS(beta)
+    H = np.array([math.exp(-beta * h), math.exp(beta * h)])
+    syms = "abcdefgh"[:ndir]
+    eq = ",".join("i" + s for s in syms) + ",i->" + syms
+    return np.einsum(eq, *([S] * ndir), H)
+
+
+def tn2d_classical_ising(Lx, Ly, beta, h=0.0):
+    inputs = tn2d_inds(Lx, Ly)
+    arrays = [ising_T(beta, len(t), h) for t in inputs]
+    return arrays, inputs
+
+
+def ising_partition_exact(Lx, Ly, beta, j=1.0):
+    """Exact open-boundary 2D Ising partition function by row transfer over the
+    2^Ly row configurations -- independent of any tensor-network code."""
+    n = 1 << Ly
+    spins = 1 - 2 * ((np.arange(n)[:, None] >> np.arange(Ly)[None, :]) & 1)  # (n, Ly) in {+1,-1}
+    horiz = np.exp(beta * j * np.sum(spins[:, :-1] * spins[:, 1:], axis=1))  # within-row bonds
+    w = np.array([[math.exp(beta * j), math.exp(-beta * j)], [math.exp(-beta * j), math.exp(beta * j)]])
+    v = horiz.astype(np.float64).copy()
+    log_scale = 0.0
+    for _ in range(Lx - 1):
+        t = v.reshape((2,) * Ly)
+        for ax in range(Ly):
+            t = np.moveaxis(np.tensordot(w, t, axes=([1], [ax])), 0, ax)
+        v = t.reshape(n) * horiz
+        m = v.max()
+        v /= m
+        log_scale += math.log10(m)
+    return float(v.sum()) * 10**log_scale if log_scale < 300 else (float(v.sum()), log_scale)
+
+
+def mps_rand(L, chi, d=2, seed=0, dtype="float64"):
+    """Open-boundary MPS tensors in the reference's l, r, p index order."""
+    rng = np.random.default_rng(seed)
+    arrays, inputs = [], []
+    for i in range(L):
+        inds, shape = [], []
+        if i > 0:
+            inds.append(("b", i - 1)); shape.append(chi)
+        if i < L - 1:
+            inds.append(("b", i)); shape.append(chi)
+        inds.append(("k", i)); shape.append(d)
+        x = rng.normal(size=shape)
+        x = x / np.linalg.norm(x) ** (1.5 / x.ndim)
+        arrays.append(x.astype(dtype))
+        inputs.append(tuple(inds))
+    return arrays, inputs

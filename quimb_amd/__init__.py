@@ -1,0 +1,33 @@
+"""quimb_amd -- an MI355X (gfx950) tensor-network contraction backend that
+plugs in at quimb's autoray array-backend boundary.
+
+The top-level module *is* the autoray backend namespace: ``autoray.do(name,
+x, like="quimb_amd")`` resolves ``quimb_amd.<name>``, and
+``autoray.infer_backend`` maps ``quimb_amd.Array`` instances to ``"quimb_amd"``
+because the class is exported from here (see ``autoray_backend.register``).
+
+Importing this package never touches the GPU; the HIP library and device are
+bound on first use and there is no CPU fallback.
+"""
+
+from .array import Array, asarray, to_numpy
+from .ops import (  # noqa: F401  (autoray resolves these by name)
+    absmax, add, array, astype, concatenate, conj, conjugate, divide, dot, einsum, einsum_pair,
+    expand_dims, eye, fuse, imag, matmul, multiply, ndim, negative, norm_fro, ones, ravel, real,
+    reshape, shape, size, squeeze, subtract, sum, take, tensordot, trace, transpose, true_divide, zeros,
+)
+from .contract import (  # noqa: F401
+    ContractExpression, Tensor, array_contract, array_contract_expression, array_contract_path,
+    array_contract_tree, contract_backend, contract_strategy, get_contract_backend,
+    get_contract_strategy, get_tensor_linop_backend, set_contract_backend, set_contract_strategy,
+    set_tensor_linop_backend, tensor_contract, tensor_linop_backend,
+)
+from .executor import TreeExecutor
+from .pathfind import find_path, find_slices, greedy_path, random_greedy, sweep_path_2d
+from .tree import ContractionTree
+from .device import HipDevice, default_device
+
+# the class must report the top-level module for autoray's backend inference
+Array.__module__ = "quimb_amd"
+
+__version__ = "0.1.0"

@@ -1,0 +1,389 @@
+// api.cpp -- host side of the C-ABI (include/quimb_amd.h): plan validation,
+// tile / vector-width / split-K selection, bundle construction for the tiled
+// permute, argument packing.  No device code here; kernels live in gett.hip and
+// elementwise.hip.  Nothing in this file allocates device memory or synchronises.
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "../../include/quimb_amd.h"
+#include "ew_args.h"
+#include "gett_args.h"
+
+static const int kEsize[4] = {4, 8, 8, 16};
+
+extern "C" int qamd_abi_version(void) { return QAMD_ABI_VERSION; }
+extern "C" const char* qamd_build_info(void) {
+  return "quimb_amd gfx950 (CDNA4) HIP backend; MFMA f32/f64 16x16x4 GETT; ABI 1";
+}
+
+// ---------------------------------------------------------------------------
+// pairwise plan
+// ---------------------------------------------------------------------------
+static bool prod_ok(const int64_t* d, int n, int64_t& out) {
+  int64_t p = 1;
+  for (int i = 0; i < n; ++i) {
+    if (d[i] <= 0) return false;
+    p *= d[i];
+    if (p >= (1ll << 31)) return false;
+  }
+  out = p;
+  return true;
+}
+
+struct PairDims { int64_t B, M, N, K; };
+
+static int pair_dims(const qamd_pair_plan* p, PairDims& d) {
+  if (!p) return QAMD_EINVAL;
+  if (p->nb < 0 || p->nm < 0 || p->nn < 0 || p->nk < 0) return QAMD_EINVAL;
+  if (p->nb > QAMD_MAX_GROUPS || p->nm > QAMD_MAX_GROUPS || p->nn > QAMD_MAX_GROUPS || p->nk > QAMD_MAX_GROUPS)
+    return QAMD_EINVAL;
+  if (!prod_ok(p->dim_b, p->nb, d.B) || !prod_ok(p->dim_m, p->nm, d.M) || !prod_ok(p->dim_n, p->nn, d.N) ||
+      !prod_ok(p->dim_k, p->nk, d.K))
+    return QAMD_EINVAL;
+  return QAMD_OK;
+}
+
+static int pick_vec(int64_t inner_dim, int64_t align_bytes, int esize, const std::vector<int64_t>& others) {
+  for (int v = 4; v >= 2; v >>= 1) {
+    if (inner_dim % v) continue;
+    if (align_bytes % ((int64_t)v * esize)) continue;
+    bool ok = true;
+    for (int64_t s : others)
+      if (s % v) { ok = false; break; }
+    if (ok) return v;
+  }
+  return 1;
+}
+
+static const int kTileBM[5] = {128, 64, 256, 256, 128};
+static const int kTileBN[5] = {128, 64, 48, 16, 32};
+static const int kBK = 16;
+static const int kNumCU = 256;
+
+extern "C" int qamd_pair_plan_finalize(qamd_pair_plan* p, int64_t align_a, int64_t align_b) {
+  PairDims d;
+  int rc = pair_dims(p, d);
+  if (rc) return rc;
+  if (p->dtype != QAMD_F32 && p->dtype != QAMD_F64) return QAMD_EUNSUPPORTED;
+  const int es = kEsize[p->dtype];
+
+  // ---- operand A: which bundle owns the stride-1 index --------------------
+  {
+    bool m1 = p->nm > 0 && p->sa_m[p->nm - 1] == 1;
+    bool k1 = p->nk > 0 && p->sa_k[p->nk - 1] == 1;
+    p->a_kcontig = (!m1 && k1) ? 1 : 0;
+    p->vec_a = 1;
+    if (m1 || k1) {
+      std::vector<int64_t> others;
+      for (int i = 0; i < p->nb; ++i) others.push_back(p->sa_b[i]);
+      for (int i = 0; i < p->nm; ++i)
+        if (!(m1 && !p->a_kcontig && i == p->nm - 1)) others.push_back(p->sa_m[i]);
+      for (int i = 0; i < p->nk; ++i)
+        if (!(p->a_kcontig && i == p->nk - 1)) others.push_back(p->sa_k[i]);
+      int64_t inner = p->a_kcontig ? p->dim_k[p->nk - 1] : p->dim_m[p->nm - 1];
+      p->vec_a = pick_vec(inner, align_a, es, others);
+    }
+  }
+  {
+    bool n1 = p->nn > 0 && p->sb_n[p->nn - 1] == 1;
+    bool k1 = p->nk > 0 && p->sb_k[p->nk - 1] == 1;
+    p->b_kcontig = (!n1 && k1) ? 1 : 0;
+    p->vec_b = 1;
+    if (n1 || k1) {
+      std::vector<int64_t> others;
+      for (int i = 0; i < p->nb; ++i) others.push_back(p->sb_b[i]);
+      for (int i = 0; i < p->nn; ++i)
+        if (!(n1 && !p->b_kcontig && i == p->nn - 1)) others.push_back(p->sb_n[i]);
+      for (int i = 0; i < p->nk; ++i)
+        if (!(p->b_kcontig && i == p->nk - 1)) others.push_back(p->sb_k[i]);
+      int64_t inner = p->b_kcontig ? p->dim_k[p->nk - 1] : p->dim_n[p->nn - 1];
+      p->vec_b = pick_vec(inner, align_b, es, others);
+    }
+  }
+  {
+    bool n1 = p->nn > 0 && p->sc_n[p->nn - 1] == 1;
+    bool m1 = p->nm > 0 && p->sc_m[p->nm - 1] == 1;
+    p->c_ncontig = (n1 || !m1) ? 1 : 0;
+  }
+
+  // ---- tile shape -----------------------------------------------------------
+  if (p->tile_cfg < 0 || p->tile_cfg > 4) {
+    int cfg;
+    if (d.N <= 16) cfg = 3;
+    else if (d.N <= 32) cfg = 4;
+    else if (d.N <= 48) cfg = 2;
+    else {
+      int64_t big = ((d.M + 127) / 128) * ((d.N + 127) / 128) * d.B;
+      cfg = (big >= 2 * kNumCU) ? 0 : 1;
+    }
+    p->tile_cfg = cfg;
+  }
+  // ---- split-K for launches that cannot fill the chip ------------------------
+  if (p->split_k < 1) {
+    int bm = kTileBM[p->tile_cfg], bn = kTileBN[p->tile_cfg];
+    int64_t tiles = ((d.M + bm - 1) / bm) * ((d.N + bn - 1) / bn) * d.B;
+    int64_t ksteps = (d.K + kBK - 1) / kBK;
+    int64_t s = 1;
+    if (tiles < kNumCU && ksteps >= 8) {
+      s = (2 * kNumCU + tiles - 1) / tiles;
+      s = std::min<int64_t>(s, ksteps / 4);
+      s = std::min<int64_t>(s, 1024);
+      s = std::max<int64_t>(s, 1);
+    }
+    p->split_k = (int32_t)s;
+  }
+  return QAMD_OK;
+}
+
+static int64_t kpad_of(int64_t K) { return ((K + kBK - 1) / kBK) * kBK; }
+
+extern "C" int64_t qamd_pair_ktab_len(const qamd_pair_plan* p) {
+  PairDims d;
+  if (pair_dims(p, d)) return -1;
+  return 2 * kpad_of(d.K);
+}
+
+extern "C" int qamd_pair_build_ktab(const qamd_pair_plan* p, void* ktab, void* stream) {
+  PairDims d;
+  int rc = pair_dims(p, d);
+  if (rc) return rc;
+  KtabArgs a;
+  memset(&a, 0, sizeof(a));
+  a.nk = p->nk;
+  a.K = (uint32_t)d.K;
+  a.Kpad = (uint32_t)kpad_of(d.K);
+  for (int i = 0; i < p->nk; ++i) {
+    a.dim_k[i] = (uint32_t)p->dim_k[i];
+    a.sa_k[i] = p->sa_k[i];
+    a.sb_k[i] = p->sb_k[i];
+  }
+  return qamd_build_ktab_launch(ktab, &a, stream);
+}
+
+static int64_t c_extent(const qamd_pair_plan* p) {
+  int64_t e = 1;
+  for (int i = 0; i < p->nb; ++i) e += (p->dim_b[i] - 1) * p->sc_b[i];
+  for (int i = 0; i < p->nm; ++i) e += (p->dim_m[i] - 1) * p->sc_m[i];
+  for (int i = 0; i < p->nn; ++i) e += (p->dim_n[i] - 1) * p->sc_n[i];
+  return e;
+}
+
+extern "C" int64_t qamd_pair_workspace_bytes(const qamd_pair_plan* p) {
+  PairDims d;
+  if (pair_dims(p, d)) return -1;
+  if (p->split_k <= 1) return 0;
+  return (int64_t)p->split_k * d.B * d.M * d.N * kEsize[p->dtype];
+}
+
+extern "C" int qamd_contract_pair(const qamd_pair_plan* p, const void* A, const void* B, void* C,
+                                  const void* ktab, void* ws, int64_t ws_bytes, void* stream) {
+  PairDims d;
+  int rc = pair_dims(p, d);
+  if (rc) return rc;
+  if (p->dtype != QAMD_F32 && p->dtype != QAMD_F64) return QAMD_EUNSUPPORTED;
+  if (p->tile_cfg < 0 || p->tile_cfg > 4 || p->split_k < 1) return QAMD_EINVAL;
+  if (!A || !B || !C || !ktab) return QAMD_EINVAL;
+  const int bm = kTileBM[p->tile_cfg], bn = kTileBN[p->tile_cfg];
+
+  GettArgs a;
+  memset(&a, 0, sizeof(a));
+  a.nb = p->nb; a.nm = p->nm; a.nn = p->nn; a.nk = p->nk;
+  for (int i = 0; i < p->nb; ++i) {
+    a.dim_b[i] = (uint32_t)p->dim_b[i];
+    a.sa_b[i] = p->sa_b[i]; a.sb_b[i] = p->sb_b[i]; a.sc_b[i] = p->sc_b[i];
+  }
+  for (int i = 0; i < p->nm; ++i) {
+    a.dim_m[i] = (uint32_t)p->dim_m[i];
+    a.sa_m[i] = p->sa_m[i]; a.sc_m[i] = p->sc_m[i];
+  }
+  for (int i = 0; i < p->nn; ++i) {
+    a.dim_n[i] = (uint32_t)p->dim_n[i];
+    a.sb_n[i] = p->sb_n[i]; a.sc_n[i] = p->sc_n[i];
+  }
+  a.B = (uint32_t)d.B; a.M = (uint32_t)d.M; a.N = (uint32_t)d.N; a.K = (uint32_t)d.K;
+  a.Kpad = (uint32_t)kpad_of(d.K);
+  int split = p->split_k;
+  int64_t ksteps = a.Kpad / kBK;
+  if (split > ksteps) split = (int)std::max<int64_t>(ksteps, 1);
+  int64_t steps_per = (ksteps + split - 1) / split;
+  split = (int)((ksteps + steps_per - 1) / steps_per);
+  if (split < 1) split = 1;
+  a.Kc = (uint32_t)(steps_per * kBK);
+  a.split_k = (uint32_t)split;
+  a.tiles_m = (uint32_t)((d.M + bm - 1) / bm);
+  a.tiles_n = (uint32_t)((d.N + bn - 1) / bn);
+  a.vec_a = p->vec_a; a.vec_b = p->vec_b;
+  a.a_kcontig = p->a_kcontig; a.b_kcontig = p->b_kcontig;
+  const int swap = p->c_ncontig ? 0 : 1;
+
+  if (split == 1) {
+    a.slab_stride = 0;
+    return qamd_gett_launch(p->dtype, p->tile_cfg, &a, swap, A, B, C, ktab, stream);
+  }
+  const int64_t csize = d.B * d.M * d.N;
+  if (c_extent(p) != csize) return QAMD_EUNSUPPORTED;  // split-K needs a compact C
+  if (!ws || ws_bytes < (int64_t)split * csize * kEsize[p->dtype]) return QAMD_EWORKSPACE;
+  a.slab_stride = csize;
+  rc = qamd_gett_launch(p->dtype, p->tile_cfg, &a, swap, A, B, ws, ktab, stream);
+  if (rc) return rc;
+  return qamd_splitk_reduce_launch(p->dtype, C, ws, csize, split, stream);
+}
+
+// ---------------------------------------------------------------------------
+// permute
+// ---------------------------------------------------------------------------
+struct Dim { int64_t n, ss, sd; };
+
+static void fuse_dims(std::vector<Dim>& d) {
+  // d in dst order (sd decreasing, contiguous): merge i,i+1 when src agrees
+  std::vector<Dim> out;
+  for (const Dim& x : d) {
+    if (x.n == 1) continue;
+    if (!out.empty() && out.back().ss == x.ss * x.n && out.back().sd == x.sd * x.n) {
+      out.back().n *= x.n;
+      out.back().ss = x.ss;
+      out.back().sd = x.sd;
+    } else {
+      out.push_back(x);
+    }
+  }
+  d.swap(out);
+}
+
+static int fill_bundle(const std::vector<Dim>& v, uint32_t* dim, int64_t* ss, int64_t* sd, int32_t& n, uint32_t& total) {
+  if ((int)v.size() > QAMD_PG) return QAMD_EUNSUPPORTED;
+  int64_t p = 1;
+  n = (int32_t)v.size();
+  for (int i = 0; i < n; ++i) {
+    dim[i] = (uint32_t)v[i].n;
+    ss[i] = v[i].ss;
+    sd[i] = v[i].sd;
+    p *= v[i].n;
+    if (p >= (1ll << 31)) return QAMD_EUNSUPPORTED;
+  }
+  total = (uint32_t)p;
+  return 0;
+}
+
+extern "C" int qamd_permute(void* dst, const void* src, int32_t ndim, const int64_t* shape,
+                            const int64_t* src_strides, int64_t src_offset, int32_t dtype, void* stream) {
+  if (ndim < 0 || ndim > QAMD_MAX_NDIM || dtype < 0 || dtype > 3) return QAMD_EINVAL;
+  if (!dst || !src) return QAMD_EINVAL;
+  std::vector<Dim> d(ndim);
+  int64_t sd = 1;
+  for (int i = ndim - 1; i >= 0; --i) {
+    if (shape[i] < 0) return QAMD_EINVAL;
+    if (shape[i] == 0) return QAMD_OK;
+    d[i] = Dim{shape[i], src_strides[i], sd};
+    sd *= shape[i];
+  }
+  fuse_dims(d);
+  if (d.empty()) d.push_back(Dim{1, 1, 1});
+  const int n = (int)d.size();
+
+  // src-fastest dim
+  int fi = n - 1;
+  for (int i = n - 1; i >= 0; --i)
+    if (std::llabs(d[i].ss) < std::llabs(d[fi].ss)) fi = i;
+
+  std::vector<Dim> X, Y, Z;
+  std::vector<char> used(n, 0);
+  PermArgs a;
+  memset(&a, 0, sizeof(a));
+  if (fi == n - 1) {
+    // direct: trailing dims are fast on both sides
+    int64_t px = 1;
+    int i = n - 1;
+    for (; i >= 0 && px < 256; --i) { X.insert(X.begin(), d[i]); used[i] = 1; px *= d[i].n; }
+    int64_t py = 1;
+    for (; i >= 0 && py < 16; --i) { Y.insert(Y.begin(), d[i]); used[i] = 1; py *= d[i].n; }
+    a.direct = 1;
+    a.TX = (int32_t)std::min<int64_t>(px, 256);
+    a.TY = (int32_t)std::max<int64_t>(1, std::min<int64_t>(py, 4096 / a.TX));
+  } else {
+    int64_t py = 1;
+    for (int i = n - 1; i >= 0 && py < 64 && i != fi; --i) { Y.insert(Y.begin(), d[i]); used[i] = 1; py *= d[i].n; }
+    // remaining dims ordered by |src stride| ascending -> X, innermost = smallest stride
+    std::vector<int> rest;
+    for (int i = 0; i < n; ++i) if (!used[i]) rest.push_back(i);
+    std::sort(rest.begin(), rest.end(), [&](int p, int q) { return std::llabs(d[p].ss) < std::llabs(d[q].ss); });
+    int64_t px = 1;
+    for (int idx : rest) {
+      if (px >= 64) break;
+      X.insert(X.begin(), d[idx]);
+      used[idx] = 1;
+      px *= d[idx].n;
+    }
+    a.direct = 0;
+    a.TX = (int32_t)std::min<int64_t>(px, 64);
+    a.TY = (int32_t)std::min<int64_t>(py, 64);
+  }
+  for (int i = 0; i < n; ++i) if (!used[i]) Z.push_back(d[i]);
+
+  int rc;
+  if ((rc = fill_bundle(X, a.dim_x, a.ss_x, a.sd_x, a.nx, a.X))) return rc;
+  if ((rc = fill_bundle(Y, a.dim_y, a.ss_y, a.sd_y, a.ny, a.Y))) return rc;
+  if ((rc = fill_bundle(Z, a.dim_z, a.ss_z, a.sd_z, a.nz, a.Z))) return rc;
+  a.tiles_x = (a.X + a.TX - 1) / a.TX;
+  a.tiles_y = (a.Y + a.TY - 1) / a.TY;
+  a.src_offset = src_offset;
+  return qamd_permute_launch(kEsize[dtype], dst, src, &a, stream);
+}
+
+// ---------------------------------------------------------------------------
+// strided reduce / binary
+// ---------------------------------------------------------------------------
+extern "C" int qamd_reduce_sum(void* out, const void* x, int32_t ndk, const int64_t* shape_keep,
+                               const int64_t* strides_keep, int32_t ndr, const int64_t* shape_red,
+                               const int64_t* strides_red, int32_t dtype, void* stream) {
+  if (ndk < 0 || ndr < 0 || ndk > QAMD_PG || ndr > QAMD_PG || dtype < 0 || dtype > 3) return QAMD_EINVAL;
+  ReduceArgs a;
+  memset(&a, 0, sizeof(a));
+  int64_t nk = 1, nr = 1;
+  for (int i = 0; i < ndk; ++i) {
+    if (shape_keep[i] <= 0) return shape_keep[i] == 0 ? QAMD_OK : QAMD_EINVAL;
+    a.dim_keep[i] = (uint32_t)shape_keep[i];
+    a.s_keep[i] = strides_keep[i];
+    nk *= shape_keep[i];
+  }
+  for (int i = 0; i < ndr; ++i) {
+    if (shape_red[i] <= 0) return QAMD_EINVAL;
+    a.dim_red[i] = (uint32_t)shape_red[i];
+    a.s_red[i] = strides_red[i];
+    nr *= shape_red[i];
+  }
+  if (nk >= (1ll << 31) || nr >= (1ll << 31)) return QAMD_EUNSUPPORTED;
+  a.nd_keep = ndk; a.nd_red = ndr;
+  a.n_keep = (uint32_t)nk; a.n_red = (uint32_t)nr;
+  a.wave_per_out = (nr >= 256 || nk < 4096) ? 1 : 0;
+  return qamd_reduce_sum_launch(dtype, out, x, &a, stream);
+}
+
+extern "C" int qamd_binary(void* out, const void* x, const int64_t* xs, const void* y, const int64_t* ys,
+                           int32_t ndim, const int64_t* shape, int32_t op, int32_t dtype, void* stream) {
+  if (ndim < 0 || ndim > QAMD_MAX_NDIM || dtype < 0 || dtype > 3 || op < 0 || op > 2) return QAMD_EINVAL;
+  // fuse adjacent dims where both operands allow it
+  struct D3 { int64_t n, sa, sb; };
+  std::vector<D3> v;
+  int64_t total = 1;
+  for (int i = 0; i < ndim; ++i) {
+    if (shape[i] < 0) return QAMD_EINVAL;
+    if (shape[i] == 0) return QAMD_OK;
+    total *= shape[i];
+    if (shape[i] == 1) continue;
+    D3 cur{shape[i], xs[i], ys[i]};
+    if (!v.empty() && v.back().sa == cur.sa * cur.n && v.back().sb == cur.sb * cur.n) {
+      v.back().n *= cur.n; v.back().sa = cur.sa; v.back().sb = cur.sb;
+    } else v.push_back(cur);
+  }
+  if ((int)v.size() > QAMD_PG) return QAMD_EUNSUPPORTED;
+  BinaryArgs a;
+  memset(&a, 0, sizeof(a));
+  a.nd = (int32_t)v.size();
+  a.op = op;
+  a.n = total;
+  for (int i = 0; i < a.nd; ++i) { a.dim[i] = v[i].n; a.sa[i] = v[i].sa; a.sb[i] = v[i].sb; }
+  return qamd_binary_launch(dtype, out, x, y, &a, stream);
+}

@@ -1,0 +1,38 @@
+// Kernel-argument blocks shared by gett.hip (device) and api.cpp (host planner).
+#pragma once
+#include <stdint.h>
+
+#define QAMD_G 8
+
+struct GettArgs {
+  int32_t nb, nm, nn, nk;
+  uint32_t dim_b[QAMD_G], dim_m[QAMD_G], dim_n[QAMD_G];
+  int64_t sa_b[QAMD_G], sb_b[QAMD_G], sc_b[QAMD_G];
+  int64_t sa_m[QAMD_G], sc_m[QAMD_G];
+  int64_t sb_n[QAMD_G], sc_n[QAMD_G];
+  uint32_t B, M, N, K;
+  uint32_t Kpad;  // K rounded up to the k-tile
+  uint32_t Kc;    // k range per split (multiple of the k-tile)
+  uint32_t tiles_m, tiles_n, split_k;
+  int32_t vec_a, vec_b, a_kcontig, b_kcontig;
+  int64_t slab_stride;  // elements between split-K slabs
+};
+
+struct KtabArgs {
+  int32_t nk;
+  uint32_t K, Kpad;
+  uint32_t dim_k[QAMD_G];
+  int64_t sa_k[QAMD_G], sb_k[QAMD_G];
+};
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+int qamd_gett_launch(int dtype, int cfg, const GettArgs* a, int swap, const void* A, const void* B,
+                     void* C, const void* ktab, void* stream);
+void qamd_gett_tile_dims(int cfg, int* bm, int* bn, int* bk);
+int qamd_splitk_reduce_launch(int dtype, void* C, const void* ws, int64_t n, int split_k, void* stream);
+int qamd_build_ktab_launch(void* ktab, const KtabArgs* a, void* stream);
+#ifdef __cplusplus
+}
+#endif

@@ -1,0 +1,248 @@
+"""Device layer: the only module that touches ``libquimb_amd.so`` and torch.
+
+``HipDevice`` owns nothing but caches: device memory comes from torch's ROCm
+allocator (plumbing, per the design brief), every arithmetic / layout operation
+is a call through the C-ABI in ``include/quimb_amd.h`` on torch's current HIP
+stream.  There is deliberately no CPU implementation here -- constructing the
+default device without the HIP library or without a GPU raises.
+"""
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _lib
+from .pairwise import GettSpec
+
+_DT_CODE = {
+    np.dtype("float32"): _lib.QAMD_F32,
+    np.dtype("float64"): _lib.QAMD_F64,
+    np.dtype("complex64"): _lib.QAMD_C64,
+    np.dtype("complex128"): _lib.QAMD_C128,
+}
+
+
+def dtype_code(dtype):
+    try:
+        return _DT_CODE[np.dtype(dtype)]
+    except KeyError:
+        raise TypeError(f"quimb_amd supports float32/float64/complex64/complex128, got {dtype}") from None
+
+
+def _i64arr(xs):
+    xs = [int(x) for x in xs]
+    return (C.c_int64 * max(len(xs), 1))(*xs)
+
+
+def fill_plan_struct(spec: GettSpec, code: int):
+    """GettSpec -> ``qamd_pair_plan`` (unfinalised)."""
+    p = _lib.PairPlanStruct()
+    p.dtype = code
+    p.nb, p.nm, p.nn, p.nk = len(spec.b), len(spec.m), len(spec.n), len(spec.k)
+    for i, (d, sa, sb, sc) in enumerate(spec.b):
+        p.dim_b[i], p.sa_b[i], p.sb_b[i], p.sc_b[i] = d, sa, sb, sc
+    for i, (d, sa, _, sc) in enumerate(spec.m):
+        p.dim_m[i], p.sa_m[i], p.sc_m[i] = d, sa, sc
+    for i, (d, _, sb, sc) in enumerate(spec.n):
+        p.dim_n[i], p.sb_n[i], p.sc_n[i] = d, sb, sc
+    for i, (d, sa, sb, _) in enumerate(spec.k):
+        p.dim_k[i], p.sa_k[i], p.sb_k[i] = d, sa, sb
+    p.tile_cfg = -1
+    p.split_k = 0
+    return p
+
+
+class _CompiledPair:
+    __slots__ = ("struct", "ktab", "ws_bytes")
+
+
+class HipDevice:
+    """MI355X device: torch-ROCm memory + hand-written HIP kernels via ctypes."""
+
+    name = "hip"
+
+    def __init__(self, index=None):
+        self.lib = _lib.load()
+        import torch
+
+        self.torch = torch
+        if not torch.cuda.is_available():
+            raise _lib.QamdError(
+                "quimb_amd: no HIP device visible (torch.cuda.is_available() is False); "
+                "the contraction backend has no CPU fallback"
+            )
+        if index is None:
+            index = torch.cuda.current_device()
+        self.index = index
+        self.tdev = torch.device("cuda", index)
+        self._tdt = {
+            np.dtype("float32"): torch.float32,
+            np.dtype("float64"): torch.float64,
+            np.dtype("complex64"): torch.complex64,
+            np.dtype("complex128"): torch.complex128,
+            np.dtype("int64"): torch.int64,
+        }
+        self._pairs = {}
+        self._ws = None
+        self._scratch = torch.zeros(4, dtype=torch.float64, device=self.tdev)
+        self.force_tile_cfg = int(os.environ.get("QAMD_TILE_CFG", "-1"))
+        self.force_split_k = int(os.environ.get("QAMD_SPLIT_K", "0"))
+
+    # ---- memory ---------------------------------------------------------
+    def empty(self, n, dtype):
+        return self.torch.empty(max(int(n), 1), dtype=self._tdt[np.dtype(dtype)], device=self.tdev)
+
+    def from_host(self, x):
+        x = np.ascontiguousarray(x)
+        t = self.torch.from_numpy(x.reshape(-1) if x.size else np.zeros(1, x.dtype))
+        return t.to(self.tdev)
+
+    def to_host(self, buf, n, dtype):
+        return buf[: max(int(n), 0)].cpu().numpy().astype(np.dtype(dtype), copy=False)
+
+    def clone(self, buf):
+        return buf.clone()
+
+    def ptr(self, buf):
+        return buf.data_ptr()
+
+    def stream(self):
+        return self.torch.cuda.current_stream(self.tdev).cuda_stream
+
+    def synchronize(self):
+        self.torch.cuda.synchronize(self.tdev)
+
+    def _workspace(self, nbytes):
+        if nbytes <= 0:
+            return None, 0
+        if self._ws is None or self._ws.numel() < nbytes:
+            self._ws = self.torch.empty(int(nbytes), dtype=self.torch.uint8, device=self.tdev)
+        return self._ws.data_ptr(), self._ws.numel()
+
+    # ---- pairwise contraction ---------------------------------------------
+    def compile_pair(self, spec, dtype, align_a=16, align_b=16):
+        code = dtype_code(dtype)
+        key = (spec, code, align_a, align_b, self.force_tile_cfg, self.force_split_k)
+        cp = self._pairs.get(key)
+        if cp is not None:
+            return cp
+        p = fill_plan_struct(spec, code)
+        p.tile_cfg = self.force_tile_cfg
+        p.split_k = self.force_split_k
+        _lib.check(self.lib.qamd_pair_plan_finalize(C.byref(p), align_a, align_b), "qamd_pair_plan_finalize")
+        klen = self.lib.qamd_pair_ktab_len(C.byref(p))
+        ktab = self.torch.empty(int(klen), dtype=self.torch.int64, device=self.tdev)
+        _lib.check(
+            self.lib.qamd_pair_build_ktab(C.byref(p), ktab.data_ptr(), self.stream()), "qamd_pair_build_ktab"
+        )
+        cp = _CompiledPair()
+        cp.struct = p
+        cp.ktab = ktab
+        cp.ws_bytes = int(self.lib.qamd_pair_workspace_bytes(C.byref(p)))
+        self._pairs[key] = cp
+        return cp
+
+    def contract_pair(self, spec, dtype, a, b, c):
+        pa, pb = a.data_ptr(), b.data_ptr()
+        cp = self.compile_pair(spec, dtype, min(pa & -pa, 16), min(pb & -pb, 16))
+        ws, wsn = self._workspace(cp.ws_bytes)
+        _lib.check(
+            self.lib.qamd_contract_pair(
+                C.byref(cp.struct), pa, pb, c.data_ptr(), cp.ktab.data_ptr(), ws, wsn, self.stream()
+            ),
+            "qamd_contract_pair",
+        )
+
+    # ---- layout / elementwise -----------------------------------------------
+    def permute(self, dst, src, shape, strides, offset, dtype):
+        nd = len(shape)
+        _lib.check(
+            self.lib.qamd_permute(
+                dst.data_ptr(), src.data_ptr(), nd, _i64arr(shape), _i64arr(strides), int(offset),
+                dtype_code(dtype), self.stream(),
+            ),
+            "qamd_permute",
+        )
+
+    def reduce_sum(self, out, x, keep_shape, keep_strides, red_shape, red_strides, dtype):
+        _lib.check(
+            self.lib.qamd_reduce_sum(
+                out.data_ptr(), x.data_ptr(), len(keep_shape), _i64arr(keep_shape), _i64arr(keep_strides),
+                len(red_shape), _i64arr(red_shape), _i64arr(red_strides), dtype_code(dtype), self.stream(),
+            ),
+            "qamd_reduce_sum",
+        )
+
+    def binary(self, out, a, a_strides, b, b_strides, shape, op, dtype):
+        _lib.check(
+            self.lib.qamd_binary(
+                out.data_ptr(), a.data_ptr(), _i64arr(a_strides), b.data_ptr(), _i64arr(b_strides),
+                len(shape), _i64arr(shape), {"add": 0, "mul": 1, "sub": 2}[op], dtype_code(dtype), self.stream(),
+            ),
+            "qamd_binary",
+        )
+
+    def scale(self, x, n, factor, dtype):
+        f = complex(factor)
+        _lib.check(self.lib.qamd_scale(x.data_ptr(), int(n), f.real, f.imag, dtype_code(dtype), self.stream()), "qamd_scale")
+
+    def axpby(self, y, x, n, fy, fx, dtype):
+        _lib.check(
+            self.lib.qamd_axpby(y.data_ptr(), x.data_ptr(), int(n), float(fy), float(fx), dtype_code(dtype), self.stream()),
+            "qamd_axpby",
+        )
+
+    def conj(self, dst, src, n, dtype):
+        _lib.check(self.lib.qamd_conj(dst.data_ptr(), src.data_ptr(), int(n), dtype_code(dtype), self.stream()), "qamd_conj")
+
+    def cast(self, dst, dst_dtype, src, src_dtype, n):
+        _lib.check(
+            self.lib.qamd_cast(dst.data_ptr(), dtype_code(dst_dtype), src.data_ptr(), dtype_code(src_dtype), int(n), self.stream()),
+            "qamd_cast",
+        )
+
+    def fill(self, dst, n, value, dtype):
+        v = complex(value)
+        _lib.check(self.lib.qamd_fill(dst.data_ptr(), int(n), v.real, v.imag, dtype_code(dtype), self.stream()), "qamd_fill")
+
+    # ---- exponent stripping ---------------------------------------------------
+    def new_exponent(self):
+        """Device-resident float64 accumulator for log10 factors."""
+        return self.torch.zeros(1, dtype=self.torch.float64, device=self.tdev)
+
+    def strip_exponent(self, x, n, dtype, exponent):
+        _lib.check(
+            self.lib.qamd_strip_exponent(
+                x.data_ptr(), int(n), dtype_code(dtype), self._scratch.data_ptr(), exponent.data_ptr(), self.stream()
+            ),
+            "qamd_strip_exponent",
+        )
+
+    def read_exponent(self, exponent):
+        return float(exponent.cpu()[0])
+
+    def absmax(self, x, n, dtype):
+        _lib.check(
+            self.lib.qamd_absmax(self._scratch.data_ptr() + 16, x.data_ptr(), int(n), dtype_code(dtype), self.stream()),
+            "qamd_absmax",
+        )
+        return float(self._scratch.cpu()[2])
+
+
+_DEFAULT = None
+
+
+def default_device():
+    """The process-wide device (``cuda:LOCAL_RANK`` under torchrun)."""
+    global _DEFAULT
+    if _DEFAULT is None:
+        _DEFAULT = HipDevice()
+    return _DEFAULT
+
+
+def set_default_device(dev):
+    """Install a device object (used by the test-suite to inject its numpy plan
+    interpreter; the product never calls this with anything but HipDevice)."""
+    global _DEFAULT
+    _DEFAULT = dev

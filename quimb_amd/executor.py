@@ -1,0 +1,229 @@
+"""Whole-tree executor: device-resident evaluation of a contraction tree.
+
+This is the MI355X replacement for the per-step python loop inside
+``cotengra.array_contract`` that quimb calls at quimb/tensor/contraction.py:285
+(hot loop described in SURVEY.md section 3.1).  Differences by design:
+
+* the executor owns every intermediate, so it *chooses* each intermediate's
+  index order such that the next contraction needs no permute (the result takes
+  the big operand's layout with the contracted run replaced by the small
+  operand's free indices) -- the reference materialises a transpose per step;
+* the final step writes straight into the requested output order;
+* ``strip_exponent`` (quimb/tensor/tensor_core.py:330-340) runs entirely on the
+  device: per-step max|x| and the log10 accumulator never visit the host;
+* sliced indices (cotengra ``tree.sliced_inds``) are executed as independent
+  slices whose outputs sum to the result; sub-trees that do not depend on any
+  sliced index are evaluated once and reused by every slice.
+"""
+
+import numpy as np
+
+from .array import Array, asarray, _coerce_dtype
+from .ops import _einsum_single, run_pair_step
+from .pairwise import plan_pair, prod
+from .tree import ContractionTree
+
+
+class StepInfo:
+    __slots__ = ("kind", "mults", "bytes", "M", "N", "K", "B", "sliced_dep")
+
+    def __init__(self, kind, mults, nbytes, dims, dep):
+        self.kind, self.mults, self.bytes = kind, mults, nbytes
+        self.B, self.M, self.N, self.K = dims
+        self.sliced_dep = dep
+
+
+class TreeExecutor:
+    """Plan once, run many times (the analogue of a cached cotengra expression,
+    pinned by tests/test_tensor/test_contract.py:155-172 in the reference)."""
+
+    def __init__(self, tree: ContractionTree, dtype="float32"):
+        self.tree = tree
+        self.dtype = _coerce_dtype(dtype)
+        size = tree.size_dict
+        sliced = set(tree.sliced_inds)
+        n = len(tree.inputs)
+        self.input_inds = [tuple(ix for ix in t if ix not in sliced) for t in tree.inputs]
+        self.input_sliced_axes = [
+            tuple((ax, ix) for ax, ix in enumerate(t) if ix in sliced) for t in tree.inputs
+        ]
+        layout = {i: self.input_inds[i] for i in range(n)}
+        dep = {i: bool(self.input_sliced_axes[i]) for i in range(n)}
+        death = tree.death_times()
+        self.plan = []
+        self.info = []
+        nsteps = len(tree.steps)
+        isz = self.dtype.itemsize
+        for si, (con, res, ops, keep, _) in enumerate(tree.steps):
+            last = si == nsteps - 1 and len(tree.remaining) == 1
+            if len(con) == 1:
+                src = layout[con[0]]
+                out = tuple(tree.output) if last else tuple(keep)
+                self.plan.append(("single", con[0], res, src, out))
+                layout[res] = out
+                dep[res] = dep[con[0]]
+                m = prod(size[ix] for ix in set(src))
+                self.info.append(StepInfo("single", 0, isz * (m + prod(size[ix] for ix in out)), (1, 1, 1, 1), dep[res]))
+                continue
+            if len(con) != 2:
+                raise ValueError("only pairwise (or single-operand) contraction steps are supported")
+            a, b = con
+            la, lb = layout[a], layout[b]
+            sa = tuple(size[ix] for ix in la)
+            sb = tuple(size[ix] for ix in lb)
+            if last:
+                step = plan_pair(la, sa, lb, sb, tuple(tree.output), True, None)
+            else:
+                d = tuple(sorted(death.get(res, {}).items(), key=repr))
+                step = plan_pair(la, sa, lb, sb, tuple(keep), False, d)
+            self.plan.append(("pair", a, b, res, step))
+            layout[res] = step.out_inds
+            dep[res] = dep[a] or dep[b]
+            if step.kind == "gett":
+                g = step.spec
+                dims = (g.B, g.M, g.N, g.K)
+                nbytes = isz * g.B * (g.M * g.K + g.K * g.N + g.M * g.N)
+            else:
+                dims = (prod(step.out_shape), 1, 1, 1)
+                nbytes = isz * 3 * prod(step.out_shape)
+            self.info.append(StepInfo(step.kind, step.mults, nbytes, dims, dep[res]))
+        self.layout = layout
+        self.dep = dep
+        if len(tree.remaining) != 1:
+            raise ValueError("contraction path does not reduce the network to a single tensor")
+        (self.root,) = tree.remaining
+        self.out_inds = layout[self.root]
+        if n == 1 and not tree.steps:
+            self.out_inds = tuple(tree.output)
+        self._hoisted = None  # cache of slice-independent intermediates for the current inputs
+
+    # ---- accounting -------------------------------------------------------------
+    def flops(self, per_slice=False, hoist=True):
+        """Floating-point operations actually executed (2 per real multiply-add,
+        8 per complex).  With ``hoist`` slice-independent steps count once."""
+        f = 8 if self.dtype.kind == "c" else 2
+        ns = 1 if per_slice else self.tree.nslices
+        tot = 0
+        for inf in self.info:
+            rep = ns if (inf.sliced_dep or not hoist) else 1
+            tot += f * inf.mults * rep
+        return tot
+
+    def algorithmic_bytes(self, hoist=True):
+        ns = self.tree.nslices
+        return sum(inf.bytes * (ns if (inf.sliced_dep or not hoist) else 1) for inf in self.info)
+
+    # ---- execution ----------------------------------------------------------------
+    def _slice_values(self, s):
+        vals = {}
+        for ix in reversed(self.tree.sliced_inds):
+            d = self.tree.size_dict[ix]
+            vals[ix] = s % d
+            s //= d
+        return vals
+
+    def _slice_input(self, x, i, vals):
+        axes = self.input_sliced_axes[i]
+        if not axes:
+            return x
+        key = [slice(None)] * x.ndim
+        for ax, ix in axes:
+            key[ax] = vals[ix]
+        return x[tuple(key)]
+
+    def _run_core(self, inputs, exponent, cache, only_independent=False):
+        """Evaluate the tree for one slice.  ``cache`` maps ssa id -> Array for
+        slice-independent intermediates (filled on first use)."""
+        dev = inputs[0]._dev
+        live = dict(enumerate(inputs))
+        uses = {}
+        for entry in self.plan:
+            ids = (entry[1],) if entry[0] == "single" else (entry[1], entry[2])
+            for s in ids:
+                uses[s] = uses.get(s, 0) + 1
+        for entry in self.plan:
+            if entry[0] == "single":
+                _, a, res, src, out = entry
+                independent = not self.dep[res]
+                if independent and cache is not None and res in cache:
+                    live[res] = cache[res]
+                elif only_independent and not independent:
+                    continue
+                else:
+                    live[res] = _einsum_single(live[a], src, out)
+                    if independent and cache is not None:
+                        cache[res] = live[res]
+                ids = (a,)
+            else:
+                _, a, b, res, step = entry
+                independent = not self.dep[res]
+                if independent and cache is not None and res in cache:
+                    live[res] = cache[res]
+                elif only_independent and not independent:
+                    continue
+                else:
+                    x = run_pair_step(step, live[a], live[b])
+                    if exponent is not None and x.size:
+                        dev.strip_exponent(x._buf, x.size, x.dtype, exponent)
+                    live[res] = x
+                    if independent and cache is not None:
+                        cache[res] = x
+                ids = (a, b)
+            for s in ids:
+                uses[s] -= 1
+                if uses[s] == 0:
+                    live.pop(s, None)
+        return live.get(self.root)
+
+    def __call__(self, arrays, strip_exponent=False, slices=None, hoist=True):
+        """Contract.  ``slices``: iterable of slice numbers to evaluate (default
+        all); the partial sum over exactly those slices is returned, which is what
+        a rank of the multi-GPU driver needs before the RCCL reduce.
+
+        Returns an ``Array`` (or ``(Array, exponent)`` if ``strip_exponent``)."""
+        tree = self.tree
+        if len(arrays) != len(tree.inputs):
+            raise ValueError(f"expected {len(tree.inputs)} arrays, got {len(arrays)}")
+        xs = [asarray(x).astype(self.dtype) for x in arrays]
+        for x, t in zip(xs, tree.inputs):
+            want = tuple(tree.size_dict[ix] for ix in t)
+            if x.shape != want:
+                raise ValueError(f"array shape {x.shape} does not match indices {t} with sizes {want}")
+        dev = xs[0]._dev
+        nsl = tree.nslices
+        if not tree.steps:
+            out = _einsum_single(xs[0], self.input_inds[0], tuple(tree.output))
+            return (out, 0.0) if strip_exponent else out
+        if nsl == 1:
+            exponent = dev.new_exponent() if strip_exponent else None
+            out = self._run_core(xs, exponent, None)
+            if strip_exponent:
+                return out, dev.read_exponent(exponent)
+            return out
+
+        todo = range(nsl) if slices is None else list(slices)
+        cache = {} if (hoist and not strip_exponent) else None
+        acc, acc_e = None, None
+        for s in todo:
+            vals = self._slice_values(s)
+            ins = [self._slice_input(x, i, vals) for i, x in enumerate(xs)]
+            if strip_exponent:
+                exponent = dev.new_exponent()
+                out = self._run_core(ins, exponent, None)
+                e = dev.read_exponent(exponent)
+                if acc is None:
+                    acc, acc_e = out.copy() if out is ins[0] else out, e
+                else:
+                    e_new = max(acc_e, e)
+                    dev.axpby(acc._buf, out._buf, acc.size, 10.0 ** (acc_e - e_new), 10.0 ** (e - e_new), acc.dtype)
+                    acc_e = e_new
+            else:
+                out = self._run_core(ins, None, cache)
+                if acc is None:
+                    acc = out.copy() if (cache is not None and self.root in cache) else out
+                else:
+                    dev.axpby(acc._buf, out._buf, acc.size, 1.0, 1.0, acc.dtype)
+        if acc is None:  # this rank owns no slices
+            acc = Array.full([tree.size_dict[ix] for ix in tree.output], 0.0, self.dtype, dev)
+            acc_e = float("-inf") if strip_exponent else None
+        return (acc, acc_e) if strip_exponent else acc

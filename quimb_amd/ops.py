@@ -1,0 +1,358 @@
+"""Module-level L0 array functions -- the surface quimb's ``do(name, ...,
+like="quimb_amd")`` resolves to.
+
+``tensordot`` / ``einsum`` / ``matmul`` run on the GETT kernel with the operand
+permutes folded into addressing; ``transpose`` / ``fuse`` / ``take`` use the
+tiled permute kernel; ``reshape`` is free.  Reference call sites:
+quimb/tensor/tensor_core.py:3793 (``do("tensordot")``), :3152-3159
+(``Tensor.gate``), quimb/tensor/array_ops.py:148-182 (``fuse``),
+tensor_core.py:2332 (``take``).
+"""
+
+import numbers
+
+import numpy as np
+
+from .array import Array, asarray, _coerce_dtype, _REAL_OF
+from .pairwise import (
+    BinarySpec,
+    PermuteSpec,
+    ReduceSpec,
+    contig_strides,
+    parse_einsum,
+    plan_pair,
+    prod,
+    tensordot_inds,
+)
+
+
+def _common(a, b):
+    a, b = asarray(a), asarray(b)
+    dt = _coerce_dtype(np.result_type(a.dtype, b.dtype))
+    return a.astype(dt), b.astype(dt), dt
+
+
+def _apply_pre(x, ops):
+    """Run the single-operand preprocessing a PairStep asks for."""
+    dev = x._dev
+    for op in ops:
+        if isinstance(op, ReduceSpec):
+            out = Array.empty(op.keep_shape, x.dtype, dev)
+            if out.size:
+                dev.reduce_sum(out._buf, x._buf, op.keep_shape, op.keep_strides, op.red_shape, op.red_strides, x.dtype)
+            x = out
+        elif isinstance(op, PermuteSpec):
+            out = Array.empty(op.shape, x.dtype, dev)
+            if out.size:
+                dev.permute(out._buf, x._buf, op.shape, op.strides, 0, x.dtype)
+            x = out
+        else:  # pragma: no cover
+            raise TypeError(op)
+    return x
+
+
+def run_pair_step(step, a, b, out=None):
+    """Execute a planned pairwise step on device arrays of a common dtype."""
+    a = _apply_pre(a, step.pre[0])
+    b = _apply_pre(b, step.pre[1])
+    dev = a._dev
+    if out is None:
+        out = Array.empty(step.out_shape, a.dtype, dev)
+    if out.size == 0:
+        return out
+    if step.kind == "binary":
+        s = step.spec
+        dev.binary(out._buf, a._buf, s.sa, b._buf, s.sb, s.shape, "mul", a.dtype)
+        return out
+    ka, kb = (b, a) if step.swapped else (a, b)
+    if a.dtype.kind == "c":
+        _complex_gett(dev, step.spec, ka, kb, out)
+    else:
+        dev.contract_pair(step.spec, a.dtype, ka._buf, kb._buf, out._buf)
+    return out
+
+
+def _complex_gett(dev, spec, ka, kb, out):
+    dev.contract_pair(spec, ka.dtype, ka._buf, kb._buf, out._buf)
+
+
+def einsum_pair(a, a_inds, b, b_inds, out_inds, out_fixed=True, death=None):
+    """``einsum`` of two operands with arbitrary hashable index labels.
+    Returns (array, out_inds)."""
+    a, b, _ = _common(a, b)
+    step = plan_pair(tuple(a_inds), a.shape, tuple(b_inds), b.shape, tuple(out_inds), out_fixed, death)
+    return run_pair_step(step, a, b), step.out_inds
+
+
+def tensordot(a, b, axes=2):
+    """numpy-semantics ``tensordot`` (output = free axes of a, then of b)."""
+    a, b, _ = _common(a, b)
+    ai, bi, oi = tensordot_inds(a.ndim, b.ndim, axes)
+    out, _ = einsum_pair(a, ai, b, bi, oi, True)
+    return out
+
+
+def matmul(a, b):
+    a, b, _ = _common(a, b)
+    if a.ndim == 0 or b.ndim == 0:
+        raise ValueError("matmul: input operand does not have enough dimensions")
+    if a.ndim == 1 and b.ndim == 1:
+        return tensordot(a, b, 1)
+    if a.ndim == 1:
+        return matmul(a.reshape(1, -1), b).reshape(b.shape[:-2] + b.shape[-1:])
+    if b.ndim == 1:
+        return matmul(a, b.reshape(-1, 1)).reshape(a.shape[:-1])
+    # broadcast batch dims
+    ba, bb = a.shape[:-2], b.shape[:-2]
+    bshape = np.broadcast_shapes(ba, bb)
+    nb = len(bshape)
+    a_inds = [("B", nb - len(ba) + i) if d != 1 or bshape[nb - len(ba) + i] == 1 else ("a1", i) for i, d in enumerate(ba)]
+    b_inds = [("B", nb - len(bb) + i) if d != 1 or bshape[nb - len(bb) + i] == 1 else ("b1", i) for i, d in enumerate(bb)]
+    a_inds += ["m", "k"]
+    b_inds += ["k", "n"]
+    if any(isinstance(i, tuple) and i[0] in ("a1", "b1") for i in a_inds + b_inds):
+        # size-1 broadcast dims: drop them via reshape, then restore
+        a2 = a.reshape([d for d, ix in zip(a.shape, a_inds) if not (isinstance(ix, tuple) and ix[0] == "a1")])
+        b2 = b.reshape([d for d, ix in zip(b.shape, b_inds) if not (isinstance(ix, tuple) and ix[0] == "b1")])
+        a_inds = [ix for ix in a_inds if not (isinstance(ix, tuple) and ix[0] == "a1")]
+        b_inds = [ix for ix in b_inds if not (isinstance(ix, tuple) and ix[0] == "b1")]
+        a, b = a2, b2
+    out_inds = [("B", i) for i in range(nb)] + ["m", "n"]
+    out, _ = einsum_pair(a, a_inds, b, b_inds, out_inds, True)
+    return out
+
+
+dot = matmul
+
+
+def einsum(eq, *operands, **kwargs):
+    """numpy-style ``einsum`` for one or two operands (what cotengra's executor
+    issues per step); more operands go through the tree executor."""
+    if not isinstance(eq, str):
+        raise TypeError("einsum: interleaved format is not supported")
+    ops = [asarray(x) for x in operands]
+    inputs, output = parse_einsum(eq, len(ops))
+    if len(ops) == 1:
+        return _einsum_single(ops[0], inputs[0], output)
+    if len(ops) == 2:
+        out, _ = einsum_pair(ops[0], inputs[0], ops[1], inputs[1], output, True)
+        return out
+    from .contract import array_contract
+
+    return array_contract(ops, inputs, output)
+
+
+def _einsum_single(x, inds, out_inds):
+    """Single-operand einsum: diagonals (repeated labels), sums, permutation."""
+    from .pairwise import _view
+
+    v = _view(inds, x.shape)
+    sz = dict(zip(v.inds, v.shape))
+    st = dict(zip(v.inds, v.strides))
+    for ix in out_inds:
+        if ix not in sz:
+            raise ValueError(f"einsum: output index {ix!r} not in input")
+    if len(set(out_inds)) != len(out_inds):
+        raise ValueError("einsum: repeated output index")
+    red = [ix for ix in v.inds if ix not in out_inds]
+    oshape = [sz[ix] for ix in out_inds]
+    ostr = [st[ix] for ix in out_inds]
+    out = Array.empty(oshape, x.dtype, x._dev)
+    if not out.size:
+        return out
+    if red:
+        x._dev.reduce_sum(out._buf, x._buf, oshape, ostr, [sz[ix] for ix in red], [st[ix] for ix in red], x.dtype)
+    else:
+        x._dev.permute(out._buf, x._buf, oshape, ostr, 0, x.dtype)
+    return out
+
+
+# ---- layout ---------------------------------------------------------------
+def transpose(x, axes=None):
+    x = asarray(x)
+    return x.transpose() if axes is None else x.transpose(axes)
+
+
+def reshape(x, shape):
+    return asarray(x).reshape(shape)
+
+
+def ravel(x):
+    return asarray(x).ravel()
+
+
+def fuse(x, *axes_groups):
+    """Index fusion in ONE permute pass: same semantics as the reference's
+    composed ``fuse`` (quimb/tensor/array_ops.py:95-182): each group of axes is
+    fused into a single axis placed at the position of the group's minimum axis,
+    groups in the order given, unfused axes keep their relative order."""
+    x = asarray(x)
+    groups = [tuple(int(a) % x.ndim for a in g) for g in axes_groups]
+    if not any(groups):
+        return x
+    in_group = {a for g in groups for a in g}
+    position = min(in_group)
+    before = [ax for ax in range(position) if ax not in in_group]
+    after = [ax for ax in range(position, x.ndim) if ax not in in_group]
+    perm = before + [ax for g in groups for ax in g] + after
+    new_shape = (
+        [x.shape[a] for a in before] + [prod(x.shape[a] for a in g) for g in groups] + [x.shape[a] for a in after]
+    )
+    return x.transpose(perm).reshape(new_shape)
+
+
+def take(x, indices, axis=None):
+    x = asarray(x)
+    if axis is None:
+        x = x.ravel()
+        axis = 0
+    axis = int(axis) % x.ndim
+    if isinstance(indices, numbers.Integral):
+        key = [slice(None)] * x.ndim
+        key[axis] = int(indices)
+        return x[tuple(key)]
+    idx = [int(i) for i in np.asarray(indices).reshape(-1)]
+    parts = []
+    for i in idx:
+        key = [slice(None)] * x.ndim
+        key[axis] = slice(i, i + 1) if i != -1 else slice(i, None)
+        parts.append(x[tuple(key)])
+    return concatenate(parts, axis=axis)
+
+
+def concatenate(arrays, axis=0):
+    arrays = [asarray(a) for a in arrays]
+    if len(arrays) == 1:
+        return arrays[0]
+    host = np.concatenate([a.to_numpy() for a in arrays], axis=axis)  # rare, off the hot path
+    return Array.from_numpy(host, dev=arrays[0]._dev)
+
+
+def squeeze(x, axis=None):
+    x = asarray(x)
+    if axis is None:
+        return x.reshape([d for d in x.shape if d != 1])
+    axes = {a % x.ndim for a in ((axis,) if isinstance(axis, numbers.Integral) else axis)}
+    return x.reshape([d for i, d in enumerate(x.shape) if i not in axes])
+
+
+def expand_dims(x, axis):
+    x = asarray(x)
+    shape = list(x.shape)
+    shape.insert(axis % (x.ndim + 1), 1)
+    return x.reshape(shape)
+
+
+# ---- elementwise / reductions ------------------------------------------------
+def multiply(a, b):
+    if isinstance(a, numbers.Number):
+        return asarray(b) * a
+    return asarray(a) * b
+
+
+def add(a, b):
+    return asarray(a) + b
+
+
+def subtract(a, b):
+    return asarray(a) - b
+
+
+def true_divide(a, b):
+    return asarray(a) / b
+
+
+divide = true_divide
+
+
+def negative(x):
+    return -asarray(x)
+
+
+def conj(x):
+    return asarray(x).conj()
+
+
+conjugate = conj
+
+
+def real(x):
+    return asarray(x).real
+
+
+def imag(x):
+    return asarray(x).imag
+
+
+def astype(x, dtype):
+    return asarray(x).astype(dtype)
+
+
+def sum(x, axis=None):
+    x = asarray(x)
+    if axis is None:
+        axes = tuple(range(x.ndim))
+    elif isinstance(axis, numbers.Integral):
+        axes = (int(axis) % x.ndim,)
+    else:
+        axes = tuple(int(a) % x.ndim for a in axis)
+    st = contig_strides(x.shape)
+    keep = [i for i in range(x.ndim) if i not in axes]
+    out = Array.empty([x.shape[i] for i in keep], x.dtype, x._dev)
+    if out.size:
+        if x.size == 0:
+            x._dev.fill(out._buf, out.size, 0.0, out.dtype)
+        else:
+            x._dev.reduce_sum(
+                out._buf, x._buf, [x.shape[i] for i in keep], [st[i] for i in keep],
+                [x.shape[i] for i in axes], [st[i] for i in axes], x.dtype,
+            )
+    return out
+
+
+def trace(x):
+    x = asarray(x)
+    return _einsum_single(x, ("i", "i"), ())
+
+
+def absmax(x):
+    """max |x| as a python float (one device reduction + 8-byte read-back)."""
+    x = asarray(x)
+    return x._dev.absmax(x._buf, x.size, x.dtype)
+
+
+def norm_fro(x):
+    """Frobenius norm, registered for ``quimb.tensor.array_ops.norm_fro``
+    (array_ops.py:257-274)."""
+    x = asarray(x)
+    v = x.ravel()
+    out, _ = einsum_pair(v.conj(), ("i",), v, ("i",), (), True)
+    return float(np.sqrt(abs(out.item())))
+
+
+def zeros(shape, dtype="float64", **_):
+    return Array.full(shape, 0.0, dtype)
+
+
+def ones(shape, dtype="float64", **_):
+    return Array.full(shape, 1.0, dtype)
+
+
+def eye(n, dtype="float64", **_):
+    return Array.from_numpy(np.eye(n), dtype=dtype)
+
+
+def array(x, dtype=None, **_):
+    return asarray(x, dtype=dtype)
+
+
+def shape(x):
+    return asarray(x).shape
+
+
+def ndim(x):
+    return asarray(x).ndim
+
+
+def size(x):
+    return asarray(x).size

@@ -1,0 +1,360 @@
+"""Pairwise contraction planner (host logic, no device access).
+
+Lowers one step of a contraction tree -- ``einsum(a_inds, b_inds -> out_inds)``
+-- onto the GETT kernel's bundle description: every index is classified as
+batch / M (only in ``a``) / N (only in ``b``) / K (contracted), runs of indices
+that are adjacent in memory in every operand holding them are fused into one
+group, and per-operand element strides are recorded.  No operand is permuted:
+the transposes the reference materialises (cotengra's ``transpose -> reshape ->
+matmul`` lowering behind quimb/tensor/contraction.py:285; quimb's own
+``do("tensordot")`` at quimb/tensor/tensor_core.py:3793) become addressing.
+
+Plans are pure data and cached, mirroring the reference's ``lru_cache`` on
+``calc_fuse_perm_and_shape`` (quimb/tensor/array_ops.py:95) and ``inds_to_eq``
+(quimb/tensor/contraction.py:103).
+"""
+
+import functools
+from dataclasses import dataclass, field
+
+MAX_GROUPS = 8
+
+
+def contig_strides(shape):
+    s = [1] * len(shape)
+    for i in range(len(shape) - 2, -1, -1):
+        s[i] = s[i + 1] * shape[i + 1]
+    return tuple(s)
+
+
+def prod(xs):
+    p = 1
+    for x in xs:
+        p *= int(x)
+    return p
+
+
+@dataclass(frozen=True)
+class ViewSpec:
+    """A strided view of a contiguous array: unique ``inds`` with ``shape`` and
+    element ``strides`` (repeated indices merged by summing strides = taking the
+    diagonal)."""
+
+    inds: tuple
+    shape: tuple
+    strides: tuple
+
+
+@dataclass(frozen=True)
+class ReduceSpec:
+    """Single-operand preprocessing: sum ``red`` indices out of a view, giving a
+    new contiguous array over ``keep``."""
+
+    keep_inds: tuple
+    keep_shape: tuple
+    keep_strides: tuple
+    red_shape: tuple
+    red_strides: tuple
+
+
+@dataclass(frozen=True)
+class PermuteSpec:
+    """Materialise a view as a contiguous array with the given index order."""
+
+    inds: tuple
+    shape: tuple
+    strides: tuple  # source strides in the new order
+
+
+@dataclass(frozen=True)
+class GettSpec:
+    """Bundle description handed to ``qamd_contract_pair``.  Each bundle is a
+    tuple of groups, outermost first; group = (dim, stride_in_A, stride_in_B,
+    stride_in_C) with ``None`` where an operand does not hold the group."""
+
+    b: tuple
+    m: tuple
+    n: tuple
+    k: tuple
+
+    @property
+    def B(self):
+        return prod(g[0] for g in self.b)
+
+    @property
+    def M(self):
+        return prod(g[0] for g in self.m)
+
+    @property
+    def N(self):
+        return prod(g[0] for g in self.n)
+
+    @property
+    def K(self):
+        return prod(g[0] for g in self.k)
+
+    @property
+    def mults(self):
+        """Scalar multiplications = cotengra's ``contraction_cost`` unit
+        (tests/test_tensor/test_tensor_core.py:1199-1205 in the reference)."""
+        return self.B * self.M * self.N * self.K
+
+
+@dataclass(frozen=True)
+class BinarySpec:
+    """Pure elementwise step (all indices are batch): out = a * b."""
+
+    shape: tuple
+    sa: tuple
+    sb: tuple
+
+
+@dataclass(frozen=True)
+class PairStep:
+    swapped: bool  # True: kernel operand A is the caller's second operand
+    pre: tuple  # per caller operand: tuple of ReduceSpec / PermuteSpec to apply in order
+    kind: str  # 'gett' | 'binary'
+    spec: object
+    out_inds: tuple
+    out_shape: tuple
+    mults: int
+
+
+def _view(inds, shape):
+    """Merge repeated indices (diagonal) into a strided view."""
+    st = contig_strides(shape)
+    uinds, ushape, ustr = [], [], []
+    pos = {}
+    for ix, d, s in zip(inds, shape, st):
+        if ix in pos:
+            j = pos[ix]
+            if ushape[j] != d:
+                raise ValueError(f"index {ix!r} has inconsistent sizes {ushape[j]} and {d}")
+            ustr[j] += s
+        else:
+            pos[ix] = len(uinds)
+            uinds.append(ix)
+            ushape.append(int(d))
+            ustr.append(s)
+    return ViewSpec(tuple(uinds), tuple(ushape), tuple(ustr))
+
+
+def _is_contig_view(v):
+    return v.strides == contig_strides(v.shape)
+
+
+def _fuse(order, size, stride_maps):
+    """Fuse adjacent indices of ``order`` when contiguous in every operand of
+    ``stride_maps`` (list of dict ind->stride).  Returns list of groups
+    (dim, [stride per operand])."""
+    groups = []
+    for ix in order:
+        d = size[ix]
+        strs = [sm[ix] for sm in stride_maps]
+        if d == 1:
+            continue
+        if groups:
+            gd, gs = groups[-1]
+            if all(p == s * d for p, s in zip(gs, strs)):
+                groups[-1] = (gd * d, strs)
+                continue
+        groups.append((d, strs))
+    return groups
+
+
+def _prepare_operand(inds, shape, other_inds, out_set):
+    """Diagonal-merge, then sum out indices private to this operand that are not
+    in the output.  Returns (pre_ops, inds, shape, strides)."""
+    v = _view(inds, shape)
+    pre = []
+    red = [ix for ix in v.inds if ix not in other_inds and ix not in out_set]
+    if red:
+        keep = [i for i, ix in enumerate(v.inds) if ix not in red]
+        rix = [i for i, ix in enumerate(v.inds) if ix in red]
+        spec = ReduceSpec(
+            tuple(v.inds[i] for i in keep),
+            tuple(v.shape[i] for i in keep),
+            tuple(v.strides[i] for i in keep),
+            tuple(v.shape[i] for i in rix),
+            tuple(v.strides[i] for i in rix),
+        )
+        pre.append(spec)
+        v = ViewSpec(spec.keep_inds, spec.keep_shape, contig_strides(spec.keep_shape))
+    return pre, v
+
+
+@functools.lru_cache(maxsize=2**14)
+def plan_pair(a_inds, a_shape, b_inds, b_shape, out_inds, out_fixed=True, death=None):
+    """Plan ``einsum(a, b -> out)``.
+
+    Parameters
+    ----------
+    a_inds, b_inds : tuple of hashable
+    a_shape, b_shape : tuple of int
+    out_inds : tuple of hashable
+        Indices of the result.  If ``out_fixed`` their order is binding;
+        otherwise the planner picks the memory order of the result (the tree
+        executor owns intermediates, so their layout is free).
+    death : tuple of (ind, step) pairs, optional
+        When each surviving index is next contracted; used to place soon-to-die
+        indices innermost among the small operand's free indices.
+    """
+    a_inds, b_inds, out_inds = tuple(a_inds), tuple(b_inds), tuple(out_inds)
+    out_set = set(out_inds)
+    if len(out_set) != len(out_inds):
+        raise ValueError("repeated output indices are not supported")
+    pre_a, va = _prepare_operand(a_inds, tuple(a_shape), set(b_inds), out_set)
+    pre_b, vb = _prepare_operand(b_inds, tuple(b_shape), set(a_inds), out_set)
+    size = {}
+    for v in (va, vb):
+        for ix, d in zip(v.inds, v.shape):
+            if size.setdefault(ix, d) != d:
+                raise ValueError(f"index {ix!r} has inconsistent sizes {size[ix]} and {d}")
+    for ix in out_inds:
+        if ix not in size:
+            raise ValueError(f"output index {ix!r} not found in inputs")
+
+    sa_set, sb_set = set(va.inds), set(vb.inds)
+    batch = [ix for ix in va.inds if ix in sb_set and ix in out_set]
+    kk = [ix for ix in va.inds if ix in sb_set and ix not in out_set]
+    mm = [ix for ix in va.inds if ix not in sb_set]
+    nn = [ix for ix in vb.inds if ix not in sa_set]
+
+    # ---- pure elementwise -------------------------------------------------
+    if not kk and not mm and not nn:
+        oi = out_inds if out_fixed else tuple(va.inds)
+        sa = dict(zip(va.inds, va.strides))
+        sb = dict(zip(vb.inds, vb.strides))
+        shp = tuple(size[ix] for ix in oi)
+        spec = BinarySpec(shp, tuple(sa[ix] for ix in oi), tuple(sb[ix] for ix in oi))
+        return PairStep(False, (tuple(pre_a), tuple(pre_b)), "binary", spec, oi, shp, prod(shp))
+
+    # ---- kernel operand A = the one with the larger free size --------------
+    swapped = prod(size[i] for i in nn) > prod(size[i] for i in mm)
+    if swapped:
+        va, vb = vb, va
+        mm, nn = nn, mm
+        batch = [ix for ix in va.inds if ix in set(vb.inds) and ix in out_set]
+        kk = [ix for ix in va.inds if ix in set(vb.inds) and ix not in out_set]
+    sa = dict(zip(va.inds, va.strides))
+    sb = dict(zip(vb.inds, vb.strides))
+
+    # ---- result memory order -----------------------------------------------
+    if out_fixed:
+        oi = out_inds
+    else:
+        dmap = dict(death) if death else {}
+        big = 1 << 60
+        # N indices: later-dying first, sooner-dying innermost (stable)
+        n_sorted = sorted(nn, key=lambda ix: -dmap.get(ix, big))
+        kset = set(kk)
+        last_k = max((i for i, ix in enumerate(va.inds) if ix in kset), default=None)
+        oi = []
+        placed = False
+        for i, ix in enumerate(va.inds):
+            if ix in kset:
+                if i == last_k:
+                    oi.extend(n_sorted)
+                    placed = True
+                continue
+            oi.append(ix)
+        if not placed:
+            oi.extend(n_sorted)
+        oi = tuple(oi)
+    oshape = tuple(size[ix] for ix in oi)
+    sc = dict(zip(oi, contig_strides(oshape)))
+
+    # ---- bundles -------------------------------------------------------------
+    # iteration order of each bundle follows the big streamed side: A for m/k/b,
+    # C for n (so stores along n run through memory in order)
+    m_order = sorted(mm, key=lambda ix: -sa[ix])
+    k_order = sorted(kk, key=lambda ix: -sa[ix])
+    b_order = sorted(batch, key=lambda ix: -sa[ix])
+    n_order = sorted(nn, key=lambda ix: -sc[ix])
+    gm = _fuse(m_order, size, [sa, sc])
+    gk = _fuse(k_order, size, [sa, sb])
+    gb = _fuse(b_order, size, [sa, sb, sc])
+    gn = _fuse(n_order, size, [sb, sc])
+
+    pre = [list(pre_a), list(pre_b)] if not swapped else [list(pre_b), list(pre_a)]
+    # pre[0] belongs to kernel operand A, pre[1] to kernel operand B
+    if max(len(gm), len(gk), len(gb), len(gn)) > MAX_GROUPS:
+        # canonicalise: permute A -> [b, m, k], B -> [b, k, n] so every bundle fuses
+        new_a = tuple(b_order + m_order + k_order)
+        new_b = tuple(b_order + k_order + n_order)
+        if tuple(va.inds) != new_a or not _is_contig_view(va):
+            shp = tuple(size[ix] for ix in new_a)
+            pre[0].append(PermuteSpec(new_a, shp, tuple(sa[ix] for ix in new_a)))
+            va = ViewSpec(new_a, shp, contig_strides(shp))
+            sa = dict(zip(va.inds, va.strides))
+        if tuple(vb.inds) != new_b or not _is_contig_view(vb):
+            shp = tuple(size[ix] for ix in new_b)
+            pre[1].append(PermuteSpec(new_b, shp, tuple(sb[ix] for ix in new_b)))
+            vb = ViewSpec(new_b, shp, contig_strides(shp))
+            sb = dict(zip(vb.inds, vb.strides))
+        if not out_fixed:
+            oi = tuple(b_order + m_order + n_order)
+            oshape = tuple(size[ix] for ix in oi)
+            sc = dict(zip(oi, contig_strides(oshape)))
+            n_order = sorted(nn, key=lambda ix: -sc[ix])
+        gm = _fuse(m_order, size, [sa, sc])
+        gk = _fuse(k_order, size, [sa, sb])
+        gb = _fuse(b_order, size, [sa, sb, sc])
+        gn = _fuse(n_order, size, [sb, sc])
+        if max(len(gm), len(gk), len(gb), len(gn)) > MAX_GROUPS:
+            raise NotImplementedError(
+                "result layout needs more than %d index groups per bundle; "
+                "request a different output order" % MAX_GROUPS
+            )
+
+    spec = GettSpec(
+        b=tuple((d, s[0], s[1], s[2]) for d, s in gb),
+        m=tuple((d, s[0], None, s[1]) for d, s in gm),
+        n=tuple((d, None, s[0], s[1]) for d, s in gn),
+        k=tuple((d, s[0], s[1], None) for d, s in gk),
+    )
+    pre_caller = (tuple(pre[1]), tuple(pre[0])) if swapped else (tuple(pre[0]), tuple(pre[1]))
+    return PairStep(swapped, pre_caller, "gett", spec, oi, oshape, spec.mults)
+
+
+def tensordot_inds(a_ndim, b_ndim, axes):
+    """Index labels for numpy-style ``tensordot(a, b, axes)``: returns
+    (a_inds, b_inds, out_inds) with the numpy output order (free a, free b)."""
+    if isinstance(axes, int):
+        ax_a = list(range(a_ndim - axes, a_ndim))
+        ax_b = list(range(axes))
+    else:
+        ax_a, ax_b = axes
+        ax_a = [ax_a] if isinstance(ax_a, int) else list(ax_a)
+        ax_b = [ax_b] if isinstance(ax_b, int) else list(ax_b)
+    ax_a = [x % a_ndim for x in ax_a]
+    ax_b = [x % b_ndim for x in ax_b]
+    if len(ax_a) != len(ax_b):
+        raise ValueError("tensordot: axes lengths differ")
+    a_inds = [("a", i) for i in range(a_ndim)]
+    b_inds = [("b", i) for i in range(b_ndim)]
+    for x, y in zip(ax_a, ax_b):
+        b_inds[y] = a_inds[x]
+    out = [ix for i, ix in enumerate(a_inds) if i not in ax_a]
+    out += [ix for i, ix in enumerate(b_inds) if i not in ax_b]
+    return tuple(a_inds), tuple(b_inds), tuple(out)
+
+
+def parse_einsum(eq, nops):
+    """Parse a numpy-style explicit/implicit einsum equation for ``nops``
+    operands into (inputs, output) tuples of characters."""
+    eq = eq.replace(" ", "")
+    if "..." in eq:
+        raise NotImplementedError("ellipsis in einsum equations is not supported")
+    if "->" in eq:
+        lhs, rhs = eq.split("->")
+    else:
+        lhs = eq
+        counts = {}
+        for c in lhs.replace(",", ""):
+            counts[c] = counts.get(c, 0) + 1
+        rhs = "".join(sorted(c for c, n in counts.items() if n == 1))
+    terms = lhs.split(",")
+    if len(terms) != nops:
+        raise ValueError(f"einsum: equation has {len(terms)} terms but {nops} operands given")
+    return tuple(tuple(t) for t in terms), tuple(rhs)

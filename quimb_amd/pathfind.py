@@ -1,0 +1,200 @@
+"""Contraction-order search (host, pure python).
+
+In the reference this is cotengra's job (``optimize="greedy"`` is quimb's
+default strategy, quimb/tensor/contraction.py:11; structured 2D networks use
+explicit boundary sweeps, quimb/tensor/tn2d/core.py:1355-1484).  cotengra is not
+part of this build, so the executor ships its own finders:
+
+* ``greedy_path``      -- size-difference greedy (the classic opt_einsum rule)
+* ``random_greedy``    -- Boltzmann-perturbed greedy restarts, keep the cheapest
+* ``sweep_path_2d``    -- row-by-row, site-by-site boundary sweep of an Lx x Ly grid
+* ``find_slices``      -- greedy choice of sliced indices (what cotengra's
+                          SliceFinder does) so that the slices can be sharded
+"""
+
+import heapq
+import math
+import random
+
+from .pairwise import prod
+from .tree import ContractionTree, ssa_to_linear
+
+
+def _result_inds(a, b, counts, out_set):
+    seen = {}
+    for ix in a:
+        seen[ix] = 1
+    for ix in b:
+        seen[ix] = seen.get(ix, 0) + 1
+    keep = []
+    for ix in a + tuple(i for i in b if i not in a):
+        if ix in out_set or counts[ix] > seen[ix]:
+            keep.append(ix)
+    return tuple(keep), seen
+
+
+def greedy_ssa(inputs, output, size_dict, temperature=0.0, rng=None, costmod=1.0):
+    """Greedy pairwise ordering.  score = size(out) - costmod*(size(a)+size(b)),
+    optionally Boltzmann-perturbed (``temperature`` > 0)."""
+    inputs = [tuple(dict.fromkeys(t)) for t in inputs]
+    out_set = set(output)
+    n = len(inputs)
+    terms = {i: t for i, t in enumerate(inputs)}
+    counts = {}
+    where = {}
+    for i, t in terms.items():
+        for ix in t:
+            counts[ix] = counts.get(ix, 0) + 1
+            where.setdefault(ix, set()).add(i)
+    tsize = {i: prod(size_dict[ix] for ix in t) for i, t in terms.items()}
+    rng = rng or random
+
+    def score(i, j):
+        keep, _ = _result_inds(terms[i], terms[j], counts, out_set)
+        so = prod(size_dict[ix] for ix in keep)
+        s = so - costmod * (tsize[i] + tsize[j])
+        if temperature > 0:
+            gumbel = -math.log(-math.log(rng.random() * 0.999999 + 1e-12))
+            s = s - temperature * abs(s if s != 0 else 1.0) * gumbel
+        return s
+
+    heap = []
+    for ix, ts in where.items():
+        ts = sorted(ts)
+        for a in range(len(ts)):
+            for b in range(a + 1, len(ts)):
+                heapq.heappush(heap, (score(ts[a], ts[b]), ts[a], ts[b]))
+    ssa = []
+    nxt = n
+    while len(terms) > 1:
+        pick = None
+        while heap:
+            s, i, j = heapq.heappop(heap)
+            if i in terms and j in terms:
+                pick = (i, j)
+                break
+        if pick is None:
+            # disconnected components: outer products, smallest first
+            i, j = sorted(terms, key=lambda t: tsize[t])[:2]
+            pick = (i, j)
+        i, j = pick
+        keep, seen = _result_inds(terms[i], terms[j], counts, out_set)
+        for t in (i, j):
+            for ix in terms[t]:
+                where[ix].discard(t)
+        for ix, c in seen.items():
+            counts[ix] -= c
+        for ix in keep:
+            counts[ix] += 1
+            where[ix].add(nxt)
+        del terms[i], terms[j]
+        terms[nxt] = keep
+        tsize[nxt] = prod(size_dict[ix] for ix in keep)
+        ssa.append((i, j))
+        neigh = set()
+        for ix in keep:
+            neigh |= where[ix]
+        neigh.discard(nxt)
+        for t in neigh:
+            heapq.heappush(heap, (score(t, nxt), t, nxt))
+        nxt += 1
+    return ssa
+
+
+def greedy_path(inputs, output, size_dict):
+    n = len(inputs)
+    return ssa_to_linear(greedy_ssa(inputs, output, size_dict), n)
+
+
+def random_greedy(inputs, output, size_dict, repeats=32, seed=0, temperature=0.3):
+    """Best of ``repeats`` perturbed greedy runs (by total multiplications)."""
+    rng = random.Random(seed)
+    best, best_cost = None, None
+    for r in range(max(1, repeats)):
+        ssa = greedy_ssa(
+            inputs, output, size_dict,
+            temperature=0.0 if r == 0 else temperature * rng.random(),
+            rng=rng,
+            costmod=1.0 if r == 0 else rng.choice([0.5, 1.0, 1.0, 2.0]),
+        )
+        tree = ContractionTree(inputs, output, size_dict, ssa_path=ssa)
+        c = tree.contraction_cost()
+        if best_cost is None or c < best_cost:
+            best, best_cost = tree, c
+    return best
+
+
+def sweep_ssa_2d(Lx, Ly):
+    """SSA path for a row-major Lx x Ly grid of tensors: absorb sites one at a
+    time, left to right, top row to bottom row, into a single boundary tensor
+    (the exact version of quimb's boundary contraction sweep,
+    quimb/tensor/tn2d/core.py:1355-1484, without compression)."""
+    n = Lx * Ly
+    ssa, cur, nxt = [], 0, n
+    for t in range(1, n):
+        ssa.append((cur, t))
+        cur = nxt
+        nxt += 1
+    return ssa
+
+
+def sweep_path_2d(Lx, Ly):
+    return ssa_to_linear(sweep_ssa_2d(Lx, Ly), Lx * Ly)
+
+
+def find_path(inputs, output, size_dict, optimize="greedy"):
+    """Resolve quimb's ``optimize=`` argument to a ``ContractionTree``."""
+    if isinstance(optimize, ContractionTree):
+        return optimize
+    if hasattr(optimize, "get_path") and hasattr(optimize, "size_dict"):
+        return ContractionTree.from_any(optimize, inputs, output, size_dict)
+    if isinstance(optimize, str):
+        if optimize in ("greedy", "auto"):
+            ssa = greedy_ssa(inputs, output, size_dict)
+            return ContractionTree(inputs, output, size_dict, ssa_path=ssa)
+        if optimize in ("auto-hq", "random-greedy"):
+            return random_greedy(inputs, output, size_dict, repeats=64 if optimize == "auto-hq" else 32)
+        raise ValueError(f"unknown contraction strategy {optimize!r}")
+    if callable(optimize):
+        path = optimize(inputs, output, size_dict)
+        return ContractionTree(inputs, output, size_dict, path=path)
+    # explicit linear path
+    return ContractionTree(inputs, output, size_dict, path=list(optimize))
+
+
+def find_slices(tree, target_slices=None, target_size=None, max_slices=1 << 20):
+    """Greedily pick indices to slice: at every round take the index whose
+    removal gives the lowest total cost (per-slice cost x number of slices),
+    until ``target_slices`` slices / ``target_size`` max intermediate is reached."""
+    if target_slices is None and target_size is None:
+        raise ValueError("need target_slices or target_size")
+    sliced = list(tree.sliced_inds)
+    cur = tree
+    out_set = set(tree.output)
+
+    def done(t):
+        ok = True
+        if target_slices is not None:
+            ok = ok and t.nslices >= target_slices
+        if target_size is not None:
+            ok = ok and t.max_size() <= target_size
+        return ok
+
+    while not done(cur) and cur.nslices < max_slices:
+        cands = set()
+        for con, res, ops, keep, _ in cur.steps:
+            for t in ops:
+                cands.update(t)
+        cands -= out_set
+        cands = [ix for ix in cands if tree.size_dict[ix] > 1]
+        if not cands:
+            break
+        best = None
+        for ix in sorted(cands, key=repr):
+            t = tree.with_slices(sliced + [ix])
+            key = (t.contraction_cost(), t.max_size())
+            if best is None or key < best[0]:
+                best = (key, ix, t)
+        sliced.append(best[1])
+        cur = best[2]
+    return cur

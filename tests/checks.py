@@ -1,0 +1,331 @@
+"""Device-independent parity checks: each function compares quimb_amd (running
+on whatever default device the calling test installed -- the HIP device in the
+``-m gpu`` tests, the numpy plan interpreter in the CPU tests) with the oracle
+/ numpy on the same seeded inputs.  Tolerances are written here once."""
+
+import itertools
+
+import numpy as np
+import pytest
+
+import quimb_amd as qa
+from oracle import np_oracle as orc
+
+#: relative tolerances (north_star: 1e-6 rel for fp32 on conditioned inputs)
+RTOL = {np.dtype("float32"): 2e-5, np.dtype("float64"): 1e-12,
+        np.dtype("complex64"): 2e-5, np.dtype("complex128"): 1e-12}
+
+
+def rand(rng, shape, dtype):
+    dtype = np.dtype(dtype)
+    x = rng.uniform(-0.5, 1.0, size=shape)
+    if dtype.kind == "c":
+        x = x + 1j * rng.uniform(-0.5, 1.0, size=shape)
+    return x.astype(dtype)
+
+
+def assert_close(got, want, dtype, scale=None):
+    got, want = np.asarray(got), np.asarray(want)
+    assert got.shape == want.shape, (got.shape, want.shape)
+    tol = RTOL[np.dtype(dtype)]
+    ref = np.max(np.abs(want)) if scale is None else scale
+    ref = max(float(ref), 1e-300)
+    err = float(np.max(np.abs(got.astype(np.complex128) - want.astype(np.complex128)))) / ref if got.size else 0.0
+    assert err <= tol, f"rel err {err:.3e} > {tol:.1e}"
+
+
+PAIR_CASES = [
+    # (a_inds, b_inds, out_inds)
+    ("abc", "bcd", "ad"),
+    ("abc", "bcd", "da"),
+    ("abc", "cbd", "ad"),
+    ("ab", "bc", "ac"),
+    ("ab", "cb", "ca"),
+    ("ba", "bc", "ac"),
+    ("abc", "abc", ""),
+    ("abc", "def", "abcdef"),
+    ("abc", "def", "fbdace"),
+    ("abcd", "cd", "ab"),
+    ("abcd", "bd", "ac"),
+    ("abcd", "bd", "ca"),
+    ("ab", "a", "b"),
+    ("a", "ab", "b"),
+    ("a", "a", ""),
+    ("abc", "abd", "acd"),      # batch index a
+    ("abc", "abd", "dca"),
+    ("abc", "bad", "cbd"),      # batch b, contract a
+    ("ab", "ab", "ab"),         # pure elementwise
+    ("ab", "ba", "ab"),
+    ("aab", "bc", "ac"),        # diagonal of first operand
+    ("abc", "cd", "ad"),        # b summed out of first operand
+    ("abcde", "ceaf", "bdf"),
+    ("abcdef", "fcga", "gbde"),
+    ("a", "b", "ab"),
+    ("a", "b", "ba"),
+]
+DIMS = {"a": 3, "b": 4, "c": 5, "d": 6, "e": 2, "f": 7, "g": 3}
+
+
+def check_pairwise(dtype, seed=0, dims=None):
+    rng = np.random.default_rng(seed)
+    dims = dims or DIMS
+    for ai, bi, oi in PAIR_CASES:
+        a = rand(rng, [dims[c] for c in ai], dtype)
+        b = rand(rng, [dims[c] for c in bi], dtype)
+        want = np.einsum(f"{ai},{bi}->{oi}", a.astype(np.complex128 if np.dtype(dtype).kind == "c" else np.float64),
+                         b.astype(np.complex128 if np.dtype(dtype).kind == "c" else np.float64))
+        got = qa.einsum(f"{ai},{bi}->{oi}", qa.asarray(a), qa.asarray(b))
+        assert got.dtype == np.dtype(dtype)
+        assert_close(got.to_numpy(), want, dtype)
+
+
+def check_tensordot_matmul(dtype, seed=1):
+    rng = np.random.default_rng(seed)
+    a = rand(rng, (6, 5, 7), dtype)
+    b = rand(rng, (7, 5, 3), dtype)
+    assert_close(qa.tensordot(a, b, axes=([1, 2], [1, 0])).to_numpy(), np.tensordot(a, b, axes=([1, 2], [1, 0])), dtype)
+    assert_close(qa.tensordot(a, b, axes=1).to_numpy(), np.tensordot(a, b, axes=1), dtype)
+    assert_close(qa.tensordot(a, b, axes=0).to_numpy(), np.tensordot(a, b, axes=0), dtype)
+    x = rand(rng, (4, 33, 20), dtype)
+    y = rand(rng, (4, 20, 50), dtype)
+    assert_close(qa.matmul(x, y).to_numpy(), np.matmul(x, y), dtype)
+    assert_close((qa.asarray(x[0]) @ qa.asarray(y[0])).to_numpy(), x[0] @ y[0], dtype)
+    v = rand(rng, (20,), dtype)
+    assert_close(qa.matmul(x[0], v).to_numpy(), x[0] @ v, dtype)
+    assert_close(qa.matmul(v, y[0]).to_numpy(), v @ y[0], dtype)
+    # GEMM shapes that exercise every tile configuration and the split-K path
+    for (m, n, k) in [(300, 200, 100), (1000, 36, 36), (513, 17, 9), (70, 70, 3000), (1, 1, 5000), (129, 130, 17), (40, 9, 600)]:
+        p = rand(rng, (m, k), dtype)
+        q = rand(rng, (k, n), dtype)
+        want = p.astype(np.float64 if np.dtype(dtype).kind == "f" else np.complex128) @ q
+        assert_close(qa.matmul(p, q).to_numpy(), want, dtype)
+        # transposed storage of either operand
+        assert_close(qa.einsum("km,kn->mn", np.ascontiguousarray(p.T), q).to_numpy(), want, dtype)
+        assert_close(qa.einsum("mk,nk->nm", p, np.ascontiguousarray(q.T)).to_numpy(), want.T, dtype)
+
+
+def check_layout_ops(dtype, seed=2):
+    rng = np.random.default_rng(seed)
+    x = rand(rng, (3, 4, 5, 6, 2), dtype)
+    X = qa.asarray(x)
+    for perm in [(4, 3, 2, 1, 0), (0, 2, 1, 3, 4), (1, 0, 4, 2, 3), (0, 1, 2, 4, 3), (3, 0, 1, 2, 4)]:
+        np.testing.assert_array_equal(qa.transpose(X, perm).to_numpy(), np.transpose(x, perm))
+    np.testing.assert_array_equal(X.T.to_numpy(), x.T)
+    # fuse semantics of the reference (array_ops.py:95-182)
+    for groups in [((0, 1),), ((3, 1),), ((4, 2), (3, 0)), ((1,), (2, 3)), ((2, 0, 4),)]:
+        np.testing.assert_array_equal(qa.fuse(X, *groups).to_numpy(), orc.oracle_fuse(x, *groups))
+    # isel / take / basic getitem
+    np.testing.assert_array_equal(X[1].to_numpy(), x[1])
+    np.testing.assert_array_equal(X[:, 2].to_numpy(), x[:, 2])
+    np.testing.assert_array_equal(X[..., 1].to_numpy(), x[..., 1])
+    np.testing.assert_array_equal(X[1:3, :, ::2, -1].to_numpy(), x[1:3, :, ::2, -1])
+    np.testing.assert_array_equal(qa.take(X, 3, axis=2).to_numpy(), np.take(x, 3, axis=2))
+    np.testing.assert_array_equal(qa.take(X, [0, 2], axis=1).to_numpy(), np.take(x, [0, 2], axis=1))
+    np.testing.assert_array_equal(X.reshape(12, -1).to_numpy(), x.reshape(12, -1))
+    # big transposes that exercise the tiled kernel in both modes
+    y = rand(rng, (70, 129), dtype)
+    np.testing.assert_array_equal(qa.transpose(y).to_numpy(), y.T)
+    z = rand(rng, (6, 6, 6, 6, 6, 6), dtype)
+    for perm in [(5, 4, 3, 2, 1, 0), (1, 0, 3, 2, 5, 4), (2, 3, 4, 5, 0, 1), (0, 1, 2, 3, 5, 4)]:
+        np.testing.assert_array_equal(qa.transpose(z, perm).to_numpy(), np.transpose(z, perm))
+    # reductions / elementwise
+    assert_close(qa.sum(X, axis=(1, 3)).to_numpy(), x.sum(axis=(1, 3)), dtype)
+    assert_close(qa.sum(X).to_numpy(), x.sum(), dtype)
+    assert_close((X * 2.5).to_numpy(), x * np.asarray(2.5, x.real.dtype), dtype)
+    assert_close((X / 4).to_numpy(), x / 4, dtype)
+    assert_close((-X).to_numpy(), -x, dtype)
+    assert_close((X + X * 3).to_numpy(), x + x * 3, dtype)
+    assert_close((X - 1.5).to_numpy(), x - 1.5, dtype)
+    assert_close(X.conj().to_numpy(), x.conj(), dtype)
+    assert_close(qa.trace(qa.asarray(x[0, :4, :4, 0, 0])).to_numpy(), np.trace(x[0, :4, :4, 0, 0]), dtype)
+    assert abs(qa.absmax(X) - np.max(np.abs(x))) <= 1e-6 * np.max(np.abs(x))
+    assert abs(qa.norm_fro(X) - np.linalg.norm(x.ravel())) <= 1e-5 * np.linalg.norm(x.ravel())
+    np.testing.assert_array_equal(qa.einsum("abcde->eb", X).to_numpy().shape, (2, 4))
+    assert_close(qa.einsum("abcde->eb", X).to_numpy(), np.einsum("abcde->eb", x), dtype)
+
+
+def rand_reg_network(n, deg, D, rng, dtype, n_out=0):
+    """Random regular-ish tensor network (like qtn.TN_rand_reg): returns arrays, inputs, output."""
+    import random
+
+    rr = random.Random(int(rng.integers(1 << 30)))
+    while True:
+        stubs = [i for i in range(n) for _ in range(deg)]
+        rr.shuffle(stubs)
+        edges = [(stubs[2 * i], stubs[2 * i + 1]) for i in range(len(stubs) // 2)]
+        if all(a != b for a, b in edges) and len({tuple(sorted(e)) for e in edges}) == len(edges):
+            break
+    inputs = [[] for _ in range(n)]
+    for e, (a, b) in enumerate(edges):
+        inputs[a].append(f"e{e}")
+        inputs[b].append(f"e{e}")
+    output = []
+    for o in range(n_out):
+        inputs[o].append(f"o{o}")
+        output.append(f"o{o}")
+    arrays = [rand(rng, (D,) * len(t), dtype) for t in inputs]
+    return arrays, [tuple(t) for t in inputs], tuple(output)
+
+
+def check_tree_executor(dtype, seed=3):
+    rng = np.random.default_rng(seed)
+    hi = np.complex128 if np.dtype(dtype).kind == "c" else np.float64
+    for n, deg, D, n_out in [(6, 3, 3, 0), (8, 3, 2, 2), (10, 3, 3, 1), (5, 4, 3, 3)]:
+        arrays, inputs, output = rand_reg_network(n, deg, D, rng, dtype, n_out)
+        want = orc.oracle_array_contract([a.astype(hi) for a in arrays], inputs, output)
+        for opt in ("greedy", "random-greedy"):
+            got = qa.array_contract(arrays, inputs, output, optimize=opt)
+            assert isinstance(got, np.ndarray)
+            assert_close(got, want, dtype)
+        # device-resident inputs give a device result
+        got = qa.array_contract([qa.asarray(a) for a in arrays], inputs, output)
+        assert isinstance(got, qa.Array)
+        assert_close(got.to_numpy(), want, dtype)
+        # explicit linear path, as quimb passes `optimize=path`
+        tree = qa.array_contract_tree(inputs, output, shapes=[a.shape for a in arrays])
+        got = qa.array_contract(arrays, inputs, output, optimize=tree.get_path())
+        assert_close(got, want, dtype)
+        # permuted output order
+        if len(output) >= 2:
+            out2 = tuple(reversed(output))
+            assert_close(qa.array_contract(arrays, inputs, out2), np.transpose(want, list(reversed(range(len(output))))), dtype)
+
+
+def check_hyper_network(dtype, seed=4):
+    """Hyper-index network (index on 3+ tensors) == numpy einsum
+    (reference: tests/test_tensor/test_tensor_core.py:1910-1935)."""
+    rng = np.random.default_rng(seed)
+    inputs = [("a", "x"), ("b", "x"), ("c", "x", "y"), ("y", "d"), ("a", "b"), ("c", "d", "y")]
+    size = dict(a=3, b=4, c=2, d=5, x=3, y=4)
+    arrays = [rand(rng, [size[i] for i in t], dtype) for t in inputs]
+    for output in [(), ("x",), ("y", "x")]:
+        want = orc._einsum_inds([a.astype(np.float64 if np.dtype(dtype).kind == "f" else np.complex128) for a in arrays],
+                                inputs, output)
+        got = qa.array_contract(arrays, inputs, output)
+        assert_close(got, want, dtype)
+
+
+def check_strip_exponent(dtype, seed=5):
+    rng = np.random.default_rng(seed)
+    arrays, inputs, output = rand_reg_network(8, 3, 3, rng, dtype, 0)
+    hi = np.complex128 if np.dtype(dtype).kind == "c" else np.float64
+    z0 = orc.oracle_array_contract([a.astype(hi) for a in arrays], inputs, output)
+    m, e = qa.array_contract(arrays, inputs, output, strip_exponent=True)
+    assert_close(np.asarray(m) * 10**e, z0, dtype)
+    assert abs(abs(np.asarray(m).item()) - 1.0) < 1e-4  # mantissa normalised by the last step
+    ts = [qa.Tensor(a, t) for a, t in zip(arrays, inputs)]
+    (m2, e2) = qa.tensor_contract(*ts, strip_exponent=True, exponent=2.0)
+    assert_close(np.asarray(m2 * 10 ** (e2 - 2.0)), z0, dtype)
+
+
+def check_sliced(dtype, seed=6):
+    """sum over slices == unsliced (the identity the reference pins only for
+    cut_iter, tests/test_tensor/test_tensor_core.py:325-330)."""
+    rng = np.random.default_rng(seed)
+    arrays, inputs = orc.tn2d_rand(4, 4, 3, seed=seed, dtype=dtype)
+    size = {ix: 3 for t in inputs for ix in t}
+    tree = qa.ContractionTree(inputs, (), size, path=qa.sweep_path_2d(4, 4))
+    hi = np.float64
+    want = orc.oracle_array_contract([a.astype(hi) for a in arrays], inputs, (), path=tree.get_path())
+    full = qa.TreeExecutor(tree, dtype)(arrays)
+    assert_close(full.to_numpy(), want, dtype)
+    st = qa.find_slices(tree, target_slices=9)
+    assert st.nslices >= 9 and len(st.sliced_inds) >= 2
+    ex = qa.TreeExecutor(st, dtype)
+    assert_close(ex(arrays).to_numpy(), want, dtype)
+    assert_close(ex(arrays, hoist=False).to_numpy(), want, dtype)
+    # partial sums over a 2-way partition add up
+    p0 = ex(arrays, slices=range(0, st.nslices, 2)).to_numpy()
+    p1 = ex(arrays, slices=range(1, st.nslices, 2)).to_numpy()
+    assert_close(p0 + p1, want, dtype)
+    # oracle's own sliced evaluation agrees too
+    o = orc.oracle_array_contract([a.astype(hi) for a in arrays], inputs, (), path=tree.get_path(),
+                                  sliced_inds=st.sliced_inds)
+    assert_close(o, want, "float64")
+    # sliced + strip_exponent
+    m, e = ex(arrays, strip_exponent=True)
+    assert_close(m.to_numpy() * 10**e, want, dtype)
+
+
+def check_tensor_contract_semantics():
+    """Restatement of the reference's TestTensorContract
+    (tests/test_tensor/test_tensor_core.py:434-512)."""
+    rng = np.random.default_rng(7)
+    T = qa.Tensor
+    a = T(rng.normal(size=(2, 3, 4)), inds=[0, 1, 2])
+    b = T(rng.normal(size=(3, 4, 5)), inds=[1, 2, 3])
+    c = a @ b
+    assert isinstance(c, T) and c.shape == (2, 5) and c.inds == (0, 3)
+    assert_close(np.asarray(c.data), np.einsum("abc,bcd->ad", a.data, b.data), "float64")
+
+    b2 = T(rng.normal(size=(3, 4, 2)), inds=[1, 2, 0])
+    s = a @ b2
+    assert isinstance(s, float) and not isinstance(s, T)
+    assert abs(s - np.einsum("abc,bca->", a.data, b2.data)) < 1e-12 * max(1, abs(s))
+
+    b3 = T(rng.normal(size=(3, 4, 5)), inds=[3, 4, 5])
+    c = a @ b3
+    assert c.shape == (2, 3, 4, 3, 4, 5) and c.inds == (0, 1, 2, 3, 4, 5)
+    b4 = T(rng.normal(size=(3, 4, 5)), inds=[5, 4, 3])
+    c = a @ b4
+    assert c.shape == (2, 3, 4, 3, 4, 5) and c.inds == (0, 1, 2, 5, 4, 3)
+
+    with pytest.raises(ValueError):
+        a @ T(rng.normal(size=(3, 3, 4)), inds=[1, 1, 2])
+
+    a = T(rng.normal(size=(2, 3, 4)), inds=[0, 1, 2], tags="red")
+    b = T(rng.normal(size=(3, 4, 5)), inds=[1, 2, 3], tags="blue")
+    c = T(rng.normal(size=(5, 2, 6)), inds=[3, 0, 4], tags="blue")
+    d = qa.tensor_contract(a, b, c)
+    assert isinstance(d, T) and d.shape == (6,) and d.inds == (4,) and set(d.tags) == {"red", "blue"}
+    assert_close(np.asarray(d.data), np.einsum("abc,bcd,dae->e", a.data, b.data, c.data), "float64")
+
+    for ia, ib, io in [("abc", "bcd", ("a", "d")), ([-1, 100, 2200], [100, 2200, -3], (-1, -3)),
+                       (["-1", "a", "foo"], ["a", "foo", "42.42"], ("-1", "42.42"))]:
+        c = T(rng.normal(size=(2, 3, 4)), inds=ia) @ T(rng.normal(size=(3, 4, 5)), inds=ib)
+        assert c.shape == (2, 5) and c.inds == io
+
+    # cost / width definition: three chained 8x8 matmuls (reference :1199-1205)
+    tree = qa.array_contract_tree([("a", "b"), ("b", "c"), ("c", "d")], ("a", "d"), shapes=[(8, 8)] * 3)
+    assert tree.contraction_cost() == 2 * 8**3
+    assert tree.contraction_width() == 6
+
+
+def check_option_stacks():
+    """reference: tests/test_tensor/test_contract.py:137-153"""
+    assert qa.get_contract_backend() is None
+    with qa.contract_backend("quimb_amd"):
+        assert qa.get_contract_backend() == "quimb_amd"
+        with qa.contract_backend("hip"):
+            assert qa.get_contract_backend() == "hip"
+        assert qa.get_contract_backend() == "quimb_amd"
+    assert qa.get_contract_backend() is None
+    assert qa.get_contract_strategy() == "greedy"
+    with qa.contract_strategy("auto-hq"):
+        assert qa.get_contract_strategy() == "auto-hq"
+    assert qa.get_contract_strategy() == "greedy"
+    with pytest.raises(ValueError):
+        qa.array_contract([np.ones(2)], [("a",)], (), backend="cupy")
+    # same geometry + optimizer -> same cached expression (test_contract.py:155-172)
+    e1 = qa.array_contract_expression([("a", "b"), ("b", "c")], ("a", "c"), shapes=[(2, 3), (3, 4)], dtype="float32")
+    e2 = qa.array_contract_expression([("a", "b"), ("b", "c")], ("a", "c"), shapes=[(2, 3), (3, 4)], dtype="float32")
+    assert e1 is e2
+
+
+def check_ising(Lx, Ly, beta, dtype="float64", rel=1e-10):
+    arrays, inputs = orc.tn2d_classical_ising(Lx, Ly, beta)
+    size = {ix: 2 for t in inputs for ix in t}
+    tree = qa.ContractionTree(inputs, (), size, path=qa.sweep_path_2d(Lx, Ly))
+    m, e = qa.TreeExecutor(tree, dtype)([a.astype(dtype) for a in arrays], strip_exponent=True)
+    Z = m.to_numpy().item() * 10**e
+    return Z
+
+
+def check_mps_dense(dtype="float64", L=10, chi=7):
+    """MPS contracted to a dense vector == chained numpy (cf. reference
+    tests/test_tensor/test_tn1d/test_core.py:368-373)."""
+    arrays, inputs = orc.mps_rand(L, chi, 2, seed=11, dtype=dtype)
+    out = tuple(("k", i) for i in range(L))
+    want = orc.oracle_array_contract(arrays, inputs, out)
+    got = qa.array_contract(arrays, inputs, out)
+    assert_close(got, want, dtype)

@@ -1,0 +1,42 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture
+def emu():
+    """Install the numpy plan interpreter as the default device (CPU tests)."""
+    import quimb_amd.device as qd
+    from emu_device import EmuDevice
+
+    old = qd._DEFAULT
+    dev = EmuDevice()
+    qd.set_default_device(dev)
+    try:
+        yield dev
+    finally:
+        qd.set_default_device(old)
+
+
+@pytest.fixture
+def hip():
+    """The real device; fails loudly if the HIP library / GPU is missing."""
+    import quimb_amd.device as qd
+
+    old = qd._DEFAULT
+    dev = qd.HipDevice()
+    qd.set_default_device(dev)
+    try:
+        yield dev
+    finally:
+        qd.set_default_device(old)

@@ -1,0 +1,117 @@
+"""numpy interpreter of the device-op vocabulary -- TEST INFRASTRUCTURE ONLY.
+
+``EmuDevice`` implements exactly the operation semantics the C-ABI documents
+(bundle/stride addressing of ``qamd_contract_pair``, strided ``qamd_permute``,
+``qamd_reduce_sum``, ``qamd_binary`` ...), so the whole host side of quimb_amd
+(planner, tree executor, slicing, exponent stripping, multi-process sharding)
+can be checked against the oracle without a GPU.  It is installed with
+``quimb_amd.device.set_default_device`` by the CPU tests only; the product's
+default device is ``HipDevice`` and never falls back to this.
+"""
+
+import math
+
+import numpy as np
+
+
+def _offsets(groups, col):
+    """Element offsets of a bundle: mixed radix over groups (last fastest)."""
+    off = np.zeros(1, dtype=np.int64)
+    for g in groups:
+        d, s = g[0], g[col]
+        off = (off[:, None] + (np.arange(d, dtype=np.int64) * s)[None, :]).reshape(-1)
+    return off
+
+
+class EmuDevice:
+    name = "emu"
+
+    def __init__(self):
+        self.calls = {"contract_pair": 0, "permute": 0, "reduce_sum": 0, "binary": 0, "strip": 0}
+
+    # memory
+    def empty(self, n, dtype):
+        return np.zeros(max(int(n), 1), dtype=np.dtype(dtype))
+
+    def from_host(self, x):
+        x = np.ascontiguousarray(x)
+        return x.reshape(-1).copy() if x.size else np.zeros(1, x.dtype)
+
+    def to_host(self, buf, n, dtype):
+        return buf[: max(int(n), 0)].copy()
+
+    def clone(self, buf):
+        return buf.copy()
+
+    def synchronize(self):
+        pass
+
+    # kernels
+    def contract_pair(self, spec, dtype, a, b, c):
+        self.calls["contract_pair"] += 1
+        ob_a, ob_b, ob_c = _offsets(spec.b, 1), _offsets(spec.b, 2), _offsets(spec.b, 3)
+        om_a, om_c = _offsets(spec.m, 1), _offsets(spec.m, 3)
+        on_b, on_c = _offsets(spec.n, 2), _offsets(spec.n, 3)
+        ok_a, ok_b = _offsets(spec.k, 1), _offsets(spec.k, 2)
+        A = a[ob_a[:, None, None] + om_a[None, :, None] + ok_a[None, None, :]]
+        B = b[ob_b[:, None, None] + ok_b[None, :, None] + on_b[None, None, :]]
+        C = np.matmul(A, B)
+        idx = ob_c[:, None, None] + om_c[None, :, None] + on_c[None, None, :]
+        assert len(np.unique(idx)) == idx.size, "output offsets collide"
+        c[idx] = C
+
+    def permute(self, dst, src, shape, strides, offset, dtype):
+        self.calls["permute"] += 1
+        n = int(np.prod(shape)) if len(shape) else 1
+        off = np.full(1, int(offset), dtype=np.int64)
+        for d, s in zip(shape, strides):
+            off = (off[:, None] + (np.arange(d, dtype=np.int64) * s)[None, :]).reshape(-1)
+        dst[:n] = src[off]
+
+    def reduce_sum(self, out, x, keep_shape, keep_strides, red_shape, red_strides, dtype):
+        self.calls["reduce_sum"] += 1
+        ok = _offsets([(d, s) for d, s in zip(keep_shape, keep_strides)], 1)
+        orr = _offsets([(d, s) for d, s in zip(red_shape, red_strides)], 1)
+        out[: ok.size] = x[ok[:, None] + orr[None, :]].sum(axis=1)
+
+    def binary(self, out, a, a_strides, b, b_strides, shape, op, dtype):
+        self.calls["binary"] += 1
+        oa = _offsets([(d, s) for d, s in zip(shape, a_strides)], 1)
+        ob = _offsets([(d, s) for d, s in zip(shape, b_strides)], 1)
+        va, vb = a[oa], b[ob]
+        out[: oa.size] = va + vb if op == "add" else (va * vb if op == "mul" else va - vb)
+
+    def scale(self, x, n, factor, dtype):
+        f = complex(factor)
+        x[:n] = x[:n] * (f if np.dtype(dtype).kind == "c" else f.real)
+
+    def axpby(self, y, x, n, fy, fx, dtype):
+        y[:n] = y[:n] * fy + x[:n] * fx
+
+    def conj(self, dst, src, n, dtype):
+        dst[:n] = np.conj(src[:n])
+
+    def cast(self, dst, dst_dtype, src, src_dtype, n):
+        v = src[:n]
+        if np.dtype(dst_dtype).kind != "c" and np.dtype(src_dtype).kind == "c":
+            v = v.real
+        dst[:n] = v.astype(dst_dtype)
+
+    def fill(self, dst, n, value, dtype):
+        dst[:n] = value if np.dtype(dtype).kind == "c" else complex(value).real
+
+    def new_exponent(self):
+        return np.zeros(1, dtype=np.float64)
+
+    def strip_exponent(self, x, n, dtype, exponent):
+        self.calls["strip"] += 1
+        m = float(np.max(np.abs(x[:n]))) if n else 0.0
+        if m > 0:
+            x[:n] = x[:n] / np.asarray(m, dtype=x.real.dtype)
+            exponent[0] += math.log10(m)
+
+    def read_exponent(self, exponent):
+        return float(exponent[0])
+
+    def absmax(self, x, n, dtype):
+        return float(np.max(np.abs(x[:n]))) if n else 0.0
