@@ -75,6 +75,25 @@ def _einsum_inds(arrays, inds_list, out_inds):
     return np.einsum(eq, *arrays)
 
 
+def _pair_contract(ops, tis, keep):
+    """One pairwise step the way cotengra's executor issues it: ``tensordot``
+    (transpose-copies + BLAS gemm inside numpy) when there are no batch / hyper
+    indices, ``einsum`` otherwise.  Returns (array, its index order)."""
+    if len(ops) == 2:
+        ia, ib = tis
+        sa, sb, sk = set(ia), set(ib), set(keep)
+        shared = [ix for ix in ia if ix in sb]
+        simple = len(sa) == len(ia) and len(sb) == len(ib) and not any(ix in sk for ix in shared)
+        simple = simple and all(ix in sk for ix in ia if ix not in sb) and all(ix in sk for ix in ib if ix not in sa)
+        if simple:
+            ax_a = [ia.index(ix) for ix in shared]
+            ax_b = [ib.index(ix) for ix in shared]
+            x = np.tensordot(ops[0], ops[1], axes=(ax_a, ax_b))
+            order = tuple(ix for ix in ia if ix not in sb) + tuple(ix for ix in ib if ix not in sa)
+            return x, order
+    return _einsum_inds(ops, tis, keep), tuple(keep)
+
+
 def oracle_contract_core(arrays, inputs, output, path, strip_exponent=False):
     """Pairwise evaluation along a linear (opt_einsum style) path."""
     arrays = list(arrays)
@@ -88,7 +107,7 @@ def oracle_contract_core(arrays, inputs, output, path, strip_exponent=False):
             keep = _pair_result_inds(tis[0], (), inputs, output)
         else:
             keep = _pair_result_inds(tis[0], tis[1], inputs, output)
-        x = _einsum_inds(ops, tis, keep)
+        x, keep = _pair_contract(ops, tis, keep)
         if strip_exponent:
             f = np.max(np.abs(x))
             if f > 0:

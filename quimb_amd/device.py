@@ -86,6 +86,9 @@ class HipDevice:
         self._pairs = {}
         self._ws = None
         self._scratch = torch.zeros(4, dtype=torch.float64, device=self.tdev)
+        #: set to a list to collect (spec, dtype, tile_cfg, split_k, start_event, end_event)
+        #: per qamd_contract_pair launch (HIP events on the launch stream)
+        self.profile = None
         self.force_tile_cfg = int(os.environ.get("QAMD_TILE_CFG", "-1"))
         self.force_split_k = int(os.environ.get("QAMD_SPLIT_K", "0"))
 
@@ -147,12 +150,20 @@ class HipDevice:
         pa, pb = a.data_ptr(), b.data_ptr()
         cp = self.compile_pair(spec, dtype, min(pa & -pa, 16), min(pb & -pb, 16))
         ws, wsn = self._workspace(cp.ws_bytes)
+        prof = self.profile
+        if prof is not None:
+            e0 = self.torch.cuda.Event(enable_timing=True)
+            e1 = self.torch.cuda.Event(enable_timing=True)
+            e0.record()
         _lib.check(
             self.lib.qamd_contract_pair(
                 C.byref(cp.struct), pa, pb, c.data_ptr(), cp.ktab.data_ptr(), ws, wsn, self.stream()
             ),
             "qamd_contract_pair",
         )
+        if prof is not None:
+            e1.record()
+            prof.append((spec, np.dtype(dtype), cp.struct.tile_cfg, cp.struct.split_k, e0, e1))
 
     # ---- layout / elementwise -----------------------------------------------
     def permute(self, dst, src, shape, strides, offset, dtype):

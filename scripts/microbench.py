@@ -1,0 +1,75 @@
+#!/usr/bin/env python
+"""Kernel micro-benchmarks (HIP events): GETT at compute- and HBM-bound shapes,
+tiled permute.  Usage: python scripts/microbench.py [--quick]"""
+import os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+import quimb_amd as qa
+from quimb_amd.pairwise import plan_pair
+from quimb_amd.ops import run_pair_step
+
+dev = qa.default_device()
+
+def timeit(fn, reps=10, warm=2):
+    for _ in range(warm): fn()
+    torch.cuda.synchronize()
+    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps * 1e-3
+
+def rnd(shape, dtype="float32"):
+    t = torch.rand(int(np.prod(shape)), device=dev.tdev, dtype=torch.float32) - 0.5
+    if dtype == "float64": t = t.double()
+    return qa.Array(dev, t, shape, dtype)
+
+def bench_pair(name, ai, ash, bi, bsh, oi, fixed=True, dtype="float32", cfgs=(-1,)):
+    a, b = rnd(ash, dtype), rnd(bsh, dtype)
+    step = plan_pair(tuple(ai), tuple(ash), tuple(bi), tuple(bsh), tuple(oi), fixed)
+    g = step.spec
+    out = qa.Array.empty(step.out_shape, dtype, dev)
+    isz = np.dtype(dtype).itemsize
+    flops = 2 * g.mults
+    nbytes = isz * g.B * (g.M * g.K + g.K * g.N + g.M * g.N)
+    for cfg in cfgs:
+        dev.force_tile_cfg = cfg
+        try:
+            t = timeit(lambda: run_pair_step(step, a, b, out))
+        except Exception as e:
+            print(f"{name:34s} cfg={cfg} FAILED {e}"); continue
+        cp = [v for k, v in dev._pairs.items() if k[0] == g and k[4] == cfg][-1]
+        print(f"{name:34s} cfg={cp.struct.tile_cfg} sk={cp.struct.split_k} va={cp.struct.vec_a} vb={cp.struct.vec_b} "
+              f"akc={cp.struct.a_kcontig} cn={cp.struct.c_ncontig} BMNK=({g.B},{g.M},{g.N},{g.K}) "
+              f"{t*1e3:9.3f} ms {flops/t/1e12:8.2f} TF {nbytes/t/1e9:8.1f} GB/s", flush=True)
+    dev.force_tile_cfg = -1
+
+quick = "--quick" in sys.argv
+print("== GETT fp32: square GEMMs (compute-bound)")
+for n in ([2048, 4096] if quick else [1024, 2048, 4096, 8192]):
+    bench_pair(f"gemm {n}^3 NN", "mk", (n, n), "kn", (n, n), "mn", cfgs=(0, 1))
+bench_pair("gemm 4096^3 TN (A k-major)", "km", (4096, 4096), "kn", (4096, 4096), "mn", cfgs=(0,))
+bench_pair("gemm 4096^3 NT", "mk", (4096, 4096), "nk", (4096, 4096), "mn", cfgs=(0,))
+print("== GETT fp64")
+bench_pair("dgemm 4096^3 NN", "mk", (4096, 4096), "kn", (4096, 4096), "mn", dtype="float64", cfgs=(0, 1))
+print("== PEPS sweep steps, D=6 (HBM-bound): A[L,h,v,R] x S[h,x,v,y] -> C[L,y?,x?,R]")
+for (L, R) in [(6**4, 6**5), (6**8, 6), (6**9, 1), (1, 6**9), (6**2, 6**7)]:
+    bench_pair(f"sweep L=6^{round(np.log(L)/np.log(6))} R=6^{round(np.log(R)/np.log(6))}", "lhvr", (L, 6, 6, R), "hxvy", (6, 6, 6, 6), "lxyr", fixed=False, cfgs=(2, 1, 0))
+print("== merged 2-site step K=N=216")
+bench_pair("sweep2 L=6^4 R=6^4", "lkr", (6**4, 216, 6**4), "kn", (216, 216), "lnr", fixed=True, cfgs=(0, 1))
+print("== gate on state: psi[2^a,2,2^b] x G[2,2]")
+bench_pair("1q gate on 2^28 state", "lkr", (2**14, 2, 2**13), "kn", (2, 2), "lnr", cfgs=(3,))
+bench_pair("2q gate on 2^28 state", "lkr", (2**13, 4, 2**13), "kn", (4, 4), "lnr", cfgs=(3,))
+print("== permute fp32")
+def bench_perm(name, shape, perm):
+    x = rnd(shape)
+    t = timeit(lambda: x.transpose(perm))
+    nb = 2 * 4 * int(np.prod(shape))
+    print(f"{name:34s} {t*1e3:9.3f} ms {nb/t/1e9:8.1f} GB/s", flush=True)
+bench_perm("2D 16384x16384 transpose", (16384, 16384), (1, 0))
+bench_perm("6^11 reverse", (6,) * 11, tuple(reversed(range(11))))
+bench_perm("6^11 swap last two", (6,) * 11, tuple(range(9)) + (10, 9))
+bench_perm("6^11 rotate", (6,) * 11, tuple(range(1, 11)) + (0,))
+bench_perm("[L,36,R] -> [L,R,36]", (6**4, 36, 6**5), (0, 2, 1))

@@ -1,0 +1,53 @@
+"""The C-ABI shared library loads (no GPU needed) and exports every symbol
+``include/quimb_amd.h`` declares; host-only entry points behave."""
+
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from quimb_amd import _lib
+from quimb_amd.device import fill_plan_struct
+from quimb_amd.pairwise import plan_pair
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _ensure_built():
+    if not os.path.exists(_lib.library_path()):
+        import __graft_entry__ as g
+
+        g.build()
+
+
+def test_header_symbols_exported():
+    _ensure_built()
+    hdr = open(os.path.join(ROOT, "include", "quimb_amd.h")).read()
+    declared = set(re.findall(r"\b(qamd_[a-z_0-9]+)\s*\(", hdr))
+    declared = {d for d in declared if not d.endswith("_dtype")}
+    lib = C.CDLL(_lib.library_path())
+    missing = [s for s in sorted(declared) if not hasattr(lib, s)]
+    assert not missing, missing
+    assert {n for n, _, _ in _lib.SYMBOLS} == declared
+
+
+def test_load_and_plan_finalize():
+    _ensure_built()
+    lib = _lib.load()
+    assert lib.qamd_abi_version() == 1
+    assert b"gfx950" in lib.qamd_build_info()
+    step = plan_pair(("l", "h", "v", "r"), (36, 6, 6, 216), ("h", "x", "v", "y"), (6, 6, 6, 6), ("l", "x", "y", "r"), False)
+    p = fill_plan_struct(step.spec, _lib.QAMD_F32)
+    assert lib.qamd_pair_plan_finalize(C.byref(p), 16, 16) == 0
+    assert p.tile_cfg == 2 and p.vec_a == 4 and p.a_kcontig == 0 and p.c_ncontig == 0
+    assert lib.qamd_pair_ktab_len(C.byref(p)) == 2 * 48
+    assert lib.qamd_pair_workspace_bytes(C.byref(p)) == 0
+    # malformed plan is rejected, not crashed on
+    p.nm = 99
+    assert lib.qamd_pair_plan_finalize(C.byref(p), 16, 16) == -1
+
+
+def test_struct_layout_matches_header():
+    # int32 x8 + 13 int64[8] arrays + int32 x8
+    assert C.sizeof(_lib.PairPlanStruct) == 8 * 4 + 13 * 8 * 8 + 8 * 4

@@ -1,0 +1,93 @@
+"""Parity tests proper: the HIP path (through the C-ABI) against the oracle /
+numpy on the same seeded inputs.  Run with ``-m gpu`` on an MI355X."""
+
+import numpy as np
+import pytest
+
+import checks
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("dtype", ["float32", "float64"])
+def test_pairwise(hip, dtype):
+    checks.check_pairwise(dtype)
+    # bond-dimension-6 shapes (the headline network's dims)
+    checks.check_pairwise(dtype, seed=10, dims=dict(a=6, b=6, c=6, d=6, e=6, f=6, g=6))
+
+
+@pytest.mark.parametrize("dtype", ["float32", "float64"])
+def test_tensordot_matmul(hip, dtype):
+    checks.check_tensordot_matmul(dtype)
+
+
+@pytest.mark.parametrize("dtype", ["float32", "float64"])
+def test_layout_ops(hip, dtype):
+    checks.check_layout_ops(dtype)
+
+
+@pytest.mark.parametrize("dtype", ["float32", "float64"])
+def test_tree_executor(hip, dtype):
+    checks.check_tree_executor(dtype)
+
+
+def test_hyper_network(hip):
+    checks.check_hyper_network("float64")
+    checks.check_hyper_network("float32")
+
+
+@pytest.mark.parametrize("dtype", ["float32", "float64"])
+def test_strip_exponent(hip, dtype):
+    checks.check_strip_exponent(dtype)
+
+
+@pytest.mark.parametrize("dtype", ["float32", "float64"])
+def test_sliced(hip, dtype):
+    checks.check_sliced(dtype)
+
+
+def test_tensor_contract_semantics(hip):
+    checks.check_tensor_contract_semantics()
+
+
+def test_mps_dense(hip):
+    checks.check_mps_dense()
+
+
+def test_mps_L20_chi8_plumbing(hip):
+    """BASELINE config #1: MPS(L=20, bond_dim=8) contracted to its dense 2^20 vector."""
+    checks.check_mps_dense("float64", L=20, chi=8)
+
+
+def test_ising_known_answer(hip):
+    """The reference's fixed-number KAT on this path: 16x16 classical Ising at
+    beta=0.44 -> 8.459419593253275e100 (tests/test_tensor/test_tn2d/test_core.py:309-335),
+    here contracted exactly in fp64 with on-device exponent stripping."""
+    Z = checks.check_ising(16, 16, 0.44)
+    assert Z == pytest.approx(8.459419593253275e100, rel=1e-9)
+
+
+def test_peps_6x6_D6_fp32_vs_fp64_oracle(hip):
+    """Scaled-down headline network (D=6 bonds) against the fp64 oracle at the
+    north-star tolerance (1e-6 rel would need fp64; fp32 MFMA gives ~1e-6)."""
+    from oracle import np_oracle as orc
+    import quimb_amd as qa
+
+    arrays, inputs = orc.tn2d_rand(6, 6, 6, seed=3, dtype="float32")
+    size = {ix: 6 for t in inputs for ix in t}
+    tree = qa.ContractionTree(inputs, (), size, path=qa.sweep_path_2d(6, 6))
+    want = orc.oracle_array_contract([a.astype(np.float64) for a in arrays], inputs, (), path=tree.get_path(),
+                                     strip_exponent=True)
+    m, e = qa.TreeExecutor(tree, "float32")(arrays, strip_exponent=True)
+    got = m.to_numpy().item() * 10.0**e
+    ref = want[0].item() * 10.0 ** want[1]
+    assert got == pytest.approx(ref, rel=5e-6)
+
+
+def test_no_cpu_fallback(hip):
+    """The product device is the HIP one and the shared library is loaded."""
+    import quimb_amd.device as qd
+    from quimb_amd import _lib
+
+    assert isinstance(qd.default_device(), qd.HipDevice)
+    assert _lib._LIB is not None and _lib._LIB.qamd_abi_version() == 1
