@@ -74,7 +74,7 @@ typedef struct {
   int32_t dtype;     /* qamd_dtype                                       */
   int32_t nb, nm, nn, nk;
   int32_t conj_a, conj_b; /* complex only                                */
-  int32_t reserved;
+  int32_t kernel;    /* filled by finalize: 0 tiled GETT, 1 streaming (big x small) */
   int64_t dim_b[QAMD_MAX_GROUPS], sa_b[QAMD_MAX_GROUPS], sb_b[QAMD_MAX_GROUPS], sc_b[QAMD_MAX_GROUPS];
   int64_t dim_m[QAMD_MAX_GROUPS], sa_m[QAMD_MAX_GROUPS], sc_m[QAMD_MAX_GROUPS];
   int64_t dim_n[QAMD_MAX_GROUPS], sb_n[QAMD_MAX_GROUPS], sc_n[QAMD_MAX_GROUPS];
@@ -85,14 +85,32 @@ typedef struct {
   int32_t vec_a, vec_b; /* 1,2,4: elements per contiguous global load    */
   int32_t a_kcontig, b_kcontig; /* 1: stride-1 index lives in the K bundle */
   int32_t c_ncontig; /* 1: C's stride-1 index lives in the N bundle      */
-  int32_t reserved2;
+  int32_t vec_c;     /* streaming kernel: elements per contiguous C store */
 } qamd_pair_plan;
+
+/*
+ * Fused exponent stripping (strip_exponent=True, tensor_core.py:330-340).
+ * Every tensor that takes part owns QAMD_ABSMAX_SLOTS values of the plan's REAL
+ * dtype holding partial max|x| (sharded atomicMax targets; the true max is the
+ * max over the slots).  A contraction multiplies its result by
+ * 1 / (max|A| * max|B|) -- i.e. consumes operands as if they had been divided by
+ * their max, which is what the reference does right after producing them -- and
+ * reduces max|C| into absmax_out (caller zeroes it before the launch).  Any
+ * pointer may be NULL (= scale 1 / no reduction).
+ */
+#define QAMD_ABSMAX_SLOTS 64
+typedef struct {
+  const void* scale_a;
+  const void* scale_b;
+  void* absmax_out;
+} qamd_epilogue;
 
 int qamd_abi_version(void);
 const char* qamd_build_info(void);
 
 /* Validate the plan, pick tile config / split-K / vector widths. */
-int qamd_pair_plan_finalize(qamd_pair_plan* plan, int64_t align_a_bytes, int64_t align_b_bytes);
+int qamd_pair_plan_finalize(qamd_pair_plan* plan, int64_t align_a_bytes, int64_t align_b_bytes,
+                            int64_t align_c_bytes);
 /* Number of int64 entries the K-offset table needs (2 * padded K). */
 int64_t qamd_pair_ktab_len(const qamd_pair_plan* plan);
 /* Fill the K-offset table (device memory, int64[qamd_pair_ktab_len]). */
@@ -102,6 +120,19 @@ int64_t qamd_pair_workspace_bytes(const qamd_pair_plan* plan);
 /* C = A . B (overwrites C). */
 int qamd_contract_pair(const qamd_pair_plan* plan, const void* A, const void* B, void* C,
                        const void* ktab_dev, void* workspace, int64_t workspace_bytes, void* stream);
+
+/* Same with the fused exponent-stripping epilogue (ep may be NULL). */
+int qamd_contract_pair_ex(const qamd_pair_plan* plan, const void* A, const void* B, void* C,
+                          const void* ktab_dev, void* workspace, int64_t workspace_bytes,
+                          const qamd_epilogue* ep, void* stream);
+/*
+ * slots: n_tensors x QAMD_ABSMAX_SLOTS values (float for F32/C64, double
+ * otherwise).  *out_dev (double, device) = sum_t log10(max over tensor t's slots),
+ * tensors whose max is 0 are skipped.
+ */
+int qamd_absmax_log10_sum(const void* slots, int64_t n_tensors, int32_t dtype, void* out_dev, void* stream);
+/* x[i] /= max(slots[0..QAMD_ABSMAX_SLOTS))  (no-op if that max is 0) */
+int qamd_div_by_absmax(void* x, int64_t n, const void* slots, int32_t dtype, void* stream);
 
 /*
  * dst (C-contiguous, given shape) <- src viewed with arbitrary element
@@ -137,7 +168,7 @@ int qamd_fill(void* dst, int64_t n, double re, double im, int32_t dtype, void* s
  */
 int qamd_strip_exponent(void* x, int64_t n, int32_t dtype, void* scratch_dev,
                         void* exponent_dev, void* stream);
-/* out_dev (double, device) = max|x| */
+/* out_dev[0] (double, device) = max|x|; out_dev must provide 16 bytes (8 of scratch) */
 int qamd_absmax(void* out_dev, const void* x, int64_t n, int32_t dtype, void* stream);
 
 #ifdef __cplusplus

@@ -25,7 +25,7 @@ class PairPlanStruct(C.Structure):
         ("nk", C.c_int32),
         ("conj_a", C.c_int32),
         ("conj_b", C.c_int32),
-        ("reserved", C.c_int32),
+        ("kernel", C.c_int32),
         ("dim_b", _I64G), ("sa_b", _I64G), ("sb_b", _I64G), ("sc_b", _I64G),
         ("dim_m", _I64G), ("sa_m", _I64G), ("sc_m", _I64G),
         ("dim_n", _I64G), ("sb_n", _I64G), ("sc_n", _I64G),
@@ -37,9 +37,17 @@ class PairPlanStruct(C.Structure):
         ("a_kcontig", C.c_int32),
         ("b_kcontig", C.c_int32),
         ("c_ncontig", C.c_int32),
-        ("reserved2", C.c_int32),
+        ("vec_c", C.c_int32),
     ]
 
+
+class Epilogue(C.Structure):
+    """Mirror of ``qamd_epilogue``."""
+
+    _fields_ = [("scale_a", C.c_void_p), ("scale_b", C.c_void_p), ("absmax_out", C.c_void_p)]
+
+
+ABSMAX_SLOTS = 64
 
 #: every symbol ``include/quimb_amd.h`` declares: (name, restype, argtypes)
 _vp, _i32, _i64, _dbl = C.c_void_p, C.c_int32, C.c_int64, C.c_double
@@ -48,11 +56,14 @@ _pplan = C.POINTER(PairPlanStruct)
 SYMBOLS = [
     ("qamd_abi_version", C.c_int, []),
     ("qamd_build_info", C.c_char_p, []),
-    ("qamd_pair_plan_finalize", C.c_int, [_pplan, _i64, _i64]),
+    ("qamd_pair_plan_finalize", C.c_int, [_pplan, _i64, _i64, _i64]),
     ("qamd_pair_ktab_len", _i64, [_pplan]),
     ("qamd_pair_build_ktab", C.c_int, [_pplan, _vp, _vp]),
     ("qamd_pair_workspace_bytes", _i64, [_pplan]),
     ("qamd_contract_pair", C.c_int, [_pplan, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
+    ("qamd_contract_pair_ex", C.c_int, [_pplan, _vp, _vp, _vp, _vp, _vp, _i64, C.POINTER(Epilogue), _vp]),
+    ("qamd_absmax_log10_sum", C.c_int, [_vp, _i64, _i32, _vp, _vp]),
+    ("qamd_div_by_absmax", C.c_int, [_vp, _i64, _vp, _i32, _vp]),
     ("qamd_permute", C.c_int, [_vp, _vp, _i32, _pi64, _pi64, _i64, _i32, _vp]),
     ("qamd_reduce_sum", C.c_int, [_vp, _vp, _i32, _pi64, _pi64, _i32, _pi64, _pi64, _i32, _vp]),
     ("qamd_binary", C.c_int, [_vp, _vp, _pi64, _vp, _pi64, _i32, _pi64, _i32, _i32, _vp]),
@@ -101,6 +112,11 @@ def load():
             f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "or `make -C quimb_amd/csrc` -- quimb_amd has no CPU fallback"
         )
+    # torch bundles its own libamdhip64; import it FIRST so that this library binds
+    # to the same already-loaded HIP runtime (two runtimes in one process cannot
+    # share streams / allocations and every launch fails).
+    import torch  # noqa: F401
+
     lib = C.CDLL(path)
     for name, restype, argtypes in SYMBOLS:
         try:

@@ -62,7 +62,14 @@ static const int kTileBN[5] = {128, 64, 48, 16, 32};
 static const int kBK = 16;
 static const int kNumCU = 256;
 
-extern "C" int qamd_pair_plan_finalize(qamd_pair_plan* p, int64_t align_a, int64_t align_b) {
+static int stream_lds_bytes(int64_t K, int64_t N, int es) {
+  int64_t kpad = ((K + 3) / 4) * 4;
+  int64_t npad = ((N + 15) / 16) * 16;
+  int64_t ldw = npad + ((48 - npad % 32) % 32);
+  return (int)((2 * npad + kpad) * 8 + kpad * ldw * es);
+}
+
+extern "C" int qamd_pair_plan_finalize(qamd_pair_plan* p, int64_t align_a, int64_t align_b, int64_t align_c) {
   PairDims d;
   int rc = pair_dims(p, d);
   if (rc) return rc;
@@ -106,6 +113,28 @@ extern "C" int qamd_pair_plan_finalize(qamd_pair_plan* p, int64_t align_a, int64
     bool n1 = p->nn > 0 && p->sc_n[p->nn - 1] == 1;
     bool m1 = p->nm > 0 && p->sc_m[p->nm - 1] == 1;
     p->c_ncontig = (n1 || !m1) ? 1 : 0;
+  }
+
+  // ---- streaming kernel eligibility (big tensor x small tensor) ---------------
+  // A and C both have their stride-1 index in the M bundle (same fused group), the
+  // whole small operand fits in LDS, no batch bundle.
+  {
+    bool want = (p->kernel != 0) || true;
+    bool ok = want && p->nb == 0 && p->nm >= 1 && p->sa_m[p->nm - 1] == 1 && p->sc_m[p->nm - 1] == 1 &&
+              d.N <= 64 && d.M >= 4096 && d.K <= 4096 && stream_lds_bytes(d.K, d.N, es) <= 64 * 1024;
+    int vc = 1;
+    if (ok) {
+      std::vector<int64_t> others;
+      for (int i = 0; i + 1 < p->nm; ++i) others.push_back(p->sc_m[i]);
+      for (int i = 0; i < p->nn; ++i) others.push_back(p->sc_n[i]);
+      vc = pick_vec(p->dim_m[p->nm - 1], align_c, es, others);
+      int va = p->a_kcontig ? 1 : p->vec_a;
+      vc = std::min(vc, va);
+      if (es == 8 && vc > 2) vc = 2;
+    }
+    p->vec_c = vc;
+    if (p->kernel == -1) p->kernel = 0;        // caller forces the tiled kernel
+    else p->kernel = ok ? 1 : 0;
   }
 
   // ---- tile shape -----------------------------------------------------------
@@ -179,13 +208,46 @@ extern "C" int64_t qamd_pair_workspace_bytes(const qamd_pair_plan* p) {
 
 extern "C" int qamd_contract_pair(const qamd_pair_plan* p, const void* A, const void* B, void* C,
                                   const void* ktab, void* ws, int64_t ws_bytes, void* stream) {
+  return qamd_contract_pair_ex(p, A, B, C, ktab, ws, ws_bytes, nullptr, stream);
+}
+
+static int launch_stream(const qamd_pair_plan* p, const PairDims& d, const void* A, const void* B, void* C,
+                         const void* ktab, const qamd_epilogue* ep, void* stream) {
+  StreamArgs s;
+  memset(&s, 0, sizeof(s));
+  s.nm = p->nm; s.nn = p->nn;
+  for (int i = 0; i < p->nm; ++i) { s.dim_m[i] = (uint32_t)p->dim_m[i]; s.sa_m[i] = p->sa_m[i]; s.sc_m[i] = p->sc_m[i]; }
+  for (int i = 0; i < p->nn; ++i) { s.dim_n[i] = (uint32_t)p->dim_n[i]; s.sb_n[i] = p->sb_n[i]; s.sc_n[i] = p->sc_n[i]; }
+  s.M = (uint32_t)d.M; s.N = (uint32_t)d.N; s.K = (uint32_t)d.K;
+  s.KS = (uint32_t)((d.K + 3) / 4);
+  s.Kpad = 4 * s.KS;
+  s.KpadTab = (uint32_t)(((d.K + 15) / 16) * 16);
+  s.NT = (uint32_t)((d.N + 15) / 16);
+  const int V = p->vec_c;
+  s.chunks = (uint32_t)((d.M + 16 * V - 1) / (16 * V));
+  const uint32_t target_waves = 256 * 4 * 3;
+  s.chunks_per_wave = (s.chunks + target_waves - 1) / target_waves;
+  if (s.chunks_per_wave < 1) s.chunks_per_wave = 1;
+  uint32_t waves = (s.chunks + s.chunks_per_wave - 1) / s.chunks_per_wave;
+  s.grid = (waves + 3) / 4;
+  return qamd_stream_launch(p->dtype, V, &s, A, B, C, ktab, ep ? ep->scale_a : nullptr,
+                            ep ? ep->scale_b : nullptr, ep ? ep->absmax_out : nullptr, stream);
+}
+
+extern "C" int qamd_contract_pair_ex(const qamd_pair_plan* p, const void* A, const void* B, void* C,
+                                     const void* ktab, void* ws, int64_t ws_bytes, const qamd_epilogue* ep,
+                                     void* stream) {
   PairDims d;
   int rc = pair_dims(p, d);
   if (rc) return rc;
   if (p->dtype != QAMD_F32 && p->dtype != QAMD_F64) return QAMD_EUNSUPPORTED;
   if (p->tile_cfg < 0 || p->tile_cfg > 4 || p->split_k < 1) return QAMD_EINVAL;
   if (!A || !B || !C || !ktab) return QAMD_EINVAL;
+  if (p->kernel == 1) return launch_stream(p, d, A, B, C, ktab, ep, stream);
   const int bm = kTileBM[p->tile_cfg], bn = kTileBN[p->tile_cfg];
+  const void* sa = ep ? ep->scale_a : nullptr;
+  const void* sb = ep ? ep->scale_b : nullptr;
+  void* amax = ep ? ep->absmax_out : nullptr;
 
   GettArgs a;
   memset(&a, 0, sizeof(a));
@@ -220,15 +282,15 @@ extern "C" int qamd_contract_pair(const qamd_pair_plan* p, const void* A, const 
 
   if (split == 1) {
     a.slab_stride = 0;
-    return qamd_gett_launch(p->dtype, p->tile_cfg, &a, swap, A, B, C, ktab, stream);
+    return qamd_gett_launch(p->dtype, p->tile_cfg, &a, swap, A, B, C, ktab, sa, sb, amax, stream);
   }
   const int64_t csize = d.B * d.M * d.N;
   if (c_extent(p) != csize) return QAMD_EUNSUPPORTED;  // split-K needs a compact C
   if (!ws || ws_bytes < (int64_t)split * csize * kEsize[p->dtype]) return QAMD_EWORKSPACE;
   a.slab_stride = csize;
-  rc = qamd_gett_launch(p->dtype, p->tile_cfg, &a, swap, A, B, ws, ktab, stream);
+  rc = qamd_gett_launch(p->dtype, p->tile_cfg, &a, swap, A, B, ws, ktab, nullptr, nullptr, nullptr, stream);
   if (rc) return rc;
-  return qamd_splitk_reduce_launch(p->dtype, C, ws, csize, split, stream);
+  return qamd_splitk_reduce_launch(p->dtype, C, ws, csize, split, sa, sb, amax, stream);
 }
 
 // ---------------------------------------------------------------------------

@@ -10,6 +10,11 @@
 #include <stdint.h>
 #include "ew_args.h"
 
+// hipGetLastError() also reports benign stale codes (hipErrorNotReady from an
+// event query by the allocator, ...): clear them before each launch so the
+// post-launch check only sees this launch.
+#define QAMD_LAUNCH(...) do { (void)hipGetLastError(); hipLaunchKernelGGL(__VA_ARGS__); } while (0)
+
 namespace qamd {
 
 template <typename T> struct CT;  // complex helpers
@@ -318,6 +323,36 @@ __global__ void strip_finish_kernel(double* __restrict__ exponent, typename Bits
   }
 }
 
+// sum_t log10(max over tensor t's slots); one wave per launch is plenty
+template <typename R>
+__global__ void absmax_log10_sum_kernel(const R* __restrict__ slots, int64_t nt, double* __restrict__ out) {
+  double s = 0.0;
+  for (int64_t t = threadIdx.x; t < nt; t += 64) {
+    R m = R(0);
+    for (int i = 0; i < 64; ++i) {
+      R v = slots[t * 64 + i];
+      m = v > m ? v : m;
+    }
+    if (m > R(0)) s += log10((double)m);
+  }
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) s += __shfl_down(s, d, 64);
+  if (threadIdx.x == 0) out[0] = s;
+}
+
+template <typename R>
+__global__ void div_by_absmax_kernel(R* __restrict__ x, int64_t n_real, const R* __restrict__ slots) {
+  R m = R(0);
+  for (int i = 0; i < 64; ++i) {
+    R v = slots[i];
+    m = v > m ? v : m;
+  }
+  if (!(m > R(0))) return;
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < n_real; i += stride) x[i] = x[i] / m;
+}
+
 }  // namespace qamd
 
 using namespace qamd;
@@ -336,9 +371,9 @@ extern "C" int qamd_permute_launch(int esize, void* dst, const void* src, const 
   if (grid == 0 || grid > 0x7fffffffull) return -1;
   size_t lds = (size_t)(2 * p->TX + 2 * p->TY) * 8 + (size_t)(p->TX + 1) * p->TY * esize;
   switch (esize) {
-    case 4: hipLaunchKernelGGL(permute_kernel<float>, dim3((uint32_t)grid), dim3(256), lds, st, (float*)dst, (const float*)src, *p); break;
-    case 8: hipLaunchKernelGGL(permute_kernel<double>, dim3((uint32_t)grid), dim3(256), lds, st, (double*)dst, (const double*)src, *p); break;
-    case 16: hipLaunchKernelGGL(permute_kernel<c128>, dim3((uint32_t)grid), dim3(256), lds, st, (c128*)dst, (const c128*)src, *p); break;
+    case 4: QAMD_LAUNCH(permute_kernel<float>, dim3((uint32_t)grid), dim3(256), lds, st, (float*)dst, (const float*)src, *p); break;
+    case 8: QAMD_LAUNCH(permute_kernel<double>, dim3((uint32_t)grid), dim3(256), lds, st, (double*)dst, (const double*)src, *p); break;
+    case 16: QAMD_LAUNCH(permute_kernel<c128>, dim3((uint32_t)grid), dim3(256), lds, st, (c128*)dst, (const c128*)src, *p); break;
     default: return -2;
   }
   QAMD_CHECK_LAUNCH();
@@ -349,10 +384,10 @@ extern "C" int qamd_reduce_sum_launch(int dtype, void* out, const void* x, const
   int64_t threads = p->wave_per_out ? (int64_t)p->n_keep * 64 : (int64_t)p->n_keep;
   uint32_t grid = flat_grid(threads);
   switch (dtype) {
-    case 0: hipLaunchKernelGGL(reduce_sum_kernel<float>, dim3(grid), dim3(256), 0, st, (float*)out, (const float*)x, *p); break;
-    case 1: hipLaunchKernelGGL(reduce_sum_kernel<double>, dim3(grid), dim3(256), 0, st, (double*)out, (const double*)x, *p); break;
-    case 2: hipLaunchKernelGGL(reduce_sum_kernel<c64>, dim3(grid), dim3(256), 0, st, (c64*)out, (const c64*)x, *p); break;
-    case 3: hipLaunchKernelGGL(reduce_sum_kernel<c128>, dim3(grid), dim3(256), 0, st, (c128*)out, (const c128*)x, *p); break;
+    case 0: QAMD_LAUNCH(reduce_sum_kernel<float>, dim3(grid), dim3(256), 0, st, (float*)out, (const float*)x, *p); break;
+    case 1: QAMD_LAUNCH(reduce_sum_kernel<double>, dim3(grid), dim3(256), 0, st, (double*)out, (const double*)x, *p); break;
+    case 2: QAMD_LAUNCH(reduce_sum_kernel<c64>, dim3(grid), dim3(256), 0, st, (c64*)out, (const c64*)x, *p); break;
+    case 3: QAMD_LAUNCH(reduce_sum_kernel<c128>, dim3(grid), dim3(256), 0, st, (c128*)out, (const c128*)x, *p); break;
     default: return -2;
   }
   QAMD_CHECK_LAUNCH();
@@ -362,10 +397,10 @@ extern "C" int qamd_binary_launch(int dtype, void* out, const void* a, const voi
   hipStream_t st = (hipStream_t)stream;
   uint32_t grid = flat_grid(p->n);
   switch (dtype) {
-    case 0: hipLaunchKernelGGL(binary_kernel<float>, dim3(grid), dim3(256), 0, st, (float*)out, (const float*)a, (const float*)b, *p); break;
-    case 1: hipLaunchKernelGGL(binary_kernel<double>, dim3(grid), dim3(256), 0, st, (double*)out, (const double*)a, (const double*)b, *p); break;
-    case 2: hipLaunchKernelGGL(binary_kernel<c64>, dim3(grid), dim3(256), 0, st, (c64*)out, (const c64*)a, (const c64*)b, *p); break;
-    case 3: hipLaunchKernelGGL(binary_kernel<c128>, dim3(grid), dim3(256), 0, st, (c128*)out, (const c128*)a, (const c128*)b, *p); break;
+    case 0: QAMD_LAUNCH(binary_kernel<float>, dim3(grid), dim3(256), 0, st, (float*)out, (const float*)a, (const float*)b, *p); break;
+    case 1: QAMD_LAUNCH(binary_kernel<double>, dim3(grid), dim3(256), 0, st, (double*)out, (const double*)a, (const double*)b, *p); break;
+    case 2: QAMD_LAUNCH(binary_kernel<c64>, dim3(grid), dim3(256), 0, st, (c64*)out, (const c64*)a, (const c64*)b, *p); break;
+    case 3: QAMD_LAUNCH(binary_kernel<c128>, dim3(grid), dim3(256), 0, st, (c128*)out, (const c128*)a, (const c128*)b, *p); break;
     default: return -2;
   }
   QAMD_CHECK_LAUNCH();
@@ -376,10 +411,10 @@ extern "C" int qamd_scale(void* x, int64_t n, double re, double im, int32_t dtyp
   if (n <= 0) return 0;
   uint32_t grid = flat_grid(n);
   switch (dtype) {
-    case 0: hipLaunchKernelGGL((scale_real_kernel<float, float>), dim3(grid), dim3(256), 0, st, (float*)x, n, (float)re); break;
-    case 1: hipLaunchKernelGGL((scale_real_kernel<double, double>), dim3(grid), dim3(256), 0, st, (double*)x, n, re); break;
-    case 2: hipLaunchKernelGGL((scale_cplx_kernel<c64, float>), dim3(grid), dim3(256), 0, st, (c64*)x, n, (float)re, (float)im); break;
-    case 3: hipLaunchKernelGGL((scale_cplx_kernel<c128, double>), dim3(grid), dim3(256), 0, st, (c128*)x, n, re, im); break;
+    case 0: QAMD_LAUNCH((scale_real_kernel<float, float>), dim3(grid), dim3(256), 0, st, (float*)x, n, (float)re); break;
+    case 1: QAMD_LAUNCH((scale_real_kernel<double, double>), dim3(grid), dim3(256), 0, st, (double*)x, n, re); break;
+    case 2: QAMD_LAUNCH((scale_cplx_kernel<c64, float>), dim3(grid), dim3(256), 0, st, (c64*)x, n, (float)re, (float)im); break;
+    case 3: QAMD_LAUNCH((scale_cplx_kernel<c128, double>), dim3(grid), dim3(256), 0, st, (c128*)x, n, re, im); break;
     default: return -2;
   }
   QAMD_CHECK_LAUNCH();
@@ -391,9 +426,9 @@ extern "C" int qamd_axpby(void* y, const void* x, int64_t n, double fy, double f
   int64_t nr = (dtype >= 2) ? 2 * n : n;
   uint32_t grid = flat_grid(nr);
   if (dtype == 0 || dtype == 2)
-    hipLaunchKernelGGL(axpby_kernel<float>, dim3(grid), dim3(256), 0, st, (float*)y, (const float*)x, nr, (float)fy, (float)fx);
+    QAMD_LAUNCH(axpby_kernel<float>, dim3(grid), dim3(256), 0, st, (float*)y, (const float*)x, nr, (float)fy, (float)fx);
   else if (dtype == 1 || dtype == 3)
-    hipLaunchKernelGGL(axpby_kernel<double>, dim3(grid), dim3(256), 0, st, (double*)y, (const double*)x, nr, fy, fx);
+    QAMD_LAUNCH(axpby_kernel<double>, dim3(grid), dim3(256), 0, st, (double*)y, (const double*)x, nr, fy, fx);
   else
     return -2;
   QAMD_CHECK_LAUNCH();
@@ -406,8 +441,8 @@ extern "C" int qamd_conj(void* dst, const void* src, int64_t n, int32_t dtype, v
   switch (dtype) {
     case 0: if (dst != src) hipMemcpyAsync(dst, src, (size_t)n * 4, hipMemcpyDeviceToDevice, st); break;
     case 1: if (dst != src) hipMemcpyAsync(dst, src, (size_t)n * 8, hipMemcpyDeviceToDevice, st); break;
-    case 2: hipLaunchKernelGGL(conj_kernel<c64>, dim3(grid), dim3(256), 0, st, (c64*)dst, (const c64*)src, n); break;
-    case 3: hipLaunchKernelGGL(conj_kernel<c128>, dim3(grid), dim3(256), 0, st, (c128*)dst, (const c128*)src, n); break;
+    case 2: QAMD_LAUNCH(conj_kernel<c64>, dim3(grid), dim3(256), 0, st, (c64*)dst, (const c64*)src, n); break;
+    case 3: QAMD_LAUNCH(conj_kernel<c128>, dim3(grid), dim3(256), 0, st, (c128*)dst, (const c128*)src, n); break;
     default: return -2;
   }
   QAMD_CHECK_LAUNCH();
@@ -418,9 +453,9 @@ extern "C" int qamd_fill(void* dst, int64_t n, double re, double im, int32_t dty
   if (n <= 0) return 0;
   uint32_t grid = flat_grid(n);
   if (dtype == 0 || dtype == 2)
-    hipLaunchKernelGGL(fill_kernel<float>, dim3(grid), dim3(256), 0, st, (float*)dst, n, (float)re, (float)im, dtype == 2);
+    QAMD_LAUNCH(fill_kernel<float>, dim3(grid), dim3(256), 0, st, (float*)dst, n, (float)re, (float)im, dtype == 2);
   else if (dtype == 1 || dtype == 3)
-    hipLaunchKernelGGL(fill_kernel<double>, dim3(grid), dim3(256), 0, st, (double*)dst, n, re, im, dtype == 3);
+    QAMD_LAUNCH(fill_kernel<double>, dim3(grid), dim3(256), 0, st, (double*)dst, n, re, im, dtype == 3);
   else
     return -2;
   QAMD_CHECK_LAUNCH();
@@ -433,10 +468,10 @@ extern "C" int qamd_cast(void* dst, int32_t dd, const void* src, int32_t sd, int
   uint32_t grid = flat_grid(n);
   bool d64 = (dd & 1), s64 = (sd & 1);
   int dc = dd >= 2, sc = sd >= 2;
-  if (!d64 && !s64) hipLaunchKernelGGL((cast_kernel<float, float>), dim3(grid), dim3(256), 0, st, (float*)dst, (const float*)src, n, dc, sc);
-  else if (!d64 && s64) hipLaunchKernelGGL((cast_kernel<float, double>), dim3(grid), dim3(256), 0, st, (float*)dst, (const double*)src, n, dc, sc);
-  else if (d64 && !s64) hipLaunchKernelGGL((cast_kernel<double, float>), dim3(grid), dim3(256), 0, st, (double*)dst, (const float*)src, n, dc, sc);
-  else hipLaunchKernelGGL((cast_kernel<double, double>), dim3(grid), dim3(256), 0, st, (double*)dst, (const double*)src, n, dc, sc);
+  if (!d64 && !s64) QAMD_LAUNCH((cast_kernel<float, float>), dim3(grid), dim3(256), 0, st, (float*)dst, (const float*)src, n, dc, sc);
+  else if (!d64 && s64) QAMD_LAUNCH((cast_kernel<float, double>), dim3(grid), dim3(256), 0, st, (float*)dst, (const double*)src, n, dc, sc);
+  else if (d64 && !s64) QAMD_LAUNCH((cast_kernel<double, float>), dim3(grid), dim3(256), 0, st, (double*)dst, (const float*)src, n, dc, sc);
+  else QAMD_LAUNCH((cast_kernel<double, double>), dim3(grid), dim3(256), 0, st, (double*)dst, (const double*)src, n, dc, sc);
   QAMD_CHECK_LAUNCH();
 }
 
@@ -450,11 +485,11 @@ extern "C" int qamd_absmax(void* out_dev, const void* x, int64_t n, int32_t dtyp
   if (grid > 1024) grid = 1024;
   int cplx = dtype >= 2;
   if (dtype == 0 || dtype == 2) {
-    if (n > 0) hipLaunchKernelGGL(absmax_kernel<float>, dim3(grid), dim3(256), 0, st, (unsigned int*)scratch, (const float*)x, n, cplx);
-    hipLaunchKernelGGL(absmax_finish_kernel<float>, dim3(1), dim3(64), 0, st, (double*)out_dev, (unsigned int*)scratch);
+    if (n > 0) QAMD_LAUNCH(absmax_kernel<float>, dim3(grid), dim3(256), 0, st, (unsigned int*)scratch, (const float*)x, n, cplx);
+    QAMD_LAUNCH(absmax_finish_kernel<float>, dim3(1), dim3(64), 0, st, (double*)out_dev, (unsigned int*)scratch);
   } else {
-    if (n > 0) hipLaunchKernelGGL(absmax_kernel<double>, dim3(grid), dim3(256), 0, st, (unsigned long long*)scratch, (const double*)x, n, cplx);
-    hipLaunchKernelGGL(absmax_finish_kernel<double>, dim3(1), dim3(64), 0, st, (double*)out_dev, (unsigned long long*)scratch);
+    if (n > 0) QAMD_LAUNCH(absmax_kernel<double>, dim3(grid), dim3(256), 0, st, (unsigned long long*)scratch, (const double*)x, n, cplx);
+    QAMD_LAUNCH(absmax_finish_kernel<double>, dim3(1), dim3(64), 0, st, (double*)out_dev, (unsigned long long*)scratch);
   }
   QAMD_CHECK_LAUNCH();
 }
@@ -470,13 +505,35 @@ extern "C" int qamd_strip_exponent(void* x, int64_t n, int32_t dtype, void* scra
   int cplx = dtype >= 2;
   int64_t nr = cplx ? 2 * n : n;
   if (dtype == 0 || dtype == 2) {
-    hipLaunchKernelGGL(absmax_kernel<float>, dim3(grid), dim3(256), 0, st, (unsigned int*)scratch_dev, (const float*)x, n, cplx);
-    hipLaunchKernelGGL(strip_scale_kernel<float>, dim3(flat_grid(nr)), dim3(256), 0, st, (float*)x, nr, (const unsigned int*)scratch_dev);
-    hipLaunchKernelGGL(strip_finish_kernel<float>, dim3(1), dim3(64), 0, st, (double*)exponent_dev, (unsigned int*)scratch_dev);
+    QAMD_LAUNCH(absmax_kernel<float>, dim3(grid), dim3(256), 0, st, (unsigned int*)scratch_dev, (const float*)x, n, cplx);
+    QAMD_LAUNCH(strip_scale_kernel<float>, dim3(flat_grid(nr)), dim3(256), 0, st, (float*)x, nr, (const unsigned int*)scratch_dev);
+    QAMD_LAUNCH(strip_finish_kernel<float>, dim3(1), dim3(64), 0, st, (double*)exponent_dev, (unsigned int*)scratch_dev);
   } else {
-    hipLaunchKernelGGL(absmax_kernel<double>, dim3(grid), dim3(256), 0, st, (unsigned long long*)scratch_dev, (const double*)x, n, cplx);
-    hipLaunchKernelGGL(strip_scale_kernel<double>, dim3(flat_grid(nr)), dim3(256), 0, st, (double*)x, nr, (const unsigned long long*)scratch_dev);
-    hipLaunchKernelGGL(strip_finish_kernel<double>, dim3(1), dim3(64), 0, st, (double*)exponent_dev, (unsigned long long*)scratch_dev);
+    QAMD_LAUNCH(absmax_kernel<double>, dim3(grid), dim3(256), 0, st, (unsigned long long*)scratch_dev, (const double*)x, n, cplx);
+    QAMD_LAUNCH(strip_scale_kernel<double>, dim3(flat_grid(nr)), dim3(256), 0, st, (double*)x, nr, (const unsigned long long*)scratch_dev);
+    QAMD_LAUNCH(strip_finish_kernel<double>, dim3(1), dim3(64), 0, st, (double*)exponent_dev, (unsigned long long*)scratch_dev);
   }
+  QAMD_CHECK_LAUNCH();
+}
+
+extern "C" int qamd_absmax_log10_sum(const void* slots, int64_t nt, int32_t dtype, void* out_dev, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype < 0 || dtype > 3) return -2;
+  if (dtype == 0 || dtype == 2)
+    QAMD_LAUNCH(absmax_log10_sum_kernel<float>, dim3(1), dim3(64), 0, st, (const float*)slots, nt, (double*)out_dev);
+  else
+    QAMD_LAUNCH(absmax_log10_sum_kernel<double>, dim3(1), dim3(64), 0, st, (const double*)slots, nt, (double*)out_dev);
+  QAMD_CHECK_LAUNCH();
+}
+
+extern "C" int qamd_div_by_absmax(void* x, int64_t n, const void* slots, int32_t dtype, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype < 0 || dtype > 3) return -2;
+  if (n <= 0) return 0;
+  int64_t nr = dtype >= 2 ? 2 * n : n;
+  if (dtype == 0 || dtype == 2)
+    QAMD_LAUNCH(div_by_absmax_kernel<float>, dim3(flat_grid(nr)), dim3(256), 0, st, (float*)x, nr, (const float*)slots);
+  else
+    QAMD_LAUNCH(div_by_absmax_kernel<double>, dim3(flat_grid(nr)), dim3(256), 0, st, (double*)x, nr, (const double*)slots);
   QAMD_CHECK_LAUNCH();
 }

@@ -18,6 +18,11 @@
 #include <stdint.h>
 #include "gett_args.h"
 
+// hipGetLastError() also reports benign stale codes (hipErrorNotReady from an
+// event query by the allocator, ...): clear them before each launch so the
+// post-launch check only sees this launch.
+#define QAMD_LAUNCH(...) do { (void)hipGetLastError(); hipLaunchKernelGGL(__VA_ARGS__); } while (0)
+
 namespace qamd {
 
 template <typename T> struct Mfma;
@@ -38,6 +43,25 @@ template <> struct Mfma<double> {
 };
 
 template <typename T> struct Quad { T v[4]; };
+
+// max over the producer's absmax slots (0 / missing => 1)
+template <typename T>
+__device__ __forceinline__ T gett_read_scale(const T* slots) {
+  if (!slots) return T(1);
+  T m = T(0);
+  for (int i = 0; i < QAMD_SLOTS; ++i) {
+    T v = slots[i];
+    m = v > m ? v : m;
+  }
+  return m > T(0) ? m : T(1);
+}
+// non-negative IEEE values order like unsigned integers
+__device__ __forceinline__ void gett_atomic_max(float* p, float v) {
+  atomicMax(reinterpret_cast<unsigned int*>(p), __float_as_uint(v));
+}
+__device__ __forceinline__ void gett_atomic_max(double* p, double v) {
+  atomicMax(reinterpret_cast<unsigned long long*>(p), (unsigned long long)__double_as_longlong(v));
+}
 
 __device__ __forceinline__ int64_t decomp_off(uint32_t idx, int n, const uint32_t* dims,
                                               const int64_t* strides) {
@@ -197,7 +221,10 @@ constexpr int lds_pitch(int bx) { return bx + ((48 - bx % 32) % 32); }
 template <typename T, int WAVES_M, int WAVES_N, int WM, int WN, int BK, bool SWAP>
 __global__ __launch_bounds__(256) void gett_kernel(const GettArgs p, const T* __restrict__ A,
                                                     const T* __restrict__ B, T* __restrict__ C,
-                                                    const int64_t* __restrict__ ktab) {
+                                                    const int64_t* __restrict__ ktab,
+                                                    const T* __restrict__ scale_a,
+                                                    const T* __restrict__ scale_b,
+                                                    T* __restrict__ absmax_out) {
   static_assert(WAVES_M * WAVES_N == 4, "256-thread workgroup");
   constexpr int BM = WAVES_M * WM * 16;
   constexpr int BN = WAVES_N * WN * 16;
@@ -326,6 +353,10 @@ __global__ __launch_bounds__(256) void gett_kernel(const GettArgs p, const T* __
 
   // ---- epilogue: direct stores, lanes along C's contiguous bundle -------
   T* Cb = C + boffC;
+  // fused exponent stripping: scale by 1/(max|A| max|B|) read from the producers'
+  // slots, reduce max|C| into this tensor's slots (split-K defers both to the reduce)
+  const T alpha = T(1) / (gett_read_scale(scale_a) * gett_read_scale(scale_b));
+  T vmax = T(0);
 #pragma unroll
   for (int i = 0; i < WM; ++i) {
 #pragma unroll
@@ -341,22 +372,50 @@ __global__ __launch_bounds__(256) void gett_kernel(const GettArgs p, const T* __
           nl = wn * (WN * 16) + j * 16 + fr;
         }
         int64_t om = offCm[ml], on = offCn[nl];
-        if (om >= 0 && on >= 0) Cb[om + on] = acc[i][j][r];
+        T v = acc[i][j][r] * alpha;
+        if (om >= 0 && on >= 0) {
+          Cb[om + on] = v;
+          T av = v < T(0) ? -v : v;
+          vmax = av > vmax ? av : vmax;
+        }
       }
     }
+  }
+  if (absmax_out) {
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+      T o = __shfl_down(vmax, d, 64);
+      vmax = o > vmax ? o : vmax;
+    }
+    if (lane == 0) gett_atomic_max(absmax_out + ((blockIdx.x * 4 + wave) % QAMD_SLOTS), vmax);
   }
 }
 
 // ---- split-K slab reduction ------------------------------------------------
 template <typename T>
 __global__ void splitk_reduce_kernel(T* __restrict__ C, const T* __restrict__ ws, int64_t n,
-                                     int split_k) {
+                                     int split_k, const T* __restrict__ scale_a,
+                                     const T* __restrict__ scale_b, T* __restrict__ absmax_out) {
+  const T alpha = T(1) / (gett_read_scale(scale_a) * gett_read_scale(scale_b));
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  T vmax = T(0);
   for (; i < n; i += stride) {
     T s = ws[i];
     for (int k = 1; k < split_k; ++k) s += ws[(int64_t)k * n + i];
+    s *= alpha;
     C[i] = s;
+    T av = s < T(0) ? -s : s;
+    vmax = av > vmax ? av : vmax;
+  }
+  if (absmax_out) {
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+      T o = __shfl_down(vmax, d, 64);
+      vmax = o > vmax ? o : vmax;
+    }
+    if ((threadIdx.x & 63) == 0)
+      gett_atomic_max(absmax_out + (((blockIdx.x * blockDim.x + threadIdx.x) >> 6) % QAMD_SLOTS), vmax);
   }
 }
 
@@ -379,39 +438,42 @@ using namespace qamd;
 
 template <typename T, int WAVES_M, int WAVES_N, int WM, int WN, int BK>
 static int launch_cfg(const GettArgs& a, bool swap, const void* A, const void* B, void* C,
-                      const void* ktab, hipStream_t st) {
+                      const void* ktab, const void* sa, const void* sb, void* amax, hipStream_t st) {
   constexpr int BM = WAVES_M * WM * 16;
   constexpr int BN = WAVES_N * WN * 16;
   size_t lds = (size_t)(2 * BM + 2 * BN) * 8 + (size_t)BK * (lds_pitch(BM) + lds_pitch(BN)) * sizeof(T);
   uint64_t grid = (uint64_t)a.tiles_m * a.tiles_n * a.split_k * a.B;
   if (grid == 0 || grid > 0x7fffffffull) return -1;
   if (swap)
-    hipLaunchKernelGGL((gett_kernel<T, WAVES_M, WAVES_N, WM, WN, BK, true>), dim3((uint32_t)grid),
-                       dim3(256), lds, st, a, (const T*)A, (const T*)B, (T*)C, (const int64_t*)ktab);
+    QAMD_LAUNCH((gett_kernel<T, WAVES_M, WAVES_N, WM, WN, BK, true>), dim3((uint32_t)grid),
+                       dim3(256), lds, st, a, (const T*)A, (const T*)B, (T*)C, (const int64_t*)ktab,
+                       (const T*)sa, (const T*)sb, (T*)amax);
   else
-    hipLaunchKernelGGL((gett_kernel<T, WAVES_M, WAVES_N, WM, WN, BK, false>), dim3((uint32_t)grid),
-                       dim3(256), lds, st, a, (const T*)A, (const T*)B, (T*)C, (const int64_t*)ktab);
+    QAMD_LAUNCH((gett_kernel<T, WAVES_M, WAVES_N, WM, WN, BK, false>), dim3((uint32_t)grid),
+                       dim3(256), lds, st, a, (const T*)A, (const T*)B, (T*)C, (const int64_t*)ktab,
+                       (const T*)sa, (const T*)sb, (T*)amax);
   return hipGetLastError() == hipSuccess ? 0 : -4;
 }
 
 template <typename T>
 static int launch_T(int cfg, const GettArgs& a, bool swap, const void* A, const void* B, void* C,
-                    const void* ktab, hipStream_t st) {
+                    const void* ktab, const void* sa, const void* sb, void* amax, hipStream_t st) {
   switch (cfg) {
-    case 0: return launch_cfg<T, 2, 2, 4, 4, 16>(a, swap, A, B, C, ktab, st);  // 128 x 128
-    case 1: return launch_cfg<T, 2, 2, 2, 2, 16>(a, swap, A, B, C, ktab, st);  //  64 x  64
-    case 2: return launch_cfg<T, 4, 1, 4, 3, 16>(a, swap, A, B, C, ktab, st);  // 256 x  48
-    case 3: return launch_cfg<T, 4, 1, 4, 1, 16>(a, swap, A, B, C, ktab, st);  // 256 x  16
-    case 4: return launch_cfg<T, 4, 1, 2, 2, 16>(a, swap, A, B, C, ktab, st);  // 128 x  32
+    case 0: return launch_cfg<T, 2, 2, 4, 4, 16>(a, swap, A, B, C, ktab, sa, sb, amax, st);  // 128 x 128
+    case 1: return launch_cfg<T, 2, 2, 2, 2, 16>(a, swap, A, B, C, ktab, sa, sb, amax, st);  //  64 x  64
+    case 2: return launch_cfg<T, 4, 1, 4, 3, 16>(a, swap, A, B, C, ktab, sa, sb, amax, st);  // 256 x  48
+    case 3: return launch_cfg<T, 4, 1, 4, 1, 16>(a, swap, A, B, C, ktab, sa, sb, amax, st);  // 256 x  16
+    case 4: return launch_cfg<T, 4, 1, 2, 2, 16>(a, swap, A, B, C, ktab, sa, sb, amax, st);  // 128 x  32
     default: return -1;
   }
 }
 
 extern "C" int qamd_gett_launch(int dtype, int cfg, const GettArgs* a, int swap, const void* A,
-                                const void* B, void* C, const void* ktab, void* stream) {
+                                const void* B, void* C, const void* ktab, const void* sa, const void* sb,
+                                void* amax, void* stream) {
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == 0) return launch_T<float>(cfg, *a, swap != 0, A, B, C, ktab, st);
-  if (dtype == 1) return launch_T<double>(cfg, *a, swap != 0, A, B, C, ktab, st);
+  if (dtype == 0) return launch_T<float>(cfg, *a, swap != 0, A, B, C, ktab, sa, sb, amax, st);
+  if (dtype == 1) return launch_T<double>(cfg, *a, swap != 0, A, B, C, ktab, sa, sb, amax, st);
   return -2;
 }
 
@@ -422,17 +484,17 @@ extern "C" void qamd_gett_tile_dims(int cfg, int* bm, int* bn, int* bk) {
 }
 
 extern "C" int qamd_splitk_reduce_launch(int dtype, void* C, const void* ws, int64_t n, int split_k,
-                                         void* stream) {
+                                         const void* sa, const void* sb, void* amax, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   int64_t blocks = (n + 255) / 256;
   if (blocks > 4096) blocks = 4096;
   if (blocks < 1) blocks = 1;
   if (dtype == 0)
-    hipLaunchKernelGGL(splitk_reduce_kernel<float>, dim3((uint32_t)blocks), dim3(256), 0, st, (float*)C,
-                       (const float*)ws, n, split_k);
+    QAMD_LAUNCH(splitk_reduce_kernel<float>, dim3((uint32_t)blocks), dim3(256), 0, st, (float*)C,
+                       (const float*)ws, n, split_k, (const float*)sa, (const float*)sb, (float*)amax);
   else if (dtype == 1)
-    hipLaunchKernelGGL(splitk_reduce_kernel<double>, dim3((uint32_t)blocks), dim3(256), 0, st,
-                       (double*)C, (const double*)ws, n, split_k);
+    QAMD_LAUNCH(splitk_reduce_kernel<double>, dim3((uint32_t)blocks), dim3(256), 0, st,
+                       (double*)C, (const double*)ws, n, split_k, (const double*)sa, (const double*)sb, (double*)amax);
   else
     return -2;
   return hipGetLastError() == hipSuccess ? 0 : -4;
@@ -441,6 +503,6 @@ extern "C" int qamd_splitk_reduce_launch(int dtype, void* C, const void* ws, int
 extern "C" int qamd_build_ktab_launch(void* ktab, const KtabArgs* a, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   uint32_t blocks = (a->Kpad + 255) / 256;
-  hipLaunchKernelGGL(build_ktab_kernel, dim3(blocks), dim3(256), 0, st, (int64_t*)ktab, *a);
+  QAMD_LAUNCH(build_ktab_kernel, dim3(blocks), dim3(256), 0, st, (int64_t*)ktab, *a);
   return hipGetLastError() == hipSuccess ? 0 : -4;
 }

@@ -3,6 +3,7 @@
 #include <stdint.h>
 
 #define QAMD_G 8
+#define QAMD_SLOTS 64  // absmax slots per tensor (sharded atomicMax targets)
 
 struct GettArgs {
   int32_t nb, nm, nn, nk;
@@ -18,6 +19,20 @@ struct GettArgs {
   int64_t slab_stride;  // elements between split-K slabs
 };
 
+// "big tensor x small tensor" streaming kernel (stream.hip)
+struct StreamArgs {
+  int32_t nm, nn;
+  uint32_t dim_m[QAMD_G], dim_n[QAMD_G];
+  int64_t sa_m[QAMD_G], sc_m[QAMD_G];
+  int64_t sb_n[QAMD_G], sc_n[QAMD_G];
+  uint32_t M, N, K;
+  uint32_t KS;       // k-steps of 4
+  uint32_t Kpad;     // 4 * KS
+  uint32_t KpadTab;  // stride between the A and B halves of the k-offset table
+  uint32_t NT;       // n-tiles of 16
+  uint32_t chunks, chunks_per_wave, grid;
+};
+
 struct KtabArgs {
   int32_t nk;
   uint32_t K, Kpad;
@@ -29,9 +44,14 @@ struct KtabArgs {
 extern "C" {
 #endif
 int qamd_gett_launch(int dtype, int cfg, const GettArgs* a, int swap, const void* A, const void* B,
-                     void* C, const void* ktab, void* stream);
+                     void* C, const void* ktab, const void* scale_a, const void* scale_b, void* absmax_out,
+                     void* stream);
+int qamd_stream_launch(int dtype, int V, const StreamArgs* a, const void* A, const void* B, void* C,
+                       const void* ktab, const void* scale_a, const void* scale_b, void* absmax_out,
+                       void* stream);
 void qamd_gett_tile_dims(int cfg, int* bm, int* bn, int* bk);
-int qamd_splitk_reduce_launch(int dtype, void* C, const void* ws, int64_t n, int split_k, void* stream);
+int qamd_splitk_reduce_launch(int dtype, void* C, const void* ws, int64_t n, int split_k,
+                              const void* scale_a, const void* scale_b, void* absmax_out, void* stream);
 int qamd_build_ktab_launch(void* ktab, const KtabArgs* a, void* stream);
 #ifdef __cplusplus
 }

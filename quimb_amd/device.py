@@ -50,6 +50,7 @@ def fill_plan_struct(spec: GettSpec, code: int):
         p.dim_k[i], p.sa_k[i], p.sb_k[i] = d, sa, sb
     p.tile_cfg = -1
     p.split_k = 0
+    p.kernel = 0
     return p
 
 
@@ -91,6 +92,8 @@ class HipDevice:
         self.profile = None
         self.force_tile_cfg = int(os.environ.get("QAMD_TILE_CFG", "-1"))
         self.force_split_k = int(os.environ.get("QAMD_SPLIT_K", "0"))
+        #: 0 = auto (streaming kernel where eligible), -1 = always the tiled GETT kernel
+        self.force_kernel = int(os.environ.get("QAMD_KERNEL", "0"))
 
     # ---- memory ---------------------------------------------------------
     def empty(self, n, dtype):
@@ -124,16 +127,19 @@ class HipDevice:
         return self._ws.data_ptr(), self._ws.numel()
 
     # ---- pairwise contraction ---------------------------------------------
-    def compile_pair(self, spec, dtype, align_a=16, align_b=16):
+    def compile_pair(self, spec, dtype, align_a=16, align_b=16, align_c=16):
         code = dtype_code(dtype)
-        key = (spec, code, align_a, align_b, self.force_tile_cfg, self.force_split_k)
+        key = (spec, code, align_a, align_b, self.force_tile_cfg, self.force_split_k, align_c, self.force_kernel)
         cp = self._pairs.get(key)
         if cp is not None:
             return cp
         p = fill_plan_struct(spec, code)
         p.tile_cfg = self.force_tile_cfg
         p.split_k = self.force_split_k
-        _lib.check(self.lib.qamd_pair_plan_finalize(C.byref(p), align_a, align_b), "qamd_pair_plan_finalize")
+        p.kernel = self.force_kernel
+        _lib.check(
+            self.lib.qamd_pair_plan_finalize(C.byref(p), align_a, align_b, align_c), "qamd_pair_plan_finalize"
+        )
         klen = self.lib.qamd_pair_ktab_len(C.byref(p))
         ktab = self.torch.empty(int(klen), dtype=self.torch.int64, device=self.tdev)
         _lib.check(
@@ -146,24 +152,34 @@ class HipDevice:
         self._pairs[key] = cp
         return cp
 
-    def contract_pair(self, spec, dtype, a, b, c):
-        pa, pb = a.data_ptr(), b.data_ptr()
-        cp = self.compile_pair(spec, dtype, min(pa & -pa, 16), min(pb & -pb, 16))
+    def contract_pair(self, spec, dtype, a, b, c, ep=None):
+        """C = A . B.  ``ep`` = (slots_a, slots_b, slots_out) enables the fused
+        exponent-stripping epilogue (entries may be None)."""
+        pa, pb, pc = a.data_ptr(), b.data_ptr(), c.data_ptr()
+        cp = self.compile_pair(spec, dtype, min(pa & -pa, 16), min(pb & -pb, 16), min(pc & -pc, 16))
         ws, wsn = self._workspace(cp.ws_bytes)
+        epp = None
+        if ep is not None:
+            e = _lib.Epilogue()
+            e.scale_a = ep[0].data_ptr() if ep[0] is not None else None
+            e.scale_b = ep[1].data_ptr() if ep[1] is not None else None
+            e.absmax_out = ep[2].data_ptr() if ep[2] is not None else None
+            epp = C.byref(e)
         prof = self.profile
         if prof is not None:
             e0 = self.torch.cuda.Event(enable_timing=True)
             e1 = self.torch.cuda.Event(enable_timing=True)
             e0.record()
         _lib.check(
-            self.lib.qamd_contract_pair(
-                C.byref(cp.struct), pa, pb, c.data_ptr(), cp.ktab.data_ptr(), ws, wsn, self.stream()
+            self.lib.qamd_contract_pair_ex(
+                C.byref(cp.struct), pa, pb, pc, cp.ktab.data_ptr(), ws, wsn, epp, self.stream()
             ),
-            "qamd_contract_pair",
+            "qamd_contract_pair_ex",
         )
         if prof is not None:
             e1.record()
-            prof.append((spec, np.dtype(dtype), cp.struct.tile_cfg, cp.struct.split_k, e0, e1))
+            cfg = -1 if cp.struct.kernel == 1 else cp.struct.tile_cfg
+            prof.append((spec, np.dtype(dtype), cfg, cp.struct.split_k, e0, e1))
 
     # ---- layout / elementwise -----------------------------------------------
     def permute(self, dst, src, shape, strides, offset, dtype):
@@ -228,6 +244,30 @@ class HipDevice:
                 x.data_ptr(), int(n), dtype_code(dtype), self._scratch.data_ptr(), exponent.data_ptr(), self.stream()
             ),
             "qamd_strip_exponent",
+        )
+
+    # fused form: per-tensor absmax slots, consumed as scales by the next contraction
+    def new_slots(self, n_tensors, dtype):
+        """(n_tensors, 64) zeroed slots of the real dtype matching ``dtype``."""
+        rdt = self.torch.float32 if np.dtype(dtype) in (np.dtype("float32"), np.dtype("complex64")) else self.torch.float64
+        return self.torch.zeros((int(n_tensors), _lib.ABSMAX_SLOTS), dtype=rdt, device=self.tdev)
+
+    def slots_row(self, slots, i):
+        return slots[i]
+
+    def slots_log10_sum(self, slots, dtype, exponent):
+        """exponent[0] += sum_t log10(max(slots[t]))  (device side, no sync)."""
+        tmp = self.torch.empty(1, dtype=self.torch.float64, device=self.tdev)
+        _lib.check(
+            self.lib.qamd_absmax_log10_sum(slots.data_ptr(), slots.shape[0], dtype_code(dtype), tmp.data_ptr(), self.stream()),
+            "qamd_absmax_log10_sum",
+        )
+        exponent += tmp
+
+    def div_by_absmax(self, x, n, slots_row, dtype):
+        _lib.check(
+            self.lib.qamd_div_by_absmax(x.data_ptr(), int(n), slots_row.data_ptr(), dtype_code(dtype), self.stream()),
+            "qamd_div_by_absmax",
         )
 
     def read_exponent(self, exponent):

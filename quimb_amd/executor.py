@@ -133,9 +133,19 @@ class TreeExecutor:
 
     def _run_core(self, inputs, exponent, cache, only_independent=False):
         """Evaluate the tree for one slice.  ``cache`` maps ssa id -> Array for
-        slice-independent intermediates (filled on first use)."""
+        slice-independent intermediates (filled on first use).
+
+        With ``exponent`` (strip_exponent) every GETT step runs the fused epilogue:
+        it scales by 1/(max|a| max|b|) read from the operands' absmax slots and
+        reduces max|out| into its own slots; nothing is re-read to normalise.  The
+        log10 of every max is summed on the device at the end."""
         dev = inputs[0]._dev
         live = dict(enumerate(inputs))
+        slots = None
+        if exponent is not None:
+            nid = len(inputs) + len(self.plan)
+            slots = dev.new_slots(nid, self.dtype)
+            has_scale = set()
         uses = {}
         for entry in self.plan:
             ids = (entry[1],) if entry[0] == "single" else (entry[1], entry[2])
@@ -150,6 +160,9 @@ class TreeExecutor:
                 elif only_independent and not independent:
                     continue
                 else:
+                    if exponent is not None and a in has_scale:
+                        # apply the operand's deferred division before the single-term op
+                        dev.div_by_absmax(live[a]._buf, live[a].size, dev.slots_row(slots, a), live[a].dtype)
                     live[res] = _einsum_single(live[a], src, out)
                     if independent and cache is not None:
                         cache[res] = live[res]
@@ -162,9 +175,24 @@ class TreeExecutor:
                 elif only_independent and not independent:
                     continue
                 else:
-                    x = run_pair_step(step, live[a], live[b])
-                    if exponent is not None and x.size:
-                        dev.strip_exponent(x._buf, x.size, x.dtype, exponent)
+                    if exponent is not None and step.kind == "gett" and self.dtype.kind != "c":
+                        ep = (
+                            dev.slots_row(slots, a) if a in has_scale else None,
+                            dev.slots_row(slots, b) if b in has_scale else None,
+                            dev.slots_row(slots, res),
+                        )
+                        x = run_pair_step(step, live[a], live[b], ep=ep)
+                        has_scale.add(res)
+                    else:
+                        xa, xb = live[a], live[b]
+                        if exponent is not None:
+                            # operands with a pending (deferred) division: apply it now
+                            for s_, x_ in ((a, xa), (b, xb)):
+                                if s_ in has_scale:
+                                    dev.div_by_absmax(x_._buf, x_.size, dev.slots_row(slots, s_), x_.dtype)
+                        x = run_pair_step(step, xa, xb)
+                        if exponent is not None and x.size:
+                            dev.strip_exponent(x._buf, x.size, x.dtype, exponent)
                     live[res] = x
                     if independent and cache is not None:
                         cache[res] = x
@@ -173,7 +201,12 @@ class TreeExecutor:
                 uses[s] -= 1
                 if uses[s] == 0:
                     live.pop(s, None)
-        return live.get(self.root)
+        out = live.get(self.root)
+        if exponent is not None and out is not None:
+            if self.root in has_scale:
+                dev.div_by_absmax(out._buf, out.size, dev.slots_row(slots, self.root), out.dtype)
+            dev.slots_log10_sum(slots, self.dtype, exponent)
+        return out
 
     def __call__(self, arrays, strip_exponent=False, slices=None, hoist=True):
         """Contract.  ``slices``: iterable of slice numbers to evaluate (default

@@ -51,8 +51,10 @@ def _apply_pre(x, ops):
     return x
 
 
-def run_pair_step(step, a, b, out=None):
-    """Execute a planned pairwise step on device arrays of a common dtype."""
+def run_pair_step(step, a, b, out=None, ep=None):
+    """Execute a planned pairwise step on device arrays of a common dtype.
+    ``ep`` = (slots_a, slots_b, slots_out) in CALLER operand order enables the
+    fused exponent-stripping epilogue of the GETT kernels."""
     a = _apply_pre(a, step.pre[0])
     b = _apply_pre(b, step.pre[1])
     dev = a._dev
@@ -65,10 +67,12 @@ def run_pair_step(step, a, b, out=None):
         dev.binary(out._buf, a._buf, s.sa, b._buf, s.sb, s.shape, "mul", a.dtype)
         return out
     ka, kb = (b, a) if step.swapped else (a, b)
+    if ep is not None and step.swapped:
+        ep = (ep[1], ep[0], ep[2])
     if a.dtype.kind == "c":
         _complex_gett(dev, step.spec, ka, kb, out)
     else:
-        dev.contract_pair(step.spec, a.dtype, ka._buf, kb._buf, out._buf)
+        dev.contract_pair(step.spec, a.dtype, ka._buf, kb._buf, out._buf, ep)
     return out
 
 

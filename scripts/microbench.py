@@ -35,16 +35,22 @@ def bench_pair(name, ai, ash, bi, bsh, oi, fixed=True, dtype="float32", cfgs=(-1
     flops = 2 * g.mults
     nbytes = isz * g.B * (g.M * g.K + g.K * g.N + g.M * g.N)
     for cfg in cfgs:
+        # cfg == "T<n>": force the tiled GETT kernel with tile config n
+        if isinstance(cfg, str):
+            dev.force_kernel, cfg = -1, int(cfg[1:])
+        else:
+            dev.force_kernel = 0
         dev.force_tile_cfg = cfg
         try:
             t = timeit(lambda: run_pair_step(step, a, b, out))
         except Exception as e:
             print(f"{name:34s} cfg={cfg} FAILED {e}"); continue
-        cp = [v for k, v in dev._pairs.items() if k[0] == g and k[4] == cfg][-1]
-        print(f"{name:34s} cfg={cp.struct.tile_cfg} sk={cp.struct.split_k} va={cp.struct.vec_a} vb={cp.struct.vec_b} "
+        cp = [v for k, v in dev._pairs.items() if k[0] == g and k[4] == cfg and k[7] == dev.force_kernel][-1]
+        print(f"{name:34s} kern={cp.struct.kernel} vc={cp.struct.vec_c} cfg={cp.struct.tile_cfg} sk={cp.struct.split_k} va={cp.struct.vec_a} vb={cp.struct.vec_b} "
               f"akc={cp.struct.a_kcontig} cn={cp.struct.c_ncontig} BMNK=({g.B},{g.M},{g.N},{g.K}) "
               f"{t*1e3:9.3f} ms {flops/t/1e12:8.2f} TF {nbytes/t/1e9:8.1f} GB/s", flush=True)
     dev.force_tile_cfg = -1
+    dev.force_kernel = 0
 
 quick = "--quick" in sys.argv
 print("== GETT fp32: square GEMMs (compute-bound)")
@@ -56,12 +62,14 @@ print("== GETT fp64")
 bench_pair("dgemm 4096^3 NN", "mk", (4096, 4096), "kn", (4096, 4096), "mn", dtype="float64", cfgs=(0, 1))
 print("== PEPS sweep steps, D=6 (HBM-bound): A[L,h,v,R] x S[h,x,v,y] -> C[L,y?,x?,R]")
 for (L, R) in [(6**4, 6**5), (6**8, 6), (6**9, 1), (1, 6**9), (6**2, 6**7)]:
-    bench_pair(f"sweep L=6^{round(np.log(L)/np.log(6))} R=6^{round(np.log(R)/np.log(6))}", "lhvr", (L, 6, 6, R), "hxvy", (6, 6, 6, 6), "lxyr", fixed=False, cfgs=(2, 1, 0))
+    bench_pair(f"sweep L=6^{round(np.log(L)/np.log(6))} R=6^{round(np.log(R)/np.log(6))}", "lhvr", (L, 6, 6, R), "hxvy", (6, 6, 6, 6), "lxyr", fixed=False, cfgs=(-1, "T1"))
 print("== merged 2-site step K=N=216")
 bench_pair("sweep2 L=6^4 R=6^4", "lkr", (6**4, 216, 6**4), "kn", (216, 216), "lnr", fixed=True, cfgs=(0, 1))
+bench_pair("K=216 N=36 L=6^4 R=6^4", "lkr", (6**4, 216, 6**4), "kn", (216, 36), "lnr", fixed=True, cfgs=(-1, "T1"))
 print("== gate on state: psi[2^a,2,2^b] x G[2,2]")
-bench_pair("1q gate on 2^28 state", "lkr", (2**14, 2, 2**13), "kn", (2, 2), "lnr", cfgs=(3,))
-bench_pair("2q gate on 2^28 state", "lkr", (2**13, 4, 2**13), "kn", (4, 4), "lnr", cfgs=(3,))
+bench_pair("1q gate on 2^28 state", "lkr", (2**14, 2, 2**13), "kn", (2, 2), "lnr", cfgs=(-1, "T3"))
+bench_pair("2q gate on 2^28 state", "lkr", (2**13, 4, 2**13), "kn", (4, 4), "lnr", cfgs=(-1, "T3"))
+bench_pair("f64 sweep L=6^4 R=6^4", "lhvr", (6**4, 6, 6, 6**4), "hxvy", (6, 6, 6, 6), "lxyr", fixed=False, dtype="float64", cfgs=(-1, "T1"))
 print("== permute fp32")
 def bench_perm(name, shape, perm):
     x = rnd(shape)

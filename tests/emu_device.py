@@ -47,7 +47,7 @@ class EmuDevice:
         pass
 
     # kernels
-    def contract_pair(self, spec, dtype, a, b, c):
+    def contract_pair(self, spec, dtype, a, b, c, ep=None):
         self.calls["contract_pair"] += 1
         ob_a, ob_b, ob_c = _offsets(spec.b, 1), _offsets(spec.b, 2), _offsets(spec.b, 3)
         om_a, om_c = _offsets(spec.m, 1), _offsets(spec.m, 3)
@@ -56,6 +56,12 @@ class EmuDevice:
         A = a[ob_a[:, None, None] + om_a[None, :, None] + ok_a[None, None, :]]
         B = b[ob_b[:, None, None] + ok_b[None, :, None] + on_b[None, None, :]]
         C = np.matmul(A, B)
+        if ep is not None:
+            sa = float(ep[0].max()) if ep[0] is not None else 0.0
+            sb = float(ep[1].max()) if ep[1] is not None else 0.0
+            C = C * np.asarray(1.0 / ((sa if sa > 0 else 1.0) * (sb if sb > 0 else 1.0)), dtype=C.real.dtype)
+            if ep[2] is not None and C.size:
+                ep[2][self.calls["contract_pair"] % ep[2].size] = max(ep[2][self.calls["contract_pair"] % ep[2].size], np.max(np.abs(C)))
         idx = ob_c[:, None, None] + om_c[None, :, None] + on_c[None, None, :]
         assert len(np.unique(idx)) == idx.size, "output offsets collide"
         c[idx] = C
@@ -109,6 +115,22 @@ class EmuDevice:
         if m > 0:
             x[:n] = x[:n] / np.asarray(m, dtype=x.real.dtype)
             exponent[0] += math.log10(m)
+
+    def new_slots(self, n_tensors, dtype):
+        rdt = np.float32 if np.dtype(dtype) in (np.dtype("float32"), np.dtype("complex64")) else np.float64
+        return np.zeros((int(n_tensors), 64), dtype=rdt)
+
+    def slots_row(self, slots, i):
+        return slots[i]
+
+    def slots_log10_sum(self, slots, dtype, exponent):
+        m = slots.max(axis=1).astype(np.float64)
+        exponent[0] += float(np.sum(np.log10(m[m > 0])))
+
+    def div_by_absmax(self, x, n, slots_row, dtype):
+        m = slots_row.max()
+        if m > 0:
+            x[:n] = x[:n] / m
 
     def read_exponent(self, exponent):
         return float(exponent[0])

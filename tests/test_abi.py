@@ -39,15 +39,21 @@ def test_load_and_plan_finalize():
     assert b"gfx950" in lib.qamd_build_info()
     step = plan_pair(("l", "h", "v", "r"), (36, 6, 6, 216), ("h", "x", "v", "y"), (6, 6, 6, 6), ("l", "x", "y", "r"), False)
     p = fill_plan_struct(step.spec, _lib.QAMD_F32)
-    assert lib.qamd_pair_plan_finalize(C.byref(p), 16, 16) == 0
+    assert lib.qamd_pair_plan_finalize(C.byref(p), 16, 16, 16) == 0
     assert p.tile_cfg == 2 and p.vec_a == 4 and p.a_kcontig == 0 and p.c_ncontig == 0
+    # big tensor x small tensor with the stride-1 index in M on both sides -> streaming kernel
+    assert p.kernel == 1 and p.vec_c == 4
     assert lib.qamd_pair_ktab_len(C.byref(p)) == 2 * 48
     assert lib.qamd_pair_workspace_bytes(C.byref(p)) == 0
+    # caller can force the tiled kernel
+    p.kernel = -1
+    assert lib.qamd_pair_plan_finalize(C.byref(p), 16, 16, 16) == 0 and p.kernel == 0
     # malformed plan is rejected, not crashed on
     p.nm = 99
-    assert lib.qamd_pair_plan_finalize(C.byref(p), 16, 16) == -1
+    assert lib.qamd_pair_plan_finalize(C.byref(p), 16, 16, 16) == -1
 
 
 def test_struct_layout_matches_header():
     # int32 x8 + 13 int64[8] arrays + int32 x8
     assert C.sizeof(_lib.PairPlanStruct) == 8 * 4 + 13 * 8 * 8 + 8 * 4
+    assert C.sizeof(_lib.Epilogue) == 24
