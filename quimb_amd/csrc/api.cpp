@@ -62,6 +62,16 @@ static const int kTileBN[5] = {128, 64, 48, 16, 32};
 static const int kBK = 16;
 static const int kNumCU = 256;
 
+// size of the trailing block of N groups that is contiguous (stride-1 run) in C
+static int64_t n_inner_block(const qamd_pair_plan* p) {
+  int64_t d = 1;
+  for (int g = p->nn - 1; g >= 0; --g) {
+    if (p->sc_n[g] != d) break;
+    d *= p->dim_n[g];
+  }
+  return d;
+}
+
 static int stream_lds_bytes(int64_t K, int64_t N, int es) {
   int64_t kpad = ((K + 3) / 4) * 4;
   int64_t npad = ((N + 15) / 16) * 16;
@@ -116,25 +126,37 @@ extern "C" int qamd_pair_plan_finalize(qamd_pair_plan* p, int64_t align_a, int64
   }
 
   // ---- streaming kernel eligibility (big tensor x small tensor) ---------------
-  // A and C both have their stride-1 index in the M bundle (same fused group), the
-  // whole small operand fits in LDS, no batch bundle.
+  // kernel 1 (X): A and C both have their stride-1 index in the same innermost M group.
+  // kernel 2 (Z): A as above, C = [.., m_in, n_in] with n_in stride-1 directly inside
+  //               the innermost M group (death-ordered executor layouts).
+  // Both: the whole small operand fits in LDS, no batch bundle.
   {
-    bool want = (p->kernel != 0) || true;
-    bool ok = want && p->nb == 0 && p->nm >= 1 && p->sa_m[p->nm - 1] == 1 && p->sc_m[p->nm - 1] == 1 &&
-              d.N <= 64 && d.M >= 4096 && d.K <= 4096 && stream_lds_bytes(d.K, d.N, es) <= 64 * 1024;
-    int vc = 1;
-    if (ok) {
+    const bool base_ok = p->nb == 0 && p->nm >= 1 && p->sa_m[p->nm - 1] == 1 && !p->a_kcontig &&
+                         d.N <= 64 && d.M >= 4096 && d.K <= 4096;
+    const int ev = 16 / es;  // elements per 16-byte vector
+    int kern = 0, vc = 1;
+    const int64_t d_in = n_inner_block(p);
+    if (base_ok && p->nn >= 1 && d_in > 1 && p->sc_m[p->nm - 1] == d_in && p->vec_a >= ev &&
+        align_c % 16 == 0 && p->dim_m[p->nm - 1] % (16 * ev) == 0) {
+      bool ok = true;
+      for (int i = 0; i + 1 < p->nm; ++i) ok = ok && (p->sc_m[i] % ev == 0);
+      for (int i = 0; i < p->nn; ++i) ok = ok && (p->sc_n[i] < d_in || p->sc_n[i] % ev == 0);
+      int64_t npad = ((d.N + 15) / 16) * 16;
+      ok = ok && (stream_lds_bytes(d.K, d.N, es) + 4 * npad * 16 * ev * es <= 80 * 1024);
+      if (ok) { kern = 2; vc = ev; }
+    }
+    if (!kern && base_ok && p->sc_m[p->nm - 1] == 1 && stream_lds_bytes(d.K, d.N, es) <= 64 * 1024) {
       std::vector<int64_t> others;
       for (int i = 0; i + 1 < p->nm; ++i) others.push_back(p->sc_m[i]);
       for (int i = 0; i < p->nn; ++i) others.push_back(p->sc_n[i]);
       vc = pick_vec(p->dim_m[p->nm - 1], align_c, es, others);
-      int va = p->a_kcontig ? 1 : p->vec_a;
-      vc = std::min(vc, va);
-      if (es == 8 && vc > 2) vc = 2;
+      vc = std::min(vc, (int)p->vec_a);
+      if (vc > ev) vc = ev;
+      kern = 1;
     }
     p->vec_c = vc;
-    if (p->kernel == -1) p->kernel = 0;        // caller forces the tiled kernel
-    else p->kernel = ok ? 1 : 0;
+    if (p->kernel == -1) p->kernel = 0;  // caller forces the tiled kernel
+    else p->kernel = kern;
   }
 
   // ---- tile shape -----------------------------------------------------------
@@ -224,8 +246,13 @@ static int launch_stream(const qamd_pair_plan* p, const PairDims& d, const void*
   s.KpadTab = (uint32_t)(((d.K + 15) / 16) * 16);
   s.NT = (uint32_t)((d.N + 15) / 16);
   const int V = p->vec_c;
+  s.zmode = (p->kernel == 2) ? 1 : 0;
+  s.d_in = s.zmode ? (uint32_t)n_inner_block(p) : 1;
+  s.sc_m_in = p->sc_m[p->nm - 1];
+  s.aligned = (p->dim_m[p->nm - 1] % (16 * V) == 0) ? 1 : 0;
+  s.inner_chunks = s.aligned ? (uint32_t)(p->dim_m[p->nm - 1] / (16 * V)) : 1;
   s.chunks = (uint32_t)((d.M + 16 * V - 1) / (16 * V));
-  const uint32_t target_waves = 256 * 4 * 3;
+  const uint32_t target_waves = 256 * 4 * (s.zmode ? 2 : 3);
   s.chunks_per_wave = (s.chunks + target_waves - 1) / target_waves;
   if (s.chunks_per_wave < 1) s.chunks_per_wave = 1;
   uint32_t waves = (s.chunks + s.chunks_per_wave - 1) / s.chunks_per_wave;
@@ -243,7 +270,7 @@ extern "C" int qamd_contract_pair_ex(const qamd_pair_plan* p, const void* A, con
   if (p->dtype != QAMD_F32 && p->dtype != QAMD_F64) return QAMD_EUNSUPPORTED;
   if (p->tile_cfg < 0 || p->tile_cfg > 4 || p->split_k < 1) return QAMD_EINVAL;
   if (!A || !B || !C || !ktab) return QAMD_EINVAL;
-  if (p->kernel == 1) return launch_stream(p, d, A, B, C, ktab, ep, stream);
+  if (p->kernel == 1 || p->kernel == 2) return launch_stream(p, d, A, B, C, ktab, ep, stream);
   const int bm = kTileBM[p->tile_cfg], bn = kTileBN[p->tile_cfg];
   const void* sa = ep ? ep->scale_a : nullptr;
   const void* sb = ep ? ep->scale_b : nullptr;

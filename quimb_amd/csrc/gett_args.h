@@ -31,6 +31,11 @@ struct StreamArgs {
   uint32_t KpadTab;  // stride between the A and B halves of the k-offset table
   uint32_t NT;       // n-tiles of 16
   uint32_t chunks, chunks_per_wave, grid;
+  uint32_t aligned;       // innermost M group is a whole number of chunks (wave-uniform offsets)
+  uint32_t inner_chunks;  // chunks per innermost M group (aligned mode)
+  uint32_t zmode;         // 1: C[.., m, n_in] with n_in stride-1 -> LDS-transposed stores
+  uint32_t d_in;          // zmode: size of the innermost N group
+  int64_t sc_m_in;        // C stride of the innermost M group
 };
 
 struct KtabArgs {

@@ -10,10 +10,17 @@
 // straight from HBM into MFMA B-operand registers (no LDS hop): the stride-1
 // index of A is an M index, so lane (j = l&15, kq = l>>4) loads V consecutive m
 // for k = 4s+kq -- exactly the v_mfma_*_16x16x4 B-fragment layout, V tiles at a
-// time, 16*V*sizeof(T) contiguous bytes per 16 lanes.  D = W^T . A^T puts m along
-// lanes again, so the V accumulator tiles store V-wide vectors back to C with the
-// same coalescing.  Loads run RING k-steps ahead of the MFMAs (across chunk
-// boundaries), waves are independent (no barrier in the stream loop).
+// time, 16*V*sizeof(T) contiguous bytes per 16 lanes.  Loads run RING k-steps
+// ahead of the MFMAs (across chunk boundaries); waves are independent (no
+// workgroup barrier in the stream loop).
+//
+// Two store paths:
+//  * X: C's stride-1 index is the same M group -> D = W^T . A^T has m along lanes,
+//    the V accumulator tiles store V-wide vectors straight from registers.
+//  * Z: C's stride-1 index is an N group of size d_in directly inside the M run
+//    (C[.., m, n_in]) -- what the executor's death-ordered layouts produce.  The
+//    wave transposes its 16V x N tile through a private LDS buffer and writes
+//    n_out contiguous runs of 16V*d_in elements with 16-byte stores.
 //
 // Exponent stripping is fused: alpha = 1/(max|A| * max|W|) comes from device
 // slots written by the producers' epilogues, and this kernel's own max|C| is
@@ -36,7 +43,6 @@ template <> struct SMfma<float> {
   }
   static __device__ __forceinline__ int row(int lane, int r) { return (lane >> 4) * 4 + r; }
   static __device__ __forceinline__ bits_t bits(float v) { return __float_as_uint(v); }
-  static __device__ __forceinline__ float from_bits(bits_t b) { return __uint_as_float(b); }
 };
 template <> struct SMfma<double> {
   typedef __attribute__((ext_vector_type(4))) double acc_t;
@@ -46,7 +52,6 @@ template <> struct SMfma<double> {
   }
   static __device__ __forceinline__ int row(int lane, int r) { return (lane >> 4) + 4 * r; }
   static __device__ __forceinline__ bits_t bits(double v) { return (bits_t)__double_as_longlong(v); }
-  static __device__ __forceinline__ double from_bits(bits_t b) { return __longlong_as_double((long long)b); }
 };
 
 template <typename T, int V> struct SVec {
@@ -89,7 +94,7 @@ __device__ __forceinline__ void sdecomp2(uint32_t idx, int n, const uint32_t* di
   }
 }
 
-// reduce the 64 producer slots to one scale; slots hold max|x| (0 => treat as 1)
+// reduce the producer's slots to one scale; slots hold max|x| (0 => treat as 1)
 template <typename T>
 __device__ __forceinline__ T read_scale(const T* slots) {
   if (!slots) return T(1);
@@ -101,7 +106,7 @@ __device__ __forceinline__ T read_scale(const T* slots) {
   return m > T(0) ? m : T(1);
 }
 
-template <typename T, int V, int NT, int RING>
+template <typename T, int V, int NT, int RING, bool ZMODE>
 __global__ __launch_bounds__(256) void stream_kernel(const StreamArgs p, const T* __restrict__ A,
                                                       const T* __restrict__ B, T* __restrict__ C,
                                                       const int64_t* __restrict__ ktab,
@@ -111,11 +116,14 @@ __global__ __launch_bounds__(256) void stream_kernel(const StreamArgs p, const T
   typedef typename SMfma<T>::acc_t acc_t;
   constexpr int NPAD = NT * 16;
   constexpr int LDW = NPAD + ((48 - NPAD % 32) % 32);
+  constexpr int CH = 16 * V;             // m per chunk
+  constexpr int EV = 16 / sizeof(T);     // elements per 16-byte vector
   extern __shared__ __attribute__((aligned(16))) char smem[];
   int64_t* offCn = reinterpret_cast<int64_t*>(smem);        // [NPAD]
   int64_t* offBn = offCn + NPAD;                             // [NPAD]
   int64_t* koffA = offBn + NPAD;                             // [Kpad]
   T* Wl = reinterpret_cast<T*>(koffA + p.Kpad);              // [Kpad][LDW]
+  T* Zl = Wl + (size_t)p.Kpad * LDW;                         // ZMODE: 4 x [NPAD*CH] (16B aligned by host)
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -153,6 +161,8 @@ __global__ __launch_bounds__(256) void stream_kernel(const StreamArgs p, const T
   if (c_begin >= c_end) return;
   const uint32_t KS = p.KS;
   const uint32_t g_total = (c_end - c_begin) * KS;
+  const bool aligned = p.aligned != 0;
+  const uint32_t inner_chunks = p.inner_chunks;  // chunks per innermost M group (aligned mode)
 
   acc_t acc[V][NT];
 #pragma unroll
@@ -160,14 +170,18 @@ __global__ __launch_bounds__(256) void stream_kernel(const StreamArgs p, const T
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) acc[t][nt] = acc_t{0, 0, 0, 0};
 
-  // load cursor (runs RING steps ahead of the compute cursor)
-  uint32_t ld_chunk = c_begin, ld_s = 0;
-  int64_t offA_ld, offC_dummy;
-  {
-    uint32_t m = ld_chunk * (16 * V) + V * j;
+  // ---- load cursor (runs RING steps ahead of the compute cursor) ---------------
+  uint32_t ld_chunk = c_begin, ld_s = 0, ld_in = aligned ? c_begin % inner_chunks : 0;
+  int64_t offA_ld = -1, dummy;
+  auto seek_load = [&]() {
+    uint32_t m = ld_chunk * CH + (aligned ? 0 : V * j);
     offA_ld = -1;
-    if (m < p.M) sdecomp2(m, p.nm, p.dim_m, p.sa_m, p.sc_m, offA_ld, offC_dummy);
-  }
+    if (ld_chunk < c_end && m < p.M) {
+      sdecomp2(m, p.nm, p.dim_m, p.sa_m, p.sc_m, offA_ld, dummy);
+      if (aligned) offA_ld += V * j;
+    }
+  };
+  seek_load();
   T areg[RING][V];
 
   auto issue_load = [&](T (&dst)[V]) {
@@ -178,9 +192,12 @@ __global__ __launch_bounds__(256) void stream_kernel(const StreamArgs p, const T
     if (++ld_s == KS) {
       ld_s = 0;
       ++ld_chunk;
-      uint32_t m = ld_chunk * (16 * V) + V * j;
-      offA_ld = -1;
-      if (ld_chunk < c_end && m < p.M) sdecomp2(m, p.nm, p.dim_m, p.sa_m, p.sc_m, offA_ld, offC_dummy);
+      if (aligned && ++ld_in != inner_chunks && ld_chunk < c_end) {
+        offA_ld += CH;  // next chunk of the same contiguous run
+      } else {
+        ld_in = 0;
+        seek_load();
+      }
     }
   };
 
@@ -189,9 +206,31 @@ __global__ __launch_bounds__(256) void stream_kernel(const StreamArgs p, const T
     if ((uint32_t)u < g_total) issue_load(areg[u]);
   }
 
-  uint32_t cp_chunk = c_begin, cp_s = 0;
+  // ---- compute / store cursor ----------------------------------------------------
+  uint32_t cp_chunk = c_begin, cp_s = 0, cp_in = aligned ? c_begin % inner_chunks : 0;
+  int64_t cbase = -1;  // aligned: C offset of the chunk's first m
+  if (aligned) sdecomp2(c_begin * CH, p.nm, p.dim_m, p.sa_m, p.sc_m, dummy, cbase);
   T vmax = T(0);
   const T* Wrow = Wl + kq * LDW + j;
+
+  // ZMODE: element offsets of this lane's accumulator rows inside the wave's LDS tile
+  int zoff[NT][4];
+  T* tile = nullptr;
+  if constexpr (ZMODE) {
+    tile = Zl + (size_t)wave * (NPAD * CH);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        uint32_t n = nt * 16 + SMfma<T>::row(lane, r);
+        if (n < p.N) {
+          uint32_t no = n / p.d_in, ni = n - no * p.d_in;
+          zoff[nt][r] = (int)((no * CH) * p.d_in + ni);
+        } else {
+          zoff[nt][r] = -1;
+        }
+      }
+  }
 
   for (uint32_t g0 = 0; g0 < g_total; g0 += RING) {
 #pragma unroll
@@ -207,32 +246,74 @@ __global__ __launch_bounds__(256) void stream_kernel(const StreamArgs p, const T
           for (int t = 0; t < V; ++t) acc[t][nt] = SMfma<T>::run(w[nt], areg[u][t], acc[t][nt]);
         if (g + RING < g_total) issue_load(areg[u]);
         if (++cp_s == KS) {
-          // ---- chunk epilogue: V-wide stores, lanes along m ---------------------
           cp_s = 0;
-          uint32_t m = cp_chunk * (16 * V) + V * j;
-          ++cp_chunk;
-          int64_t oa, oc = -1;
-          if (m < p.M) sdecomp2(m, p.nm, p.dim_m, p.sa_m, p.sc_m, oa, oc);
+          if constexpr (ZMODE) {
+            // ---- transpose through LDS, store contiguous runs ------------------
 #pragma unroll
-          for (int nt = 0; nt < NT; ++nt) {
+            for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const int n = nt * 16 + SMfma<T>::row(lane, r);
-              T o[V];
+              for (int r = 0; r < 4; ++r) {
+                if (zoff[nt][r] >= 0) {
 #pragma unroll
-              for (int t = 0; t < V; ++t) {
-                o[t] = acc[t][nt][r] * alpha;
-                T a = o[t] < T(0) ? -o[t] : o[t];
+                  for (int t = 0; t < V; ++t)
+                    tile[zoff[nt][r] + (V * j + t) * (int)p.d_in] = acc[t][nt][r] * alpha;
+                }
+              }
+            __builtin_amdgcn_wave_barrier();
+            const uint32_t run_v = (CH * p.d_in) / EV;          // 16-byte vectors per n_out run
+            const uint32_t tot_v = (p.N * CH) / EV;
+            for (uint32_t q = lane; q < tot_v; q += 64) {
+              uint32_t no = q / run_v, wv = q - no * run_v;
+              T o[EV];
+              vload<T, EV>(o, tile + (size_t)q * EV);
+#pragma unroll
+              for (int e = 0; e < EV; ++e) {
+                T a = o[e] < T(0) ? -o[e] : o[e];
                 vmax = a > vmax ? a : vmax;
               }
-              const int64_t on = offCn[n];
-              if (oc >= 0 && on >= 0) vstore<T, V>(C + oc + on, o);
+              vstore<T, EV>(C + cbase + offCn[no * p.d_in] + (int64_t)wv * EV, o);
+            }
+            __builtin_amdgcn_wave_barrier();
+          } else {
+            // ---- V-wide stores straight from the accumulators, lanes along m ------
+            int64_t oc = -1;
+            if (aligned) {
+              oc = cbase + V * j;
+            } else {
+              uint32_t m = cp_chunk * CH + V * j;
+              int64_t oa;
+              if (m < p.M) sdecomp2(m, p.nm, p.dim_m, p.sa_m, p.sc_m, oa, oc);
+            }
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                const int n = nt * 16 + SMfma<T>::row(lane, r);
+                T o[V];
+#pragma unroll
+                for (int t = 0; t < V; ++t) {
+                  o[t] = acc[t][nt][r] * alpha;
+                  T a = o[t] < T(0) ? -o[t] : o[t];
+                  vmax = a > vmax ? a : vmax;
+                }
+                const int64_t on = offCn[n];
+                if (oc >= 0 && on >= 0) vstore<T, V>(C + oc + on, o);
+              }
             }
           }
 #pragma unroll
           for (int t = 0; t < V; ++t)
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) acc[t][nt] = acc_t{0, 0, 0, 0};
+          ++cp_chunk;
+          if (aligned && cp_chunk < c_end) {
+            if (++cp_in != inner_chunks) {
+              cbase += (int64_t)CH * p.sc_m_in;
+            } else {
+              cp_in = 0;
+              sdecomp2(cp_chunk * CH, p.nm, p.dim_m, p.sa_m, p.sc_m, dummy, cbase);
+            }
+          }
         }
       }
     }
@@ -254,28 +335,30 @@ __global__ __launch_bounds__(256) void stream_kernel(const StreamArgs p, const T
 
 using namespace qamd;
 
-template <typename T, int V, int NT>
-static int launch_stream_vn(const StreamArgs& a, const void* A, const void* B, void* C, const void* ktab,
-                            const void* sa, const void* sb, void* amax, hipStream_t st) {
+template <typename T, int V, int NT, bool ZMODE>
+static int launch_stream_vnz(const StreamArgs& a, const void* A, const void* B, void* C, const void* ktab,
+                             const void* sa, const void* sb, void* amax, hipStream_t st) {
   constexpr int RING = 4;
   constexpr int NPAD = NT * 16;
   constexpr int LDW = NPAD + ((48 - NPAD % 32) % 32);
   size_t lds = (size_t)(2 * NPAD + a.Kpad) * 8 + (size_t)a.Kpad * LDW * sizeof(T);
+  if (ZMODE) lds += (size_t)4 * NPAD * 16 * V * sizeof(T);
   if (lds > 64 * 1024)
-    (void)hipFuncSetAttribute((const void*)stream_kernel<T, V, NT, RING>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  QAMD_LAUNCH((stream_kernel<T, V, NT, RING>), dim3(a.grid), dim3(256), lds, st, a, (const T*)A, (const T*)B,
-              (T*)C, (const int64_t*)ktab, (const T*)sa, (const T*)sb, (T*)amax);
+    (void)hipFuncSetAttribute((const void*)stream_kernel<T, V, NT, RING, ZMODE>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  QAMD_LAUNCH((stream_kernel<T, V, NT, RING, ZMODE>), dim3(a.grid), dim3(256), lds, st, a, (const T*)A,
+              (const T*)B, (T*)C, (const int64_t*)ktab, (const T*)sa, (const T*)sb, (T*)amax);
   return hipGetLastError() == hipSuccess ? 0 : -4;
 }
 
-template <typename T, int V>
-static int launch_stream_v(const StreamArgs& a, const void* A, const void* B, void* C, const void* ktab,
-                           const void* sa, const void* sb, void* amax, hipStream_t st) {
+template <typename T, int V, bool ZMODE>
+static int launch_stream_vz(const StreamArgs& a, const void* A, const void* B, void* C, const void* ktab,
+                            const void* sa, const void* sb, void* amax, hipStream_t st) {
   switch (a.NT) {
-    case 1: return launch_stream_vn<T, V, 1>(a, A, B, C, ktab, sa, sb, amax, st);
-    case 2: return launch_stream_vn<T, V, 2>(a, A, B, C, ktab, sa, sb, amax, st);
-    case 3: return launch_stream_vn<T, V, 3>(a, A, B, C, ktab, sa, sb, amax, st);
-    case 4: return launch_stream_vn<T, V, 4>(a, A, B, C, ktab, sa, sb, amax, st);
+    case 1: return launch_stream_vnz<T, V, 1, ZMODE>(a, A, B, C, ktab, sa, sb, amax, st);
+    case 2: return launch_stream_vnz<T, V, 2, ZMODE>(a, A, B, C, ktab, sa, sb, amax, st);
+    case 3: return launch_stream_vnz<T, V, 3, ZMODE>(a, A, B, C, ktab, sa, sb, amax, st);
+    case 4: return launch_stream_vnz<T, V, 4, ZMODE>(a, A, B, C, ktab, sa, sb, amax, st);
     default: return -1;
   }
 }
@@ -285,12 +368,20 @@ extern "C" int qamd_stream_launch(int dtype, int V, const StreamArgs* a, const v
                                   void* absmax_out, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   if (dtype == 0) {
-    if (V == 4) return launch_stream_v<float, 4>(*a, A, B, C, ktab, scale_a, scale_b, absmax_out, st);
-    if (V == 2) return launch_stream_v<float, 2>(*a, A, B, C, ktab, scale_a, scale_b, absmax_out, st);
-    if (V == 1) return launch_stream_v<float, 1>(*a, A, B, C, ktab, scale_a, scale_b, absmax_out, st);
+    if (a->zmode) {
+      if (V == 4) return launch_stream_vz<float, 4, true>(*a, A, B, C, ktab, scale_a, scale_b, absmax_out, st);
+      return -2;
+    }
+    if (V == 4) return launch_stream_vz<float, 4, false>(*a, A, B, C, ktab, scale_a, scale_b, absmax_out, st);
+    if (V == 2) return launch_stream_vz<float, 2, false>(*a, A, B, C, ktab, scale_a, scale_b, absmax_out, st);
+    if (V == 1) return launch_stream_vz<float, 1, false>(*a, A, B, C, ktab, scale_a, scale_b, absmax_out, st);
   } else if (dtype == 1) {
-    if (V == 2) return launch_stream_v<double, 2>(*a, A, B, C, ktab, scale_a, scale_b, absmax_out, st);
-    if (V == 1) return launch_stream_v<double, 1>(*a, A, B, C, ktab, scale_a, scale_b, absmax_out, st);
+    if (a->zmode) {
+      if (V == 2) return launch_stream_vz<double, 2, true>(*a, A, B, C, ktab, scale_a, scale_b, absmax_out, st);
+      return -2;
+    }
+    if (V == 2) return launch_stream_vz<double, 2, false>(*a, A, B, C, ktab, scale_a, scale_b, absmax_out, st);
+    if (V == 1) return launch_stream_vz<double, 1, false>(*a, A, B, C, ktab, scale_a, scale_b, absmax_out, st);
   }
   return -2;
 }

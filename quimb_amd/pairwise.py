@@ -243,24 +243,18 @@ def plan_pair(a_inds, a_shape, b_inds, b_shape, out_inds, out_fixed=True, death=
     if out_fixed:
         oi = out_inds
     else:
+        # "death-ordered" layout: indices that are contracted sooner sit further
+        # out (slower).  The consumer then finds its contracted indices outermost and
+        # adjacent (one fused K group) and everything it keeps as one long contiguous
+        # run -- the streaming kernel's ideal operand -- and because every operand is
+        # already death-ordered the surviving M indices keep their relative order, so
+        # they fuse on both the load and the store side.  Stable: ties keep the big
+        # operand's order, then the small operand's.
         dmap = dict(death) if death else {}
         big = 1 << 60
-        # N indices: later-dying first, sooner-dying innermost (stable)
-        n_sorted = sorted(nn, key=lambda ix: -dmap.get(ix, big))
         kset = set(kk)
-        last_k = max((i for i, ix in enumerate(va.inds) if ix in kset), default=None)
-        oi = []
-        placed = False
-        for i, ix in enumerate(va.inds):
-            if ix in kset:
-                if i == last_k:
-                    oi.extend(n_sorted)
-                    placed = True
-                continue
-            oi.append(ix)
-        if not placed:
-            oi.extend(n_sorted)
-        oi = tuple(oi)
+        cand = [ix for ix in va.inds if ix not in kset] + list(nn)
+        oi = tuple(sorted(cand, key=lambda ix: dmap.get(ix, big)))
     oshape = tuple(size[ix] for ix in oi)
     sc = dict(zip(oi, contig_strides(oshape)))
 

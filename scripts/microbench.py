@@ -63,6 +63,12 @@ bench_pair("dgemm 4096^3 NN", "mk", (4096, 4096), "kn", (4096, 4096), "mn", dtyp
 print("== PEPS sweep steps, D=6 (HBM-bound): A[L,h,v,R] x S[h,x,v,y] -> C[L,y?,x?,R]")
 for (L, R) in [(6**4, 6**5), (6**8, 6), (6**9, 1), (1, 6**9), (6**2, 6**7)]:
     bench_pair(f"sweep L=6^{round(np.log(L)/np.log(6))} R=6^{round(np.log(R)/np.log(6))}", "lhvr", (L, 6, 6, R), "hxvy", (6, 6, 6, 6), "lxyr", fixed=False, cfgs=(-1, "T1"))
+print("== sweep steps in the executor's death-ordered layout: A[h,v,(a),m] x S[h,x,v,y] -> C[x,(a),m,y]")
+bench_pair("sweepZ m=6^9", "hvm", (6, 6, 6**9), "hxvy", (6, 6, 6, 6), "xmy", cfgs=(-1, "T1"))
+bench_pair("sweepZ a=6 m=6^8", "havm", (6, 6, 6, 6**8), "hxvy", (6, 6, 6, 6), "axmy", cfgs=(-1,))
+bench_pair("sweepX m=6^9 (C=[x,y,m])", "hvm", (6, 6, 6**9), "hxvy", (6, 6, 6, 6), "xym", cfgs=(-1,))
+bench_pair("row-end K=36 N=6", "hvm", (6, 6, 6**9), "hvy", (6, 6, 6), "my", cfgs=(-1, "T3"))
+bench_pair("row-start K=6 N=36", "vm", (6, 6**9), "xvy", (6, 6, 6), "xmy", cfgs=(-1, "T1"))
 print("== merged 2-site step K=N=216")
 bench_pair("sweep2 L=6^4 R=6^4", "lkr", (6**4, 216, 6**4), "kn", (216, 216), "lnr", fixed=True, cfgs=(0, 1))
 bench_pair("K=216 N=36 L=6^4 R=6^4", "lkr", (6**4, 216, 6**4), "kn", (216, 36), "lnr", fixed=True, cfgs=(-1, "T1"))

@@ -329,3 +329,30 @@ def check_mps_dense(dtype="float64", L=10, chi=7):
     want = orc.oracle_array_contract(arrays, inputs, out)
     got = qa.array_contract(arrays, inputs, out)
     assert_close(got, want, dtype)
+
+
+def check_stream_kernels(dtype, seed=8):
+    """Shapes that select the streaming kernels (big tensor x small tensor):
+    X (register stores, aligned and unaligned chunks) and Z (LDS-transposed
+    stores), single and multi-group M."""
+    rng = np.random.default_rng(seed)
+    hi = np.float64
+    cases = [
+        ("km,kn->nm", dict(k=36, m=46656, n=36)),        # X, aligned chunks, vec4
+        ("km,kn->nm", dict(k=36, m=23328, n=36)),        # X, chunks straddle nothing but M % 64 != 0
+        ("km,kn->nm", dict(k=6, m=7776 * 5, n=17)),      # X, odd N, scalar-ish vec
+        ("hvm,hxvy->xmy", dict(h=6, v=6, m=46656, x=6, y=6)),   # Z, d_in = 6
+        ("hvm,hxvy->mxy", dict(h=6, v=6, m=46656, x=6, y=6)),   # Z, d_in = 36
+        ("havm,hxvy->axmy", dict(h=6, a=3, v=6, m=46656, x=6, y=6)),  # Z, two M groups
+        ("ham,hx->axm", dict(h=4, a=5, m=8192, x=4)),     # X, two M groups
+        ("km,kn->mn", dict(k=2, m=1 << 16, n=2)),         # gate-like, C row-major -> Z with d_in = 2
+        ("lkr,kn->lnr", dict(l=64, k=4, r=1024, n=4)),    # 2-qubit gate on a state
+    ]
+    for eq, dims in cases:
+        lhs, out = eq.split("->")
+        ai, bi = lhs.split(",")
+        a = rand(rng, [dims[c] for c in ai], dtype)
+        b = rand(rng, [dims[c] for c in bi], dtype)
+        want = np.einsum(eq, a.astype(hi), b.astype(hi))
+        got = qa.einsum(eq, qa.asarray(a), qa.asarray(b))
+        assert_close(got.to_numpy(), want, dtype)

@@ -37,17 +37,29 @@ def test_load_and_plan_finalize():
     lib = _lib.load()
     assert lib.qamd_abi_version() == 1
     assert b"gfx950" in lib.qamd_build_info()
-    step = plan_pair(("l", "h", "v", "r"), (36, 6, 6, 216), ("h", "x", "v", "y"), (6, 6, 6, 6), ("l", "x", "y", "r"), False)
+    # a boundary-sweep step in the executor's death-ordered layout:
+    #   A[h, v, m] (m one contiguous run)  x  S[h, x, v, y]  ->  C[x, m, y]
+    death = (("x", 1), ("m", 5), ("y", 9))
+    step = plan_pair(("h", "v", "m"), (6, 6, 46656), ("h", "x", "v", "y"), (6, 6, 6, 6), ("m", "x", "y"), False, death)
+    assert step.out_inds == ("x", "m", "y")
     p = fill_plan_struct(step.spec, _lib.QAMD_F32)
     assert lib.qamd_pair_plan_finalize(C.byref(p), 16, 16, 16) == 0
-    assert p.tile_cfg == 2 and p.vec_a == 4 and p.a_kcontig == 0 and p.c_ncontig == 0
-    # big tensor x small tensor with the stride-1 index in M on both sides -> streaming kernel
-    assert p.kernel == 1 and p.vec_c == 4
+    assert p.vec_a == 4 and p.a_kcontig == 0 and p.c_ncontig == 1
+    # big x small, A's stride-1 index in M, C = [.., m, y] -> streaming kernel with transposed stores
+    assert p.kernel == 2 and p.vec_c == 4
     assert lib.qamd_pair_ktab_len(C.byref(p)) == 2 * 48
     assert lib.qamd_pair_workspace_bytes(C.byref(p)) == 0
     # caller can force the tiled kernel
     p.kernel = -1
     assert lib.qamd_pair_plan_finalize(C.byref(p), 16, 16, 16) == 0 and p.kernel == 0
+    # same operands, numpy-style output order [m, x, y]: M-contiguous C is impossible, N block is 36
+    step2 = plan_pair(("h", "v", "m"), (6, 6, 46656), ("h", "x", "v", "y"), (6, 6, 6, 6), ("m", "x", "y"), True)
+    p2 = fill_plan_struct(step2.spec, _lib.QAMD_F32)
+    assert lib.qamd_pair_plan_finalize(C.byref(p2), 16, 16, 16) == 0 and p2.kernel == 2
+    # A[m, k] row-major (k contiguous) cannot stream -> tiled kernel
+    step3 = plan_pair(("m", "k"), (46656, 36), ("k", "n"), (36, 36), ("m", "n"), True)
+    p3 = fill_plan_struct(step3.spec, _lib.QAMD_F32)
+    assert lib.qamd_pair_plan_finalize(C.byref(p3), 16, 16, 16) == 0 and p3.kernel == 0 and p3.a_kcontig == 1
     # malformed plan is rejected, not crashed on
     p.nm = 99
     assert lib.qamd_pair_plan_finalize(C.byref(p), 16, 16, 16) == -1

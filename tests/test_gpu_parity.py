@@ -31,6 +31,33 @@ def test_tree_executor(hip, dtype):
     checks.check_tree_executor(dtype)
 
 
+@pytest.mark.parametrize("dtype", ["float32", "float64"])
+def test_stream_kernels(hip, dtype):
+    checks.check_stream_kernels(dtype)
+
+
+def test_sweep_3x8_D6_streams(hip):
+    """3x8 D=6 sweep: boundary 6^9, the death-ordered layouts select the streaming
+    kernels (aligned Z-mode) with the fused exponent-stripping epilogue."""
+    from oracle import np_oracle as orc
+    import quimb_amd as qa
+
+    arrays, inputs = orc.tn2d_rand(3, 8, 6, seed=5, dtype="float32")
+    size = {ix: 6 for t in inputs for ix in t}
+    tree = qa.ContractionTree(inputs, (), size, path=qa.sweep_path_2d(3, 8))
+    wm, we = orc.oracle_array_contract([a.astype(np.float64) for a in arrays], inputs, (), path=tree.get_path(),
+                                       strip_exponent=True)
+    hip.profile = []
+    m, e = qa.TreeExecutor(tree, "float32")(arrays, strip_exponent=True)
+    kinds = {cfg for (_, _, cfg, _, _, _) in hip.profile}
+    hip.profile = None
+    assert -1 in kinds  # at least one step ran on a streaming kernel
+    assert m.to_numpy().item() * 10.0**e == pytest.approx(wm.item() * 10.0**we, rel=5e-6)
+    # and without exponent stripping
+    out = qa.TreeExecutor(tree, "float32")(arrays)
+    assert out.to_numpy().item() == pytest.approx(wm.item() * 10.0**we, rel=5e-6)
+
+
 def test_hyper_network(hip):
     checks.check_hyper_network("float64")
     checks.check_hyper_network("float32")

@@ -74,3 +74,7 @@ def test_sweep_needs_no_permutes(emu):
     checks.assert_close(out.to_numpy(), want, "float64")
     assert emu.calls["permute"] == 0
     assert emu.calls["contract_pair"] == 24
+
+
+def test_stream_shapes_on_emulator(emu):
+    checks.check_stream_kernels("float64")
