@@ -172,7 +172,10 @@ def main():
                 roof = {"bound": "mfma", "achieved": flops_launch / avg / 1e12, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s"}
             roof["frac"] = roof["achieved"] / roof["peak"]
             roof["traffic"] = None
-            roof["kernel"] = f"gett_kernel<float> tile_cfg={cfg} split_k={sk}"
+            roof["kernel"] = (
+                {-1: "stream_kernel<float> X (register stores)", -2: "stream_kernel<float> Z (LDS-transposed stores)"}[cfg]
+                if cfg < 0 else f"gett_kernel<float> tile_cfg={cfg} split_k={sk}"
+            )
             roof["shape"] = {"B": B, "M": M, "N": N, "K": K}
             roof["avg_launch_ms"] = avg * 1e3
             roof["launches_timed"] = cnt

@@ -141,8 +141,7 @@ extern "C" int qamd_pair_plan_finalize(qamd_pair_plan* p, int64_t align_a, int64
       bool ok = true;
       for (int i = 0; i + 1 < p->nm; ++i) ok = ok && (p->sc_m[i] % ev == 0);
       for (int i = 0; i < p->nn; ++i) ok = ok && (p->sc_n[i] < d_in || p->sc_n[i] % ev == 0);
-      int64_t npad = ((d.N + 15) / 16) * 16;
-      ok = ok && (stream_lds_bytes(d.K, d.N, es) + 4 * npad * 16 * ev * es <= 80 * 1024);
+      ok = ok && (stream_lds_bytes(d.K, d.N, es) + 4 * d.N * 16 * ev * es <= 80 * 1024);
       if (ok) { kern = 2; vc = ev; }
     }
     if (!kern && base_ok && p->sc_m[p->nm - 1] == 1 && stream_lds_bytes(d.K, d.N, es) <= 64 * 1024) {
@@ -252,7 +251,7 @@ static int launch_stream(const qamd_pair_plan* p, const PairDims& d, const void*
   s.aligned = (p->dim_m[p->nm - 1] % (16 * V) == 0) ? 1 : 0;
   s.inner_chunks = s.aligned ? (uint32_t)(p->dim_m[p->nm - 1] / (16 * V)) : 1;
   s.chunks = (uint32_t)((d.M + 16 * V - 1) / (16 * V));
-  const uint32_t target_waves = 256 * 4 * (s.zmode ? 2 : 3);
+  const uint32_t target_waves = 256 * 4 * 3;
   s.chunks_per_wave = (s.chunks + target_waves - 1) / target_waves;
   if (s.chunks_per_wave < 1) s.chunks_per_wave = 1;
   uint32_t waves = (s.chunks + s.chunks_per_wave - 1) / s.chunks_per_wave;

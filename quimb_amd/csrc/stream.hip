@@ -123,7 +123,7 @@ __global__ __launch_bounds__(256) void stream_kernel(const StreamArgs p, const T
   int64_t* offBn = offCn + NPAD;                             // [NPAD]
   int64_t* koffA = offBn + NPAD;                             // [Kpad]
   T* Wl = reinterpret_cast<T*>(koffA + p.Kpad);              // [Kpad][LDW]
-  T* Zl = Wl + (size_t)p.Kpad * LDW;                         // ZMODE: 4 x [NPAD*CH] (16B aligned by host)
+  T* Zl = Wl + (size_t)p.Kpad * LDW;                         // ZMODE: 4 x [N*CH] wave-private tiles
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -150,6 +150,18 @@ __global__ __launch_bounds__(256) void stream_kernel(const StreamArgs p, const T
     }
   }
   __syncthreads();
+  if constexpr (ZMODE) {
+    int* zt = reinterpret_cast<int*>(offBn);
+    for (int n = tid; n < NPAD; n += 256) {
+      int z = -1;
+      if ((uint32_t)n < p.N) {
+        uint32_t no = n / p.d_in, ni = n - no * p.d_in;
+        z = (int)((no * CH) * p.d_in + ni);
+      }
+      zt[n] = z;
+    }
+    __syncthreads();
+  }
 
   const T alpha = T(1) / (read_scale(scale_a) * read_scale(scale_b));
 
@@ -213,24 +225,11 @@ __global__ __launch_bounds__(256) void stream_kernel(const StreamArgs p, const T
   T vmax = T(0);
   const T* Wrow = Wl + kq * LDW + j;
 
-  // ZMODE: element offsets of this lane's accumulator rows inside the wave's LDS tile
-  int zoff[NT][4];
+  // ZMODE: element offset of accumulator row n inside a wave's LDS tile, or -1.
+  // (lives in LDS -- offBn's storage is free once W is staged -- to keep VGPRs low)
+  int* zoffT = reinterpret_cast<int*>(offBn);
   T* tile = nullptr;
-  if constexpr (ZMODE) {
-    tile = Zl + (size_t)wave * (NPAD * CH);
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        uint32_t n = nt * 16 + SMfma<T>::row(lane, r);
-        if (n < p.N) {
-          uint32_t no = n / p.d_in, ni = n - no * p.d_in;
-          zoff[nt][r] = (int)((no * CH) * p.d_in + ni);
-        } else {
-          zoff[nt][r] = -1;
-        }
-      }
-  }
+  if constexpr (ZMODE) tile = Zl + (size_t)wave * (p.N * CH);
 
   for (uint32_t g0 = 0; g0 < g_total; g0 += RING) {
 #pragma unroll
@@ -253,10 +252,11 @@ __global__ __launch_bounds__(256) void stream_kernel(const StreamArgs p, const T
             for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
               for (int r = 0; r < 4; ++r) {
-                if (zoff[nt][r] >= 0) {
+                const int z = zoffT[nt * 16 + SMfma<T>::row(lane, r)];
+                if (z >= 0) {
 #pragma unroll
                   for (int t = 0; t < V; ++t)
-                    tile[zoff[nt][r] + (V * j + t) * (int)p.d_in] = acc[t][nt][r] * alpha;
+                    tile[z + (V * j + t) * (int)p.d_in] = acc[t][nt][r] * alpha;
                 }
               }
             __builtin_amdgcn_wave_barrier();
@@ -338,11 +338,11 @@ using namespace qamd;
 template <typename T, int V, int NT, bool ZMODE>
 static int launch_stream_vnz(const StreamArgs& a, const void* A, const void* B, void* C, const void* ktab,
                              const void* sa, const void* sb, void* amax, hipStream_t st) {
-  constexpr int RING = 4;
+  constexpr int RING = 8;
   constexpr int NPAD = NT * 16;
   constexpr int LDW = NPAD + ((48 - NPAD % 32) % 32);
   size_t lds = (size_t)(2 * NPAD + a.Kpad) * 8 + (size_t)a.Kpad * LDW * sizeof(T);
-  if (ZMODE) lds += (size_t)4 * NPAD * 16 * V * sizeof(T);
+  if (ZMODE) lds += (size_t)4 * a.N * 16 * V * sizeof(T);
   if (lds > 64 * 1024)
     (void)hipFuncSetAttribute((const void*)stream_kernel<T, V, NT, RING, ZMODE>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -178,7 +178,7 @@ class HipDevice:
         )
         if prof is not None:
             e1.record()
-            cfg = -1 if cp.struct.kernel == 1 else cp.struct.tile_cfg
+            cfg = -cp.struct.kernel if cp.struct.kernel else cp.struct.tile_cfg  # -1 / -2: streaming X / Z
             prof.append((spec, np.dtype(dtype), cfg, cp.struct.split_k, e0, e1))
 
     # ---- layout / elementwise -----------------------------------------------

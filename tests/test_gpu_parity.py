@@ -51,7 +51,7 @@ def test_sweep_3x8_D6_streams(hip):
     m, e = qa.TreeExecutor(tree, "float32")(arrays, strip_exponent=True)
     kinds = {cfg for (_, _, cfg, _, _, _) in hip.profile}
     hip.profile = None
-    assert -1 in kinds  # at least one step ran on a streaming kernel
+    assert kinds & {-1, -2}  # at least one step ran on a streaming kernel
     assert m.to_numpy().item() * 10.0**e == pytest.approx(wm.item() * 10.0**we, rel=5e-6)
     # and without exponent stripping
     out = qa.TreeExecutor(tree, "float32")(arrays)
