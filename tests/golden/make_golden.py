@@ -1,0 +1,127 @@
+#!/usr/bin/env python
+"""Generate golden vectors by running the REAL quimb sources from /root/reference.
+
+quimb's hard imports that are absent from this image (autoray, cotengra, numba,
+cytoolz/toolz -- SURVEY.md section 0.3) are satisfied by the minimal numpy-only
+stand-ins in ``tests/golden/_shims`` (dispatch + a restated pairwise contraction
+loop); everything else -- Tensor / TensorNetwork bookkeeping, tensor_contract's
+output-index / scalar / tag / exponent rules, the builders (TN2D_rand,
+MPS_rand_state, TN2D_classical_ising_partition_function, PEPS.rand), Tensor.fuse /
+transpose / isel, contract_structured for 1D -- is quimb's own code.
+
+    PYTHONPATH=tests/golden/_shims:/root/reference python tests/golden/make_golden.py
+
+writes tests/golden/*.npz (committed).  /root/reference only exists in the build
+container, so nothing at test time imports it.
+"""
+import json
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "_shims"))
+sys.path.insert(0, "/root/reference")
+
+import quimb as qu  # noqa: E402
+import quimb.tensor as qtn  # noqa: E402
+
+
+def enc_inds(inds):
+    return json.dumps([list(map(str, t)) for t in inds])
+
+
+def save_network(name, tn, extra):
+    arrays = [np.asarray(t.data) for t in tn]
+    inds = [t.inds for t in tn]
+    tags = [list(t.tags) for t in tn]
+    out = {f"a{i}": a for i, a in enumerate(arrays)}
+    out["inds"] = enc_inds(inds)
+    out["tags"] = json.dumps(tags)
+    out["n"] = len(arrays)
+    for k, v in extra.items():
+        out[k] = v
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print("wrote", name, {k: (np.shape(v) if hasattr(v, "shape") else v) for k, v in extra.items() if k != "inds"})
+
+
+def main():
+    rng = np.random.default_rng(1234)
+
+    # 1. pairwise tensor_contract cases (reference tests/test_tensor/test_tensor_core.py:434-512)
+    a = qtn.Tensor(rng.normal(size=(2, 3, 4)), inds=["i0", "i1", "i2"], tags="red")
+    b = qtn.Tensor(rng.normal(size=(3, 4, 5)), inds=["i1", "i2", "i3"], tags="blue")
+    c = qtn.Tensor(rng.normal(size=(5, 2, 6)), inds=["i3", "i0", "i4"], tags="blue")
+    ab = a @ b
+    abc = qtn.tensor_contract(a, b, c)
+    b2 = qtn.Tensor(rng.normal(size=(3, 4, 2)), inds=["i1", "i2", "i0"])
+    scalar = a @ b2
+    outer = a @ qtn.Tensor(b.data, inds=["j5", "j4", "j3"])
+    np.savez_compressed(
+        os.path.join(HERE, "pairwise.npz"),
+        a=a.data, b=b.data, c=c.data, b2=b2.data,
+        ab=ab.data, ab_inds=json.dumps(list(ab.inds)),
+        abc=abc.data, abc_inds=json.dumps(list(abc.inds)), abc_tags=json.dumps(list(abc.tags)),
+        scalar=np.asarray(scalar), scalar_is_float=isinstance(scalar, float),
+        outer=outer.data, outer_inds=json.dumps(list(outer.inds)),
+    )
+    print("wrote pairwise")
+
+    # 2. random 2D lattice (TN2D_rand, index order l,r,u,d), exact contraction
+    tn = qtn.TN2D_rand(4, 4, 3, seed=42, dtype="float64")
+    z = tn.contract(all, optimize="greedy")
+    m, e = tn.contract(all, optimize="greedy", strip_exponent=True)
+    save_network("tn2d_rand_4x4_D3", tn, dict(value=np.asarray(z), mantissa=np.asarray(m), exponent=np.asarray(e)))
+
+    # 3. classical Ising partition function 6x6 (builder tensor_builder.py:2687)
+    tn = qtn.TN2D_classical_ising_partition_function(6, 6, 0.44)
+    z = tn.contract(all, optimize="greedy")
+    save_network("ising_6x6_b044", tn, dict(value=np.asarray(z)))
+
+    # 4. MPS -> dense vector via quimb's structured contraction (tn1d/core.py:502)
+    mps = qtn.MPS_rand_state(8, 5, seed=7, dtype="float64")
+    dense = mps.contract()
+    save_network("mps_L8_chi5", mps, dict(dense=np.asarray(dense.data), dense_inds=json.dumps(list(dense.inds))))
+
+    # 5. PEPS amplitude: isel every physical index, contract the single-layer network
+    peps = qtn.PEPS.rand(3, 3, 4, seed=11, dtype="float64")
+    bits = [0, 1, 1, 0, 1, 0, 0, 1, 1]
+    sel = {peps.site_ind(i, j): bits[i * 3 + j] for i in range(3) for j in range(3)}
+    amp_tn = peps.isel(sel)
+    amp = amp_tn.contract(all, optimize="greedy")
+    save_network("peps_3x3_D4_amp", amp_tn, dict(value=np.asarray(amp)))
+
+    # 6. hyper-index network with explicit output_inds
+    hin = [("a", "x"), ("b", "x"), ("c", "x", "y"), ("y", "d"), ("a", "b"), ("c", "d", "y")]
+    size = dict(a=3, b=4, c=2, d=5, x=3, y=4)
+    ts = [qtn.Tensor(rng.normal(size=[size[i] for i in t]), inds=t) for t in hin]
+    htn = qtn.TensorNetwork(ts)
+    h0 = htn.contract(all, output_inds=(), optimize="greedy")
+    hx = htn.contract(all, output_inds=("y", "x"), optimize="greedy")
+    save_network("hyper_net", htn, dict(value=np.asarray(h0), yx=np.asarray(hx.data)))
+
+    # 7. fuse / transpose / isel of a Tensor (array_ops.py:95-182, tensor_core.py:3252-3298)
+    t = qtn.Tensor(rng.normal(size=(2, 3, 4, 5, 6)), inds=["a", "b", "c", "d", "e"])
+    f1 = t.fuse({"ce": ["e", "c"], "da": ["d", "a"]})
+    f2 = t.fuse({"bc": ["b", "c"]})
+    tr = t.transpose("e", "c", "a", "d", "b")
+    sl = t.isel({"c": 2, "a": 1})
+    np.savez_compressed(
+        os.path.join(HERE, "layout.npz"),
+        t=t.data, f1=f1.data, f1_inds=json.dumps(list(f1.inds)), f2=f2.data, f2_inds=json.dumps(list(f2.inds)),
+        tr=tr.data, sl=sl.data, sl_inds=json.dumps(list(sl.inds)),
+    )
+    print("wrote layout")
+
+    # 8. cut_iter sliced-sum identity (tensor_core.py:9291-9328)
+    tn = qtn.TN2D_rand(3, 3, 3, seed=5, dtype="float64")
+    full = tn.contract(all, optimize="greedy")
+    cut = [ix for ix in tn.inner_inds()][:2]
+    parts = [stn.contract(all, optimize="greedy") for stn in tn.cut_iter(*cut)]
+    save_network("tn2d_cut_3x3_D3", tn, dict(value=np.asarray(full), cut=json.dumps(list(cut)), parts=np.asarray(parts)))
+    print("quimb version:", qu.__version__)
+
+
+if __name__ == "__main__":
+    main()

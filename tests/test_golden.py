@@ -1,0 +1,48 @@
+"""Golden vectors from the real quimb (tests/golden/) against (a) the oracle,
+(b) the host logic on the numpy plan interpreter, (c) the HIP path (-m gpu)."""
+
+import numpy as np
+import pytest
+
+import checks
+from oracle import np_oracle as orc
+
+
+def _product_fns():
+    import quimb_amd as qa
+
+    def contract(arrays, inputs, output):
+        return qa.array_contract(arrays, inputs, output)
+
+    def tensor_contract(ts):
+        r = qa.tensor_contract(*[qa.Tensor(*t) for t in ts])
+        if isinstance(r, qa.Tensor):
+            return (np.asarray(r.data), r.inds, r.tags)
+        return r
+
+    return dict(
+        contract=contract,
+        tensor_contract=tensor_contract,
+        fuse=lambda x, *g: qa.fuse(qa.asarray(x), *g).to_numpy(),
+        transpose=lambda x, p: qa.transpose(qa.asarray(x), p).to_numpy(),
+        getitem=lambda x, k: qa.asarray(x)[k].to_numpy(),
+    )
+
+
+def test_oracle_matches_golden():
+    checks.check_golden(
+        contract=lambda a, i, o: orc.oracle_array_contract(a, i, o),
+        tensor_contract=lambda ts: orc.oracle_tensor_contract(ts),
+        fuse=orc.oracle_fuse,
+        transpose=np.transpose,
+        getitem=lambda x, k: x[k],
+    )
+
+
+def test_host_logic_matches_golden(emu):
+    checks.check_golden(**_product_fns())
+
+
+@pytest.mark.gpu
+def test_hip_matches_golden(hip):
+    checks.check_golden(**_product_fns(), rtol=1e-10)
