@@ -159,6 +159,13 @@ int qamd_axpby(void* y, const void* x, int64_t n, double fy, double fx, int32_t 
 int qamd_conj(void* dst, const void* src, int64_t n, int32_t dtype, void* stream);
 int qamd_cast(void* dst, int32_t dst_dtype, const void* src, int32_t src_dtype, int64_t n, void* stream);
 int qamd_fill(void* dst, int64_t n, double re, double im, int32_t dtype, void* stream);
+/*
+ * Complex contraction support: dst (4n reals) <- for every complex src[i] the 2x2
+ * real block [[re, im], [-im, re]] (im negated first if conj).  A complex pairwise
+ * contraction is then ONE real qamd_contract_pair with the K and N bundles doubled:
+ * A and C are used in place through their interleaved (re, im) real views.
+ */
+int qamd_complex_expand(void* dst, const void* src, int64_t n, int32_t conj, int32_t dtype, void* stream);
 
 /*
  * Exponent stripping: x /= max|x|; *exponent_dev (double, device) +=

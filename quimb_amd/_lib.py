@@ -72,6 +72,7 @@ SYMBOLS = [
     ("qamd_conj", C.c_int, [_vp, _vp, _i64, _i32, _vp]),
     ("qamd_cast", C.c_int, [_vp, _i32, _vp, _i32, _i64, _vp]),
     ("qamd_fill", C.c_int, [_vp, _i64, _dbl, _dbl, _i32, _vp]),
+    ("qamd_complex_expand", C.c_int, [_vp, _vp, _i64, _i32, _i32, _vp]),
     ("qamd_strip_exponent", C.c_int, [_vp, _i64, _i32, _vp, _vp, _vp]),
     ("qamd_absmax", C.c_int, [_vp, _vp, _i64, _i32, _vp]),
 ]

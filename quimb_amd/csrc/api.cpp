@@ -141,7 +141,7 @@ extern "C" int qamd_pair_plan_finalize(qamd_pair_plan* p, int64_t align_a, int64
       bool ok = true;
       for (int i = 0; i + 1 < p->nm; ++i) ok = ok && (p->sc_m[i] % ev == 0);
       for (int i = 0; i < p->nn; ++i) ok = ok && (p->sc_n[i] < d_in || p->sc_n[i] % ev == 0);
-      ok = ok && (stream_lds_bytes(d.K, d.N, es) + 4 * d.N * 16 * ev * es <= 80 * 1024);
+      ok = ok && (stream_lds_bytes(d.K, d.N, es) + 4 * (d.N + d_in) * 16 * ev * es <= 80 * 1024);
       if (ok) { kern = 2; vc = ev; }
     }
     if (!kern && base_ok && p->sc_m[p->nm - 1] == 1 && stream_lds_bytes(d.K, d.N, es) <= 64 * 1024) {
@@ -256,6 +256,37 @@ static int launch_stream(const qamd_pair_plan* p, const PairDims& d, const void*
   if (s.chunks_per_wave < 1) s.chunks_per_wave = 1;
   uint32_t waves = (s.chunks + s.chunks_per_wave - 1) / s.chunks_per_wave;
   s.grid = (waves + 3) / 4;
+  // ---- straight-line "sweep" kernel when the launch qualifies ------------------
+  const int es = kEsize[p->dtype];
+  const int ev = 16 / es;
+  int64_t kmax = 0;
+  for (int i = 0; i < p->nk; ++i) kmax += (p->dim_k[i] - 1) * p->sa_k[i];
+  if (s.aligned && V == ev && s.KS <= 9 && (kmax + 16 * ev) * es < (1ll << 32) && !getenv("QAMD_NO_SWEEP")) {
+    static const int kPS[6] = {1, 2, 3, 4, 6, 9};
+    int PS = 9;
+    for (int i = 0; i < 6; ++i) if (kPS[i] >= (int)s.KS) { PS = kPS[i]; break; }
+    // chunks per workgroup: a divisor of the innermost group's chunk count, near the target
+    const uint32_t ic = s.inner_chunks;
+    const uint32_t target = std::max<uint32_t>(8, (s.chunks + 256 * 6 - 1) / (256 * 6));
+    uint32_t best = 0;
+    for (uint32_t dlo = 1; (uint64_t)dlo * dlo <= ic; ++dlo) {
+      if (ic % dlo) continue;
+      uint32_t cand[2] = {dlo, ic / dlo};
+      for (uint32_t c : cand)
+        if (c <= 4 * target && c > best) best = c;
+    }
+    if (best >= 4) {
+      StreamArgs w = s;
+      w.Kpad = 4 * PS;
+      w.chunks_per_wave = best;  // chunks per WORKGROUP for the sweep kernel
+      w.grid = s.chunks / best;
+      if (p->dtype == QAMD_F32)
+        return qamd_sweep_launch_f32(PS, &w, A, B, C, ktab, ep ? ep->scale_a : nullptr,
+                                     ep ? ep->scale_b : nullptr, ep ? ep->absmax_out : nullptr, stream);
+      return qamd_sweep_launch_f64(PS, &w, A, B, C, ktab, ep ? ep->scale_a : nullptr,
+                                   ep ? ep->scale_b : nullptr, ep ? ep->absmax_out : nullptr, stream);
+    }
+  }
   return qamd_stream_launch(p->dtype, V, &s, A, B, C, ktab, ep ? ep->scale_a : nullptr,
                             ep ? ep->scale_b : nullptr, ep ? ep->absmax_out : nullptr, stream);
 }

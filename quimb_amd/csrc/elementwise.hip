@@ -353,6 +353,22 @@ __global__ void div_by_absmax_kernel(R* __restrict__ x, int64_t n_real, const R*
   for (; i < n_real; i += stride) x[i] = x[i] / m;
 }
 
+// complex operand -> real 2x2 blocks [[re, im], [-im, re]] so that a REAL contraction
+// with K and N doubled performs the complex product (see ops._complex_gett)
+template <typename R>
+__global__ void complex_expand_kernel(R* __restrict__ dst, const R* __restrict__ src, int64_t n, int conj) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) {
+    R re = src[2 * i], im = src[2 * i + 1];
+    if (conj) im = -im;
+    dst[4 * i + 0] = re;
+    dst[4 * i + 1] = im;
+    dst[4 * i + 2] = -im;
+    dst[4 * i + 3] = re;
+  }
+}
+
 }  // namespace qamd
 
 using namespace qamd;
@@ -535,5 +551,16 @@ extern "C" int qamd_div_by_absmax(void* x, int64_t n, const void* slots, int32_t
     QAMD_LAUNCH(div_by_absmax_kernel<float>, dim3(flat_grid(nr)), dim3(256), 0, st, (float*)x, nr, (const float*)slots);
   else
     QAMD_LAUNCH(div_by_absmax_kernel<double>, dim3(flat_grid(nr)), dim3(256), 0, st, (double*)x, nr, (const double*)slots);
+  QAMD_CHECK_LAUNCH();
+}
+
+extern "C" int qamd_complex_expand(void* dst, const void* src, int64_t n, int32_t conj, int32_t dtype, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype != 2 && dtype != 3) return -2;
+  if (n <= 0) return 0;
+  if (dtype == 2)
+    QAMD_LAUNCH(complex_expand_kernel<float>, dim3(flat_grid(n)), dim3(256), 0, st, (float*)dst, (const float*)src, n, conj);
+  else
+    QAMD_LAUNCH(complex_expand_kernel<double>, dim3(flat_grid(n)), dim3(256), 0, st, (double*)dst, (const double*)src, n, conj);
   QAMD_CHECK_LAUNCH();
 }

@@ -54,6 +54,10 @@ int qamd_gett_launch(int dtype, int cfg, const GettArgs* a, int swap, const void
 int qamd_stream_launch(int dtype, int V, const StreamArgs* a, const void* A, const void* B, void* C,
                        const void* ktab, const void* scale_a, const void* scale_b, void* absmax_out,
                        void* stream);
+int qamd_sweep_launch_f32(int PS, const StreamArgs* a, const void* A, const void* B, void* C, const void* ktab,
+                          const void* scale_a, const void* scale_b, void* absmax_out, void* stream);
+int qamd_sweep_launch_f64(int PS, const StreamArgs* a, const void* A, const void* B, void* C, const void* ktab,
+                          const void* scale_a, const void* scale_b, void* absmax_out, void* stream);
 void qamd_gett_tile_dims(int cfg, int* bm, int* bn, int* bk);
 int qamd_splitk_reduce_launch(int dtype, void* C, const void* ws, int64_t n, int split_k,
                               const void* scale_a, const void* scale_b, void* absmax_out, void* stream);

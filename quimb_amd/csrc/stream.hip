@@ -167,12 +167,18 @@ __global__ __launch_bounds__(256) void stream_kernel(const StreamArgs p, const T
 
   // ---- this wave's chunk range ------------------------------------------------
   const uint32_t wglob = blockIdx.x * 4 + wave;
-  uint32_t c_begin = wglob * p.chunks_per_wave;
-  uint32_t c_end = c_begin + p.chunks_per_wave;
+  // the 4 waves of a workgroup interleave over the workgroup's chunk range (wave w
+  // takes chunks first+w, first+w+4, ...), so together they touch 4 consecutive
+  // chunks -- 4x the contiguous bytes per k-row -- at about the same time
+  constexpr uint32_t CSTRIDE = 4;
+  const uint32_t blk_first = blockIdx.x * (p.chunks_per_wave * CSTRIDE);
+  uint32_t c_end = blk_first + p.chunks_per_wave * CSTRIDE;
   if (c_end > p.chunks) c_end = p.chunks;
+  const uint32_t c_begin = blk_first + wave;
   if (c_begin >= c_end) return;
   const uint32_t KS = p.KS;
-  const uint32_t g_total = (c_end - c_begin) * KS;
+  const uint32_t my_chunks = (c_end - c_begin + CSTRIDE - 1) / CSTRIDE;
+  const uint32_t g_total = my_chunks * KS;
   const bool aligned = p.aligned != 0;
   const uint32_t inner_chunks = p.inner_chunks;  // chunks per innermost M group (aligned mode)
 
@@ -203,11 +209,12 @@ __global__ __launch_bounds__(256) void stream_kernel(const StreamArgs p, const T
     if (offA_ld >= 0 && ko >= 0) vload<T, V>(dst, A + offA_ld + ko);
     if (++ld_s == KS) {
       ld_s = 0;
-      ++ld_chunk;
-      if (aligned && ++ld_in != inner_chunks && ld_chunk < c_end) {
-        offA_ld += CH;  // next chunk of the same contiguous run
+      ld_chunk += CSTRIDE;
+      ld_in += CSTRIDE;
+      if (aligned && ld_in < inner_chunks && ld_chunk < c_end) {
+        offA_ld += CSTRIDE * CH;  // same contiguous run
       } else {
-        ld_in = 0;
+        ld_in = aligned ? ld_chunk % inner_chunks : 0;
         seek_load();
       }
     }
@@ -305,12 +312,13 @@ __global__ __launch_bounds__(256) void stream_kernel(const StreamArgs p, const T
           for (int t = 0; t < V; ++t)
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) acc[t][nt] = acc_t{0, 0, 0, 0};
-          ++cp_chunk;
+          cp_chunk += CSTRIDE;
+          cp_in += CSTRIDE;
           if (aligned && cp_chunk < c_end) {
-            if (++cp_in != inner_chunks) {
-              cbase += (int64_t)CH * p.sc_m_in;
+            if (cp_in < inner_chunks) {
+              cbase += (int64_t)(CSTRIDE * CH) * p.sc_m_in;
             } else {
-              cp_in = 0;
+              cp_in = cp_chunk % inner_chunks;
               sdecomp2(cp_chunk * CH, p.nm, p.dim_m, p.sa_m, p.sc_m, dummy, cbase);
             }
           }

@@ -233,6 +233,17 @@ class HipDevice:
         v = complex(value)
         _lib.check(self.lib.qamd_fill(dst.data_ptr(), int(n), v.real, v.imag, dtype_code(dtype), self.stream()), "qamd_fill")
 
+    # ---- complex support ----------------------------------------------------------
+    def as_real(self, buf):
+        """Interleaved (re, im) real view of a complex buffer (shares memory)."""
+        return self.torch.view_as_real(buf).reshape(-1)
+
+    def complex_expand(self, dst, src, n, dtype, conj=False):
+        _lib.check(
+            self.lib.qamd_complex_expand(dst.data_ptr(), src.data_ptr(), int(n), int(bool(conj)), dtype_code(dtype), self.stream()),
+            "qamd_complex_expand",
+        )
+
     # ---- exponent stripping ---------------------------------------------------
     def new_exponent(self):
         """Device-resident float64 accumulator for log10 factors."""

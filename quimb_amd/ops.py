@@ -16,6 +16,7 @@ import numpy as np
 from .array import Array, asarray, _coerce_dtype, _REAL_OF
 from .pairwise import (
     BinarySpec,
+    GettSpec,
     PermuteSpec,
     ReduceSpec,
     contig_strides,
@@ -76,8 +77,25 @@ def run_pair_step(step, a, b, out=None, ep=None):
     return out
 
 
+def _complex_spec(spec):
+    """Real GETT spec of a complex contraction: every stride doubles (interleaved
+    re/im), the expanded small operand's strides quadruple, K gains an innermost
+    group over A's component c, N one over the output component d."""
+    b = tuple((d, 2 * sa, 4 * sb, 2 * sc) for d, sa, sb, sc in spec.b)
+    m = tuple((d, 2 * sa, None, 2 * sc) for d, sa, _, sc in spec.m)
+    n = tuple((d, None, 4 * sb, 2 * sc) for d, _, sb, sc in spec.n) + ((2, None, 1, 1),)
+    k = tuple((d, 2 * sa, 4 * sb, None) for d, sa, sb, _ in spec.k) + ((2, 1, 2, None),)
+    return GettSpec(b=b, m=m, n=n, k=k)
+
+
 def _complex_gett(dev, spec, ka, kb, out):
-    dev.contract_pair(spec, ka.dtype, ka._buf, kb._buf, out._buf)
+    """Complex pairwise contraction on the REAL MFMA kernels (the 4-multiply form):
+    the small operand is expanded once to 2x2 real blocks, the big operand and the
+    result are used in place through their interleaved real views."""
+    rdt = _REAL_OF[ka.dtype]
+    kb2 = dev.empty(4 * kb.size, rdt)
+    dev.complex_expand(kb2, kb._buf, kb.size, ka.dtype)
+    dev.contract_pair(_complex_spec(spec), rdt, dev.as_real(ka._buf), kb2, dev.as_real(out._buf))
 
 
 def einsum_pair(a, a_inds, b, b_inds, out_inds, out_fixed=True, death=None):

@@ -106,6 +106,14 @@ class EmuDevice:
     def fill(self, dst, n, value, dtype):
         dst[:n] = value if np.dtype(dtype).kind == "c" else complex(value).real
 
+    def as_real(self, buf):
+        return buf.view(buf.real.dtype)
+
+    def complex_expand(self, dst, src, n, dtype, conj=False):
+        z = np.conj(src[:n]) if conj else src[:n]
+        blk = np.stack([z.real, z.imag, -z.imag, z.real], axis=1).reshape(-1)
+        dst[: 4 * n] = blk
+
     def new_exponent(self):
         return np.zeros(1, dtype=np.float64)
 

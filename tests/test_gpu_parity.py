@@ -9,14 +9,14 @@ import checks
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("dtype", ["float32", "float64"])
+@pytest.mark.parametrize("dtype", ["float32", "float64", "complex64", "complex128"])
 def test_pairwise(hip, dtype):
     checks.check_pairwise(dtype)
     # bond-dimension-6 shapes (the headline network's dims)
     checks.check_pairwise(dtype, seed=10, dims=dict(a=6, b=6, c=6, d=6, e=6, f=6, g=6))
 
 
-@pytest.mark.parametrize("dtype", ["float32", "float64"])
+@pytest.mark.parametrize("dtype", ["float32", "float64", "complex64"])
 def test_tensordot_matmul(hip, dtype):
     checks.check_tensordot_matmul(dtype)
 
@@ -26,7 +26,7 @@ def test_layout_ops(hip, dtype):
     checks.check_layout_ops(dtype)
 
 
-@pytest.mark.parametrize("dtype", ["float32", "float64"])
+@pytest.mark.parametrize("dtype", ["float32", "float64", "complex64", "complex128"])
 def test_tree_executor(hip, dtype):
     checks.check_tree_executor(dtype)
 
@@ -63,7 +63,7 @@ def test_hyper_network(hip):
     checks.check_hyper_network("float32")
 
 
-@pytest.mark.parametrize("dtype", ["float32", "float64"])
+@pytest.mark.parametrize("dtype", ["float32", "float64", "complex64", "complex128"])
 def test_strip_exponent(hip, dtype):
     checks.check_strip_exponent(dtype)
 

@@ -7,7 +7,7 @@ import pytest
 import checks
 
 
-@pytest.mark.parametrize("dtype", ["float32", "float64"])
+@pytest.mark.parametrize("dtype", ["float32", "float64", "complex64", "complex128"])
 def test_pairwise(emu, dtype):
     checks.check_pairwise(dtype)
     assert emu.calls["contract_pair"] > 0
@@ -23,7 +23,7 @@ def test_layout_ops(emu, dtype):
     checks.check_layout_ops(dtype)
 
 
-@pytest.mark.parametrize("dtype", ["float32", "float64"])
+@pytest.mark.parametrize("dtype", ["float32", "float64", "complex128"])
 def test_tree_executor(emu, dtype):
     checks.check_tree_executor(dtype)
 
@@ -32,7 +32,7 @@ def test_hyper_network(emu):
     checks.check_hyper_network("float64")
 
 
-@pytest.mark.parametrize("dtype", ["float32", "float64"])
+@pytest.mark.parametrize("dtype", ["float32", "float64", "complex128"])
 def test_strip_exponent(emu, dtype):
     checks.check_strip_exponent(dtype)
 
