@@ -121,6 +121,8 @@ int64_t qamd_pair_workspace_bytes(const qamd_pair_plan* plan);
 int qamd_contract_pair(const qamd_pair_plan* plan, const void* A, const void* B, void* C,
                        const void* ktab_dev, void* workspace, int64_t workspace_bytes, void* stream);
 
+/* Name of the kernel instantiation a finalized plan launches (for profiles/benchmarks). */
+int qamd_pair_describe(const qamd_pair_plan* plan, char* buf, int32_t buflen);
 /* Same with the fused exponent-stripping epilogue (ep may be NULL). */
 int qamd_contract_pair_ex(const qamd_pair_plan* plan, const void* A, const void* B, void* C,
                           const void* ktab_dev, void* workspace, int64_t workspace_bytes,

@@ -61,6 +61,7 @@ SYMBOLS = [
     ("qamd_pair_build_ktab", C.c_int, [_pplan, _vp, _vp]),
     ("qamd_pair_workspace_bytes", _i64, [_pplan]),
     ("qamd_contract_pair", C.c_int, [_pplan, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
+    ("qamd_pair_describe", C.c_int, [_pplan, C.c_char_p, _i32]),
     ("qamd_contract_pair_ex", C.c_int, [_pplan, _vp, _vp, _vp, _vp, _vp, _i64, C.POINTER(Epilogue), _vp]),
     ("qamd_absmax_log10_sum", C.c_int, [_vp, _i64, _i32, _vp, _vp]),
     ("qamd_div_by_absmax", C.c_int, [_vp, _i64, _vp, _i32, _vp]),

@@ -3,6 +3,7 @@
 // permute, argument packing.  No device code here; kernels live in gett.hip and
 // elementwise.hip.  Nothing in this file allocates device memory or synchronises.
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <vector>
@@ -232,9 +233,33 @@ extern "C" int qamd_contract_pair(const qamd_pair_plan* p, const void* A, const 
   return qamd_contract_pair_ex(p, A, B, C, ktab, ws, ws_bytes, nullptr, stream);
 }
 
-static int launch_stream(const qamd_pair_plan* p, const PairDims& d, const void* A, const void* B, void* C,
-                         const void* ktab, const qamd_epilogue* ep, void* stream) {
-  StreamArgs s;
+// Does the launch qualify for the straight-line sweep kernel?  (aligned chunks, full
+// 16-byte vectors, K <= 36, 32-bit in-chunk byte offsets, a usable chunk-range divisor)
+static bool sweep_config(const qamd_pair_plan* p, const StreamArgs& s, int V, int& PS, uint32_t& cpb) {
+  const int es = kEsize[p->dtype];
+  const int ev = 16 / es;
+  int64_t kmax = 0;
+  for (int i = 0; i < p->nk; ++i) kmax += (p->dim_k[i] - 1) * p->sa_k[i];
+  if (!(s.aligned && V == ev && s.KS <= 9 && (kmax + 16 * ev) * es < (1ll << 32)) || getenv("QAMD_NO_SWEEP"))
+    return false;
+  static const int kPS[6] = {1, 2, 3, 4, 6, 9};
+  PS = 9;
+  for (int i = 0; i < 6; ++i) if (kPS[i] >= (int)s.KS) { PS = kPS[i]; break; }
+  // chunks per workgroup: a divisor of the innermost group's chunk count, near the target
+  const uint32_t ic = s.inner_chunks;
+  const uint32_t target = std::max<uint32_t>(8, (s.chunks + 256 * 6 - 1) / (256 * 6));
+  uint32_t best = 0;
+  for (uint32_t dlo = 1; (uint64_t)dlo * dlo <= ic; ++dlo) {
+    if (ic % dlo) continue;
+    uint32_t cand[2] = {dlo, ic / dlo};
+    for (uint32_t c : cand)
+      if (c <= 4 * target && c > best) best = c;
+  }
+  cpb = best;
+  return best >= 4;
+}
+
+static void fill_stream_args(const qamd_pair_plan* p, const PairDims& d, StreamArgs& s) {
   memset(&s, 0, sizeof(s));
   s.nm = p->nm; s.nn = p->nn;
   for (int i = 0; i < p->nm; ++i) { s.dim_m[i] = (uint32_t)p->dim_m[i]; s.sa_m[i] = p->sa_m[i]; s.sc_m[i] = p->sc_m[i]; }
@@ -256,36 +281,26 @@ static int launch_stream(const qamd_pair_plan* p, const PairDims& d, const void*
   if (s.chunks_per_wave < 1) s.chunks_per_wave = 1;
   uint32_t waves = (s.chunks + s.chunks_per_wave - 1) / s.chunks_per_wave;
   s.grid = (waves + 3) / 4;
+}
+
+static int launch_stream(const qamd_pair_plan* p, const PairDims& d, const void* A, const void* B, void* C,
+                         const void* ktab, const qamd_epilogue* ep, void* stream) {
+  StreamArgs s;
+  fill_stream_args(p, d, s);
+  const int V = p->vec_c;
   // ---- straight-line "sweep" kernel when the launch qualifies ------------------
-  const int es = kEsize[p->dtype];
-  const int ev = 16 / es;
-  int64_t kmax = 0;
-  for (int i = 0; i < p->nk; ++i) kmax += (p->dim_k[i] - 1) * p->sa_k[i];
-  if (s.aligned && V == ev && s.KS <= 9 && (kmax + 16 * ev) * es < (1ll << 32) && !getenv("QAMD_NO_SWEEP")) {
-    static const int kPS[6] = {1, 2, 3, 4, 6, 9};
-    int PS = 9;
-    for (int i = 0; i < 6; ++i) if (kPS[i] >= (int)s.KS) { PS = kPS[i]; break; }
-    // chunks per workgroup: a divisor of the innermost group's chunk count, near the target
-    const uint32_t ic = s.inner_chunks;
-    const uint32_t target = std::max<uint32_t>(8, (s.chunks + 256 * 6 - 1) / (256 * 6));
-    uint32_t best = 0;
-    for (uint32_t dlo = 1; (uint64_t)dlo * dlo <= ic; ++dlo) {
-      if (ic % dlo) continue;
-      uint32_t cand[2] = {dlo, ic / dlo};
-      for (uint32_t c : cand)
-        if (c <= 4 * target && c > best) best = c;
-    }
-    if (best >= 4) {
-      StreamArgs w = s;
-      w.Kpad = 4 * PS;
-      w.chunks_per_wave = best;  // chunks per WORKGROUP for the sweep kernel
-      w.grid = s.chunks / best;
-      if (p->dtype == QAMD_F32)
-        return qamd_sweep_launch_f32(PS, &w, A, B, C, ktab, ep ? ep->scale_a : nullptr,
-                                     ep ? ep->scale_b : nullptr, ep ? ep->absmax_out : nullptr, stream);
-      return qamd_sweep_launch_f64(PS, &w, A, B, C, ktab, ep ? ep->scale_a : nullptr,
+  int PS = 0;
+  uint32_t cpb = 0;
+  if (sweep_config(p, s, V, PS, cpb)) {
+    StreamArgs w = s;
+    w.Kpad = 4 * PS;
+    w.chunks_per_wave = cpb;  // chunks per WORKGROUP for the sweep kernel
+    w.grid = s.chunks / cpb;
+    if (p->dtype == QAMD_F32)
+      return qamd_sweep_launch_f32(PS, &w, A, B, C, ktab, ep ? ep->scale_a : nullptr,
                                    ep ? ep->scale_b : nullptr, ep ? ep->absmax_out : nullptr, stream);
-    }
+    return qamd_sweep_launch_f64(PS, &w, A, B, C, ktab, ep ? ep->scale_a : nullptr,
+                                 ep ? ep->scale_b : nullptr, ep ? ep->absmax_out : nullptr, stream);
   }
   return qamd_stream_launch(p->dtype, V, &s, A, B, C, ktab, ep ? ep->scale_a : nullptr,
                             ep ? ep->scale_b : nullptr, ep ? ep->absmax_out : nullptr, stream);
@@ -505,4 +520,26 @@ extern "C" int qamd_binary(void* out, const void* x, const int64_t* xs, const vo
   a.n = total;
   for (int i = 0; i < a.nd; ++i) { a.dim[i] = v[i].n; a.sa[i] = v[i].sa; a.sb[i] = v[i].sb; }
   return qamd_binary_launch(dtype, out, x, y, &a, stream);
+}
+
+extern "C" int qamd_pair_describe(const qamd_pair_plan* p, char* buf, int32_t buflen) {
+  PairDims d;
+  int rc = pair_dims(p, d);
+  if (rc || !buf || buflen <= 0) return QAMD_EINVAL;
+  const char* T = p->dtype == QAMD_F32 ? "float" : (p->dtype == QAMD_F64 ? "double" : "?");
+  if (p->kernel == 1 || p->kernel == 2) {
+    StreamArgs s;
+    fill_stream_args(p, d, s);
+    int PS = 0;
+    uint32_t cpb = 0;
+    if (sweep_config(p, s, p->vec_c, PS, cpb))
+      snprintf(buf, buflen, "sweep_kernel<%s, %u, %d, %s>", T, s.NT, PS, s.zmode ? "true" : "false");
+    else
+      snprintf(buf, buflen, "stream_kernel<%s, %d, %u, 8, %s>", T, p->vec_c, s.NT, s.zmode ? "true" : "false");
+  } else {
+    static const char* cfg[5] = {"2, 2, 4, 4", "2, 2, 2, 2", "4, 1, 4, 3", "4, 1, 4, 1", "4, 1, 2, 2"};
+    snprintf(buf, buflen, "gett_kernel<%s, %s, 16, %s> split_k=%d", T,
+             (p->tile_cfg >= 0 && p->tile_cfg < 5) ? cfg[p->tile_cfg] : "?", p->c_ncontig ? "false" : "true", p->split_k);
+  }
+  return QAMD_OK;
 }

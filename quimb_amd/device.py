@@ -152,6 +152,11 @@ class HipDevice:
         self._pairs[key] = cp
         return cp
 
+    def describe_pair(self, cp):
+        buf = C.create_string_buffer(160)
+        self.lib.qamd_pair_describe(C.byref(cp.struct), buf, 160)
+        return buf.value.decode()
+
     def contract_pair(self, spec, dtype, a, b, c, ep=None):
         """C = A . B.  ``ep`` = (slots_a, slots_b, slots_out) enables the fused
         exponent-stripping epilogue (entries may be None)."""
@@ -178,8 +183,7 @@ class HipDevice:
         )
         if prof is not None:
             e1.record()
-            cfg = -cp.struct.kernel if cp.struct.kernel else cp.struct.tile_cfg  # -1 / -2: streaming X / Z
-            prof.append((spec, np.dtype(dtype), cfg, cp.struct.split_k, e0, e1))
+            prof.append((spec, np.dtype(dtype), self.describe_pair(cp), cp.struct.split_k, e0, e1))
 
     # ---- layout / elementwise -----------------------------------------------
     def permute(self, dst, src, shape, strides, offset, dtype):
