@@ -153,19 +153,26 @@ def main():
         value = flops_step / (dt / args.steps) / 1e12
         # ---- dominant kernel from HIP-event timings over the timed region ------
         agg = {}
-        for spec, dt_, cfg, sk, e0, e1 in prof:
-            key = (spec.B, spec.M, spec.N, spec.K, cfg, sk)
-            a = agg.setdefault(key, [0.0, 0, spec])
+        for spec, dt_, name, sk, e0, e1 in prof:
+            if hasattr(spec, "off_k1"):  # fused pair of steps (Chain2Spec)
+                shape = {"fused_steps": 2, "M": spec.M, "D": spec.D, "K": spec.D**2, "N": spec.D**2}
+                nbytes = 4 * (spec.a_size + spec.c_size + 2 * spec.D**4)
+                nflops = 2 * spec.mults
+            else:
+                shape = {"B": spec.B, "M": spec.M, "N": spec.N, "K": spec.K}
+                nbytes = 4 * spec.B * (spec.M * spec.K + spec.K * spec.N + spec.M * spec.N)
+                nflops = 2 * spec.B * spec.M * spec.N * spec.K
+            key = (name, tuple(sorted(shape.items())))
+            a = agg.setdefault(key, [0.0, 0, shape, nbytes, nflops])
             a[0] += e0.elapsed_time(e1) * 1e-3
             a[1] += 1
         roof = None
         if agg:
-            key, (tsum, cnt, spec) = max(agg.items(), key=lambda kv: kv[1][0])
-            B, M, N, K, cfg, sk = key
+            key, (tsum, cnt, shape, bytes_launch, flops_launch) = max(agg.items(), key=lambda kv: kv[1][0])
+            cfg = key[0]
             avg = tsum / cnt
-            bytes_launch = 4 * B * (M * K + K * N + M * N)
-            flops_launch = 2 * B * M * N * K
             ai = flops_launch / bytes_launch
+            # the roof that bounds this launch: min(MFMA peak, AI x HBM peak)
             if ai < MFMA_F32_PEAK_TF * 1e12 / (HBM_PEAK_GBS * 1e9):
                 roof = {"bound": "hbm", "achieved": bytes_launch / avg / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s"}
             else:
@@ -177,11 +184,13 @@ def main():
             # FETCH_SIZE x 2 (gfx950 correction, MI355X_MICROARCH.md section HBM) + WRITE_SIZE, per launch
             try:
                 tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
-                if tj.get("kernel") == cfg and tj.get("shape") == {"B": B, "M": M, "N": N, "K": K}:
+                if tj.get("kernel") == cfg and tj.get("shape") == shape:
                     roof["traffic"] = tj["hbm_bytes_per_launch"]
             except Exception:
                 pass
-            roof["shape"] = {"B": B, "M": M, "N": N, "K": K}
+            roof["shape"] = shape
+            roof["arithmetic_intensity_flop_per_byte"] = ai
+            roof["tflops"] = flops_launch / avg / 1e12
             roof["avg_launch_ms"] = avg * 1e3
             roof["launches_timed"] = cnt
             roof["share_of_step_time"] = tsum / dt

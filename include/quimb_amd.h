@@ -128,6 +128,31 @@ int qamd_contract_pair_ex(const qamd_pair_plan* plan, const void* A, const void*
                           const void* ktab_dev, void* workspace, int64_t workspace_bytes,
                           const qamd_epilogue* ep, void* stream);
 /*
+ * Fused PAIR of streaming contractions (two adjacent site absorptions of a boundary
+ * sweep, quimb/tensor/tn2d/core.py:1402 twice) -- the intermediate never touches HBM:
+ *
+ *   X[x, y, v, m] = sum_k1     A[k1, v, m] * W1[k1, (x, y)]
+ *   C[x, n2, m]   = sum_{y,v}  X[x, y, v, m] * W2[(y, v), n2]        n2 = (n2_out, n2_in)
+ *
+ * every index size is D (k1 is D*D).  A: element offset of row k1 from offK1_dev[k1],
+ * v at stride sa_v, m over the bundle (dim_m, sa_m) with the innermost group stride-1
+ * and a multiple of qamd_chain2_chunk().  W1p / W2p: dense [D*D][D*D] device copies laid
+ * out [k1][x*D + y] and [y*D + v][n2_out*D + n2_in].  C: the innermost m group has
+ * stride D*D and is followed by the contiguous block [x][n2_in]; n2_out at element
+ * offset offCo_dev[n2_out].  scale_* / absmax_out: slots as described for the epilogue struct above; any may be NULL.
+ */
+typedef struct {
+  int32_t dtype, D, nm, reserved;
+  int64_t dim_m[QAMD_MAX_GROUPS], sa_m[QAMD_MAX_GROUPS], sc_m[QAMD_MAX_GROUPS];
+  int64_t sa_v;
+} qamd_chain2_plan;
+/* m-chunk the fused kernel works in for (dtype, D); 0 = combination not supported */
+int qamd_chain2_chunk(int32_t dtype, int32_t D);
+int qamd_contract_chain2(const qamd_chain2_plan* plan, const void* A, const void* W1p, const void* W2p, void* C,
+                         const void* offK1_dev, const void* offCo_dev, const void* scale_a, const void* scale_1,
+                         const void* scale_2, void* absmax_out, void* stream);
+
+/*
  * slots: n_tensors x QAMD_ABSMAX_SLOTS values (float for F32/C64, double
  * otherwise).  *out_dev (double, device) = sum_t log10(max over tensor t's slots),
  * tensors whose max is 0 are skipped.

@@ -41,6 +41,16 @@ class PairPlanStruct(C.Structure):
     ]
 
 
+class Chain2PlanStruct(C.Structure):
+    """Mirror of ``qamd_chain2_plan``."""
+
+    _fields_ = [
+        ("dtype", C.c_int32), ("D", C.c_int32), ("nm", C.c_int32), ("reserved", C.c_int32),
+        ("dim_m", _I64G), ("sa_m", _I64G), ("sc_m", _I64G),
+        ("sa_v", C.c_int64),
+    ]
+
+
 class Epilogue(C.Structure):
     """Mirror of ``qamd_epilogue``."""
 
@@ -63,6 +73,8 @@ SYMBOLS = [
     ("qamd_contract_pair", C.c_int, [_pplan, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
     ("qamd_pair_describe", C.c_int, [_pplan, C.c_char_p, _i32]),
     ("qamd_contract_pair_ex", C.c_int, [_pplan, _vp, _vp, _vp, _vp, _vp, _i64, C.POINTER(Epilogue), _vp]),
+    ("qamd_chain2_chunk", C.c_int, [_i32, _i32]),
+    ("qamd_contract_chain2", C.c_int, [C.POINTER(Chain2PlanStruct), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     ("qamd_absmax_log10_sum", C.c_int, [_vp, _i64, _i32, _vp, _vp]),
     ("qamd_div_by_absmax", C.c_int, [_vp, _i64, _vp, _i32, _vp]),
     ("qamd_permute", C.c_int, [_vp, _vp, _i32, _pi64, _pi64, _i64, _i32, _vp]),

@@ -543,3 +543,44 @@ extern "C" int qamd_pair_describe(const qamd_pair_plan* p, char* buf, int32_t bu
   }
   return QAMD_OK;
 }
+
+// ---------------------------------------------------------------------------
+// fused pair of streaming contractions
+// ---------------------------------------------------------------------------
+extern "C" int qamd_contract_chain2(const qamd_chain2_plan* p, const void* A, const void* W1p, const void* W2p,
+                                    void* C, const void* offK1_dev, const void* offCo_dev, const void* scale_a,
+                                    const void* scale_1, const void* scale_2, void* absmax_out, void* stream) {
+  if (!p || !A || !W1p || !W2p || !C || !offK1_dev || !offCo_dev) return QAMD_EINVAL;
+  if (p->nm < 1 || p->nm > QAMD_MAX_GROUPS) return QAMD_EINVAL;
+  const int ch = qamd_chain2_chunk(p->dtype, p->D);
+  if (!ch) return QAMD_EUNSUPPORTED;
+  const int64_t DD = (int64_t)p->D * p->D;
+  int64_t M = 1;
+  for (int i = 0; i < p->nm; ++i) {
+    if (p->dim_m[i] <= 0) return QAMD_EINVAL;
+    M *= p->dim_m[i];
+    if (M >= (1ll << 31)) return QAMD_EUNSUPPORTED;
+  }
+  const int64_t inner = p->dim_m[p->nm - 1];
+  if (p->sa_m[p->nm - 1] != 1 || p->sc_m[p->nm - 1] != DD || inner % ch) return QAMD_EUNSUPPORTED;
+  Chain2Args a;
+  memset(&a, 0, sizeof(a));
+  a.nm = p->nm;
+  for (int i = 0; i < p->nm; ++i) { a.dim_m[i] = (uint32_t)p->dim_m[i]; a.sa_m[i] = p->sa_m[i]; a.sc_m[i] = p->sc_m[i]; }
+  a.sa_v = p->sa_v;
+  a.chunks = (uint32_t)(M / ch);
+  const uint32_t ic = (uint32_t)(inner / ch);
+  const uint32_t target = std::max<uint32_t>(4, (a.chunks + 256 * 4 - 1) / (256 * 4));
+  uint32_t best = 0;
+  for (uint32_t dlo = 1; (uint64_t)dlo * dlo <= ic; ++dlo) {
+    if (ic % dlo) continue;
+    uint32_t cand[2] = {dlo, ic / dlo};
+    for (uint32_t c : cand)
+      if (c <= 4 * target && c > best) best = c;
+  }
+  if (best < 1) return QAMD_EUNSUPPORTED;
+  a.chunks_per_block = best;
+  a.grid = a.chunks / best;
+  return qamd_chain2_launch(p->dtype, p->D, &a, A, W1p, W2p, C, offK1_dev, offCo_dev, scale_a, scale_1, scale_2,
+                            absmax_out, stream);
+}

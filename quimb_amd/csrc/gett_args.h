@@ -38,6 +38,15 @@ struct StreamArgs {
   int64_t sc_m_in;        // C stride of the innermost M group
 };
 
+// fused pair of streaming contractions (chain2.hip)
+struct Chain2Args {
+  int32_t nm;
+  uint32_t dim_m[QAMD_G];
+  int64_t sa_m[QAMD_G], sc_m[QAMD_G];
+  int64_t sa_v;  // A stride of the carried index v
+  uint32_t chunks, chunks_per_block, grid;
+};
+
 struct KtabArgs {
   int32_t nk;
   uint32_t K, Kpad;
@@ -58,6 +67,9 @@ int qamd_sweep_launch_f32(int PS, const StreamArgs* a, const void* A, const void
                           const void* scale_a, const void* scale_b, void* absmax_out, void* stream);
 int qamd_sweep_launch_f64(int PS, const StreamArgs* a, const void* A, const void* B, void* C, const void* ktab,
                           const void* scale_a, const void* scale_b, void* absmax_out, void* stream);
+int qamd_chain2_launch(int dtype, int D, const Chain2Args* a, const void* A, const void* W1p, const void* W2p,
+                       void* C, const void* offK1, const void* offCo, const void* scale_a, const void* scale_1,
+                       const void* scale_2, void* absmax_out, void* stream);
 void qamd_gett_tile_dims(int cfg, int* bm, int* bn, int* bk);
 int qamd_splitk_reduce_launch(int dtype, void* C, const void* ws, int64_t n, int split_k,
                               const void* scale_a, const void* scale_b, void* absmax_out, void* stream);

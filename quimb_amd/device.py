@@ -185,6 +185,45 @@ class HipDevice:
             e1.record()
             prof.append((spec, np.dtype(dtype), self.describe_pair(cp), cp.struct.split_k, e0, e1))
 
+    # ---- fused pair of streaming steps ---------------------------------------------
+    def contract_chain2(self, c2, dtype, a, w1p, w2p, c, ep=None):
+        """C = (A . W1) . W2 in one pass (chain2.hip).  ``c2``: pairwise.Chain2Spec;
+        ``ep`` = (slots_a, slots_w1, slots_w2, slots_out) or None."""
+        key = ("chain2", c2, dtype_code(dtype))
+        ent = self._pairs.get(key)
+        if ent is None:
+            pl = _lib.Chain2PlanStruct()
+            pl.dtype, pl.D, pl.nm = dtype_code(dtype), c2.D, len(c2.m)
+            for i, (d, sa, sc) in enumerate(c2.m):
+                pl.dim_m[i], pl.sa_m[i], pl.sc_m[i] = d, sa, sc
+            pl.sa_v = c2.sa_v
+            k1 = self.torch.tensor(c2.off_k1, dtype=self.torch.int64, device=self.tdev)
+            co = self.torch.tensor(c2.off_co, dtype=self.torch.int64, device=self.tdev)
+            ent = (pl, k1, co)
+            self._pairs[key] = ent
+        pl, k1, co = ent
+        ptr = lambda t: (t.data_ptr() if t is not None else None)
+        sa = s1 = s2 = so = None
+        if ep is not None:
+            sa, s1, s2, so = (ptr(t) for t in ep)
+        prof = self.profile
+        if prof is not None:
+            e0 = self.torch.cuda.Event(enable_timing=True)
+            e1 = self.torch.cuda.Event(enable_timing=True)
+            e0.record()
+        _lib.check(
+            self.lib.qamd_contract_chain2(
+                C.byref(pl), a.data_ptr(), w1p.data_ptr(), w2p.data_ptr(), c.data_ptr(), k1.data_ptr(), co.data_ptr(),
+                sa, s1, s2, so, self.stream(),
+            ),
+            "qamd_contract_chain2",
+        )
+        if prof is not None:
+            e1.record()
+            tname = "float" if np.dtype(dtype) == np.dtype("float32") else "double"
+            ch = self.lib.qamd_chain2_chunk(dtype_code(dtype), c2.D)
+            prof.append((c2, np.dtype(dtype), f"chain2_kernel<{tname}, {c2.D}, {ch // 16}>", 1, e0, e1))
+
     # ---- layout / elementwise -----------------------------------------------
     def permute(self, dst, src, shape, strides, offset, dtype):
         nd = len(shape)

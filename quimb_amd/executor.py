@@ -20,7 +20,7 @@ import numpy as np
 
 from .array import Array, asarray, _coerce_dtype
 from .ops import _einsum_single, run_pair_step
-from .pairwise import plan_pair, prod
+from .pairwise import plan_chain2, plan_pair, prod
 from .tree import ContractionTree
 
 
@@ -89,6 +89,7 @@ class TreeExecutor:
             self.info.append(StepInfo(step.kind, step.mults, nbytes, dims, dep[res]))
         self.layout = layout
         self.dep = dep
+        self._fuse_pairs(size)
         if len(tree.remaining) != 1:
             raise ValueError("contraction path does not reduce the network to a single tensor")
         (self.root,) = tree.remaining
@@ -96,6 +97,44 @@ class TreeExecutor:
         if n == 1 and not tree.steps:
             self.out_inds = tuple(tree.output)
         self._hoisted = None  # cache of slice-independent intermediates for the current inputs
+
+    def _fuse_pairs(self, size):
+        """Replace consecutive big-x-small steps that have the two-site structure by one
+        fused launch (qamd_contract_chain2): the intermediate never reaches HBM."""
+        import os
+
+        if self.dtype.kind == "c" or os.environ.get("QAMD_NO_CHAIN2"):
+            return
+        plan, info = self.plan, self.info
+        new_plan, new_info = [], []
+        i = 0
+        while i < len(plan):
+            fused = None
+            if i + 1 < len(plan) and plan[i][0] == "pair" and plan[i + 1][0] == "pair":
+                _, a, b, r1, st1 = plan[i]
+                _, a2, b2, r2, st2 = plan[i + 1]
+                ok = st1.kind == "gett" and st2.kind == "gett" and not any(st1.pre) and not any(st2.pre)
+                ok = ok and self.dep[r1] == self.dep[r2]
+                if ok:
+                    A_id, W1_id = (b, a) if st1.swapped else (a, b)
+                    X_id, W2_id = (b2, a2) if st2.swapped else (a2, b2)
+                    if X_id == r1 and not st1.spec.b and not st2.spec.b:
+                        c2 = plan_chain2(self.layout[A_id], self.layout[W1_id], st1.out_inds, self.layout[W2_id],
+                                         st2.out_inds, size, self.dtype.name)
+                        if c2 is not None:
+                            fused = ("chain2", A_id, W1_id, W2_id, r2, c2)
+            if fused is not None:
+                c2 = fused[5]
+                isz = self.dtype.itemsize
+                new_plan.append(fused)
+                new_info.append(StepInfo("chain2", c2.mults, isz * (c2.a_size + c2.c_size + 2 * c2.D**4),
+                                         (1, c2.M, c2.D**2, c2.D**2), self.dep[fused[4]]))
+                i += 2
+            else:
+                new_plan.append(plan[i])
+                new_info.append(info[i])
+                i += 1
+        self.plan, self.info = new_plan, new_info
 
     # ---- accounting -------------------------------------------------------------
     def flops(self, per_slice=False, hoist=True):
@@ -143,13 +182,19 @@ class TreeExecutor:
         live = dict(enumerate(inputs))
         slots = None
         if exponent is not None:
-            nid = len(inputs) + len(self.plan)
+            nid = len(inputs) + len(self.tree.steps)
             slots = dev.new_slots(nid, self.dtype)
             has_scale = set()
         uses = {}
+        def operands(entry):
+            if entry[0] == "single":
+                return (entry[1],)
+            if entry[0] == "chain2":
+                return (entry[1], entry[2], entry[3])
+            return (entry[1], entry[2])
+
         for entry in self.plan:
-            ids = (entry[1],) if entry[0] == "single" else (entry[1], entry[2])
-            for s in ids:
+            for s in operands(entry):
                 uses[s] = uses.get(s, 0) + 1
         for entry in self.plan:
             if entry[0] == "single":
@@ -167,6 +212,29 @@ class TreeExecutor:
                     if independent and cache is not None:
                         cache[res] = live[res]
                 ids = (a,)
+            elif entry[0] == "chain2":
+                _, a, w1, w2, res, c2 = entry
+                independent = not self.dep[res]
+                if independent and cache is not None and res in cache:
+                    live[res] = cache[res]
+                elif only_independent and not independent:
+                    continue
+                else:
+                    from .ops import _apply_pre
+
+                    w1p = _apply_pre(live[w1], (c2.w1_pack,))
+                    w2p = _apply_pre(live[w2], (c2.w2_pack,))
+                    x = Array.empty(c2.out_shape, self.dtype, dev)
+                    ep = None
+                    if exponent is not None:
+                        ep = tuple(dev.slots_row(slots, s_) if s_ in has_scale else None for s_ in (a, w1, w2))
+                        ep = ep + (dev.slots_row(slots, res),)
+                        has_scale.add(res)
+                    dev.contract_chain2(c2, self.dtype, live[a]._buf, w1p._buf, w2p._buf, x._buf, ep)
+                    live[res] = x
+                    if independent and cache is not None:
+                        cache[res] = x
+                ids = (a, w1, w2)
             else:
                 _, a, b, res, step = entry
                 independent = not self.dep[res]

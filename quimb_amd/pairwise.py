@@ -352,3 +352,117 @@ def parse_einsum(eq, nops):
     if len(terms) != nops:
         raise ValueError(f"einsum: equation has {len(terms)} terms but {nops} operands given")
     return tuple(tuple(t) for t in terms), tuple(rhs)
+
+
+# ---------------------------------------------------------------------------
+# fused pair of streaming steps (qamd_contract_chain2)
+# ---------------------------------------------------------------------------
+def chain2_chunk(dtype_name, D):
+    """m-chunk of the fused pair kernel; mirrors ``qamd_chain2_chunk`` (0 = unsupported)."""
+    if dtype_name == "float32":
+        return 32 if 2 <= D <= 6 else (16 if D == 7 else 0)
+    if dtype_name == "float64":
+        return 16 if 2 <= D <= 6 else 0
+    return 0
+
+
+@dataclass(frozen=True)
+class Chain2Spec:
+    """Two consecutive big-x-small steps fused:  X = A.W1 ; C = X.W2  (see chain2.hip)."""
+
+    D: int
+    m: tuple          # groups (dim, stride_in_A, stride_in_C), outermost first
+    sa_v: int         # A stride of the carried index v
+    off_k1: tuple     # A element offset of every k1 row (D*D entries)
+    off_co: tuple     # C element offset of every n2_out value (D entries)
+    w1_pack: PermuteSpec   # W1 -> [k1..., x, y] contiguous
+    w2_pack: PermuteSpec   # W2 -> [y, v, n2_out, n2_in] contiguous
+    out_inds: tuple
+    out_shape: tuple
+    mults: int        # scalar multiplications of both steps
+    a_size: int
+    c_size: int
+
+    @property
+    def M(self):
+        return prod(g[0] for g in self.m)
+
+
+def plan_chain2(la, l1, lx, l2, lc, size, dtype_name):
+    """Try to fuse  X[lx] = A[la].W1[l1]  and  C[lc] = X.W2[l2]  (all layouts are index
+    tuples of C-contiguous arrays; ``lc`` is the layout already chosen for C).  Returns a
+    ``Chain2Spec`` or None if the pair does not have the fusable structure."""
+    s1, sx, s2, sc_ = set(l1), set(lx), set(l2), set(lc)
+    if len(set(la)) != len(la) or len(s1) != len(l1) or len(s2) != len(l2):
+        return None
+    k1 = [ix for ix in la if ix in s1 and ix not in sx]
+    if any(ix in s1 and ix in sx for ix in la):      # batch index in step 1
+        return None
+    n1 = [ix for ix in l1 if ix not in k1]
+    if any(ix not in sx for ix in n1) or any(ix not in sx for ix in la if ix not in k1):
+        return None                                    # step 1 sums something away
+    k2 = [ix for ix in lx if ix in s2 and ix not in sc_]
+    if any(ix in s2 and ix in sc_ for ix in lx):      # batch index in step 2
+        return None
+    n1set = set(n1)
+    k2n = [ix for ix in k2 if ix in n1set]
+    k2m = [ix for ix in k2 if ix not in n1set]
+    xs = [ix for ix in n1 if ix not in k2]
+    n2 = [ix for ix in l2 if ix not in k2]
+    if any(ix not in sc_ for ix in n2) or any(ix not in sc_ for ix in lx if ix not in k2):
+        return None
+    if not (len(k2m) == 1 and len(k2n) == 1 and len(xs) == 1 and len(n2) == 2):
+        return None
+    D = size[k2m[0]]
+    if any(size[ix] != D for ix in k2n + xs + n2) or prod(size[ix] for ix in k1) != D * D or not k1:
+        return None
+    chunk = chain2_chunk(dtype_name, D)
+    if not chunk:
+        return None
+    v, y, x = k2m[0], k2n[0], xs[0]
+    mm = [ix for ix in la if ix not in k1 and ix != v]
+    if not mm or set(lc) != set(mm) | {x} | set(n2):
+        return None
+    sa = dict(zip(la, contig_strides(tuple(size[i] for i in la))))
+    sc = dict(zip(lc, contig_strides(tuple(size[i] for i in lc))))
+    # C must end with [.., m_inner, x, n2_in]
+    n2in = lc[-1]
+    if n2in not in n2 or lc[-2] != x:
+        return None
+    n2out = [ix for ix in n2 if ix != n2in][0]
+    gm = _fuse(mm, size, [sa, sc])
+    if not gm or len(gm) > MAX_GROUPS:
+        return None
+    d_in, (sa_in, sc_in) = gm[-1]
+    if sa_in != 1 or sc_in != D * D or d_in % chunk:
+        return None
+    # byte offsets inside a chunk must fit 32 bits
+    kshape = [size[ix] for ix in k1]
+    kstr = [sa[ix] for ix in k1]
+    off_k1 = [0]
+    for d, st in zip(kshape, kstr):
+        off_k1 = [o + i * st for o in off_k1 for i in range(d)]
+    if (max(off_k1) + (D - 1) * sa[v] + 64) * 8 >= 2**32:
+        return None
+    s1d = dict(zip(l1, contig_strides(tuple(size[i] for i in l1))))
+    s2d = dict(zip(l2, contig_strides(tuple(size[i] for i in l2))))
+    o1 = tuple(k1) + (x, y)
+    o2 = (y, v, n2out, n2in)
+    w1_pack = PermuteSpec(o1, tuple(size[i] for i in o1), tuple(s1d[i] for i in o1))
+    w2_pack = PermuteSpec(o2, tuple(size[i] for i in o2), tuple(s2d[i] for i in o2))
+    M = prod(size[i] for i in mm)
+    mults = M * D * (D * D) * (D * D) * 2   # step 1: M*D columns x K1 x N1 ; step 2: M*D columns x K2 x N2
+    return Chain2Spec(
+        D=D,
+        m=tuple((d, st[0], st[1]) for d, st in gm),
+        sa_v=sa[v],
+        off_k1=tuple(off_k1),
+        off_co=tuple(i * sc[n2out] for i in range(D)),
+        w1_pack=w1_pack,
+        w2_pack=w2_pack,
+        out_inds=tuple(lc),
+        out_shape=tuple(size[i] for i in lc),
+        mults=mults,
+        a_size=prod(size[i] for i in la),
+        c_size=prod(size[i] for i in lc),
+    )

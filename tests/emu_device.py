@@ -66,6 +66,32 @@ class EmuDevice:
         assert len(np.unique(idx)) == idx.size, "output offsets collide"
         c[idx] = C
 
+    def contract_chain2(self, c2, dtype, a, w1p, w2p, c, ep=None):
+        """Semantics of qamd_contract_chain2 (see include/quimb_amd.h)."""
+        self.calls["chain2"] = self.calls.get("chain2", 0) + 1
+        D = c2.D
+        om_a = _offsets([(d, sa) for d, sa, _ in c2.m], 1)
+        om_c = _offsets([(d, sc) for d, _, sc in c2.m], 1)
+        ok1 = np.asarray(c2.off_k1, dtype=np.int64)
+        ov = np.arange(D, dtype=np.int64) * c2.sa_v
+        A = a[ok1[:, None, None] + ov[None, :, None] + om_a[None, None, :]]          # [k1, v, m]
+        W1 = w1p[: D**4].reshape(D * D, D, D)                                          # [k1, x, y]
+        W2 = w2p[: D**4].reshape(D, D, D, D)                                           # [y, v, no, ni]
+        X = np.einsum("kvm,kxy->xyvm", A, W1)
+        Cv = np.einsum("xyvm,yvoi->omxi", X, W2)                                       # [no, m, x, ni]
+        if ep is not None:
+            sc = 1.0
+            for t in ep[:3]:
+                if t is not None and t.max() > 0:
+                    sc *= float(t.max())
+            Cv = Cv * np.asarray(1.0 / sc, dtype=Cv.real.dtype)
+            if ep[3] is not None and Cv.size:
+                ep[3][0] = max(ep[3][0], np.max(np.abs(Cv)))
+        oco = np.asarray(c2.off_co, dtype=np.int64)
+        idx = oco[:, None, None, None] + om_c[None, :, None, None] + (np.arange(D) * D)[None, None, :, None] + np.arange(D)[None, None, None, :]
+        assert len(np.unique(idx)) == idx.size
+        c[idx] = Cv
+
     def permute(self, dst, src, shape, strides, offset, dtype):
         self.calls["permute"] += 1
         n = int(np.prod(shape)) if len(shape) else 1

@@ -58,6 +58,40 @@ def test_sweep_3x8_D6_streams(hip):
     assert out.to_numpy().item() == pytest.approx(wm.item() * 10.0**we, rel=5e-6)
 
 
+@pytest.mark.parametrize("Lx,Ly,D,dtype", [(4, 8, 2, "float64"), (4, 8, 2, "float32"), (3, 6, 4, "float32"),
+                                           (3, 5, 4, "float64"), (3, 8, 6, "float32"), (3, 7, 6, "float64")])
+def test_fused_pairs(hip, Lx, Ly, D, dtype):
+    """Two adjacent site absorptions in ONE launch (chain2 kernel): same value as the
+    fp64 oracle and as the unfused executor."""
+    import os
+
+    from oracle import np_oracle as orc
+    import quimb_amd as qa
+
+    arrays, inputs = orc.tn2d_rand(Lx, Ly, D, seed=13, dtype=dtype)
+    size = {ix: D for t in inputs for ix in t}
+    tree = qa.ContractionTree(inputs, (), size, path=qa.sweep_path_2d(Lx, Ly))
+    wm, we = orc.oracle_array_contract([a.astype(np.float64) for a in arrays], inputs, (), path=tree.get_path(),
+                                       strip_exponent=True)
+    want = wm.item() * 10.0**we
+    ex = qa.TreeExecutor(tree, dtype)
+    assert any(e[0] == "chain2" for e in ex.plan)
+    hip.profile = []
+    m, e = ex(arrays, strip_exponent=True)
+    names = {n.split("<")[0] for (_, _, n, _, _, _) in hip.profile}
+    hip.profile = None
+    assert "chain2_kernel" in names
+    rel = 5e-6 if dtype == "float32" else 1e-11
+    assert m.to_numpy().item() * 10.0**e == pytest.approx(want, rel=rel)
+    assert ex(arrays).to_numpy().item() == pytest.approx(want, rel=rel)
+    os.environ["QAMD_NO_CHAIN2"] = "1"
+    try:
+        ex0 = qa.TreeExecutor(tree, dtype)
+    finally:
+        del os.environ["QAMD_NO_CHAIN2"]
+    assert ex0(arrays).to_numpy().item() == pytest.approx(want, rel=rel)
+
+
 def test_hyper_network(hip):
     checks.check_hyper_network("float64")
     checks.check_hyper_network("float32")

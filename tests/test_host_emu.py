@@ -78,3 +78,44 @@ def test_sweep_needs_no_permutes(emu):
 
 def test_stream_shapes_on_emulator(emu):
     checks.check_stream_kernels("float64")
+
+
+@pytest.mark.parametrize("Lx,Ly,D,dtype", [(4, 8, 2, "float64"), (3, 6, 4, "float32"), (3, 5, 4, "float64")])
+def test_fused_pairs_in_sweeps(emu, Lx, Ly, D, dtype):
+    """Adjacent site absorptions are fused into chain2 launches (intermediate never
+    materialised) and give the same value as the oracle, with and without exponent
+    stripping and when fusion is disabled."""
+    import os
+
+    from oracle import np_oracle as orc
+    import quimb_amd as qa
+
+    arrays, inputs = orc.tn2d_rand(Lx, Ly, D, seed=9, dtype=dtype)
+    size = {ix: D for t in inputs for ix in t}
+    tree = qa.ContractionTree(inputs, (), size, path=qa.sweep_path_2d(Lx, Ly))
+    want = orc.oracle_array_contract([a.astype(np.float64) for a in arrays], inputs, (), path=tree.get_path())
+    ex = qa.TreeExecutor(tree, dtype)
+    nfused = sum(1 for e in ex.plan if e[0] == "chain2")
+    assert nfused >= 1, ex.plan
+    assert ex.flops() == tree.total_flops(dtype)  # fusion does not change the FLOP count
+    checks.assert_close(ex(arrays).to_numpy(), want, dtype)
+    assert emu.calls.get("chain2", 0) == nfused
+    m, e = ex(arrays, strip_exponent=True)
+    checks.assert_close(m.to_numpy() * 10.0**e, want, dtype)
+    os.environ["QAMD_NO_CHAIN2"] = "1"
+    try:
+        ex0 = qa.TreeExecutor(tree, dtype)
+    finally:
+        del os.environ["QAMD_NO_CHAIN2"]
+    assert not any(e[0] == "chain2" for e in ex0.plan)
+    checks.assert_close(ex0(arrays).to_numpy(), want, dtype)
+
+
+def test_chain2_chunk_table_matches_library():
+    from quimb_amd import _lib
+    from quimb_amd.pairwise import chain2_chunk
+
+    lib = _lib.load()
+    for D in range(1, 10):
+        assert lib.qamd_chain2_chunk(0, D) == chain2_chunk("float32", D)
+        assert lib.qamd_chain2_chunk(1, D) == chain2_chunk("float64", D)
