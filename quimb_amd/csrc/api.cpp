@@ -581,6 +581,7 @@ extern "C" int qamd_contract_chain2(const qamd_chain2_plan* p, const void* A, co
   if (best < 1) return QAMD_EUNSUPPORTED;
   a.chunks_per_block = best;
   a.grid = a.chunks / best;
+  if (const char* e = getenv("QAMD_CHAIN2_ABLATE")) a.ablate = (uint32_t)atoi(e);
   return qamd_chain2_launch(p->dtype, p->D, &a, A, W1p, W2p, C, offK1_dev, offCo_dev, scale_a, scale_1, scale_2,
                             absmax_out, stream);
 }

@@ -27,6 +27,7 @@
 //    coalesced stores straight from the tile.  alpha / absmax as in stream.hip.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "gett_args.h"
 
 #define QAMD_LAUNCH(...) do { (void)hipGetLastError(); hipLaunchKernelGGL(__VA_ARGS__); } while (0)
@@ -99,7 +100,7 @@ __device__ __forceinline__ T cread_scale(const T* slots) {
 constexpr int cpitch(int n) { return n + ((48 - n % 32) % 32); }
 
 template <typename T, int D, int V>
-__global__ __launch_bounds__(256, 1) void chain2_kernel(const Chain2Args p, const T* __restrict__ A,
+__global__ __launch_bounds__(256, (V == 1 ? 2 : 1)) void chain2_kernel(const Chain2Args p, const T* __restrict__ A,
                                                          const T* __restrict__ W1p, const T* __restrict__ W2p,
                                                          T* __restrict__ C, const int64_t* __restrict__ offK1,
                                                          const int64_t* __restrict__ offCo,
@@ -165,16 +166,30 @@ __global__ __launch_bounds__(256, 1) void chain2_kernel(const Chain2Args p, cons
   }
 
   T* Xt = Xall + (size_t)wave * (D * RS);
-  const T* W1row = W1l + kq * LD1 + j;
-  const T* W2row = W2l + kq * LD2 + j;
+  // W fragments for both stages stay in registers for the whole kernel
+  T wf1[KS1][NT1], wf2[KS2][NT2];
+#pragma unroll
+  for (int s = 0; s < KS1; ++s)
+#pragma unroll
+    for (int nt = 0; nt < NT1; ++nt) wf1[s][nt] = W1l[(4 * s + kq) * LD1 + nt * 16 + j];
+#pragma unroll
+  for (int s = 0; s < KS2; ++s)
+#pragma unroll
+    for (int nt = 0; nt < NT2; ++nt) wf2[s][nt] = W2l[(4 * s + kq) * LD2 + nt * 16 + j];
   T areg[D][KS1][V];
   T vmax = T(0);
 
+  const uint32_t abl = p.ablate;
   auto issue = [&]() {
+    if (abl & 4) return;
+    // wave-uniform base per v (SGPR pair) + the 32-bit per-lane row offset: KS1 address
+    // VGPRs in total, global_load ... v_off, s[base] addressing
 #pragma unroll
-    for (int v = 0; v < D; ++v)
+    for (int v = 0; v < D; ++v) {
+      const uint64_t bv = sbase + (uint64_t)v * svb;
 #pragma unroll
-      for (int s = 0; s < KS1; ++s) cload<T, V>(areg[v][s], sbase, koff[s] + v * svb);
+      for (int s = 0; s < KS1; ++s) cload<T, V>(areg[v][s], bv, koff[s]);
+    }
     sbase += (uint64_t)(CSTRIDE * CH * sizeof(T));
   };
 
@@ -190,24 +205,24 @@ __global__ __launch_bounds__(256, 1) void chain2_kernel(const Chain2Args p, cons
         for (int nt = 0; nt < NT1; ++nt) acc[t][nt] = acc_t{0, 0, 0, 0};
 #pragma unroll
       for (int s = 0; s < KS1; ++s) {
-        T w[NT1];
-#pragma unroll
-        for (int nt = 0; nt < NT1; ++nt) w[nt] = W1row[(4 * s) * LD1 + nt * 16];
 #pragma unroll
         for (int nt = 0; nt < NT1; ++nt)
 #pragma unroll
-          for (int t = 0; t < V; ++t) acc[t][nt] = CMfma<T>::run(w[nt], areg[v][s][t], acc[t][nt]);
+          for (int t = 0; t < V; ++t) acc[t][nt] = CMfma<T>::run(wf1[s][nt], areg[v][s][t], acc[t][nt]);
       }
 #pragma unroll
       for (int nt = 0; nt < NT1; ++nt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int n1 = nt * 16 + CMfma<T>::row(lane, r);
-          if (n1 < N1) {
-            const int x = n1 / D, y = n1 - x * D;
-            T* dst = Xt + x * RS + (y * D + v) * CH + V * j;
+          const bool ok = n1 < N1;
+          const int x = ok ? n1 / D : 0, y = ok ? n1 - (n1 / D) * D : 0;
+          T* dst = Xt + x * RS + (y * D + v) * CH + V * j;
+          if (ok && !(abl & 2)) {
 #pragma unroll
             for (int t = 0; t < V; ++t) dst[t] = acc[t][nt][r];
+          } else {
+            asm volatile("" :: "v"(acc[0][nt][r]));
           }
         }
     }
@@ -216,41 +231,41 @@ __global__ __launch_bounds__(256, 1) void chain2_kernel(const Chain2Args p, cons
     __builtin_amdgcn_wave_barrier();
 
     // ---- stage 2: for every x, in place ---------------------------------------------
+    T bx[2][KS2][V];
+    auto load_b = [&](T (&dst)[KS2][V], int x) {
+      const T* xr = Xt + x * RS + kq * CH + V * j;
 #pragma unroll
-    for (int x = 0; x < D; ++x) {
+      for (int s = 0; s < KS2; ++s) {
+        const bool ok = (K2P == K2) || (4 * s + kq < K2);
+#pragma unroll
+        for (int t = 0; t < V; ++t) dst[s][t] = ok ? xr[(4 * s) * CH + t] : T(0);
+      }
+    };
+    load_b(bx[0], 0);
+#pragma unroll
+    for (int x = 0; x < ((abl & 8) ? 0 : D); ++x) {
+      if (x + 1 < D) load_b(bx[(x + 1) & 1], x + 1);   // next x's fragments behind this x's MFMAs
       acc_t acc[V][NT2];
 #pragma unroll
       for (int t = 0; t < V; ++t)
 #pragma unroll
         for (int nt = 0; nt < NT2; ++nt) acc[t][nt] = acc_t{0, 0, 0, 0};
-      const T* xr = Xt + x * RS + kq * CH + V * j;
 #pragma unroll
-      for (int s = 0; s < KS2; ++s) {
-        T w[NT2];
-#pragma unroll
-        for (int nt = 0; nt < NT2; ++nt) w[nt] = W2row[(4 * s) * LD2 + nt * 16];
-        T b[V];
-        if (K2P == K2 || 4 * s + kq < K2) {
-#pragma unroll
-          for (int t = 0; t < V; ++t) b[t] = xr[(4 * s) * CH + t];
-        } else {
-#pragma unroll
-          for (int t = 0; t < V; ++t) b[t] = T(0);
-        }
+      for (int s = 0; s < KS2; ++s)
 #pragma unroll
         for (int nt = 0; nt < NT2; ++nt)
 #pragma unroll
-          for (int t = 0; t < V; ++t) acc[t][nt] = CMfma<T>::run(w[nt], b[t], acc[t][nt]);
-      }
+          for (int t = 0; t < V; ++t) acc[t][nt] = CMfma<T>::run(wf2[s][nt], bx[x & 1][s][t], acc[t][nt]);
       __builtin_amdgcn_wave_barrier();
 #pragma unroll
       for (int nt = 0; nt < NT2; ++nt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int n2 = nt * 16 + CMfma<T>::row(lane, r);
-          if (n2 < N2) {
-            const int no = n2 / D, ni = n2 - no * D;
-            T* dst = Xt + x * RS + (no * CH + V * j) * D + ni;
+          const bool ok = n2 < N2;
+          const int no = ok ? n2 / D : 0, ni = ok ? n2 - (n2 / D) * D : 0;
+          T* dst = Xt + x * RS + (no * CH + V * j) * D + ni;
+          if (ok) {
 #pragma unroll
             for (int t = 0; t < V; ++t) dst[t * D] = acc[t][nt][r] * alpha;
           }
@@ -259,16 +274,38 @@ __global__ __launch_bounds__(256, 1) void chain2_kernel(const Chain2Args p, cons
     __builtin_amdgcn_wave_barrier();
 
     // ---- copy-out: C[n2_out][chunk][x][n2_in], contiguous runs of CH*D*D ---------------
-#pragma unroll 1
-    for (int no = 0; no < D; ++no) {
-      T* crow = C + cbase + offCo[no];
-      for (int e = lane; e < CH * D * D; e += 64) {
+    constexpr int EW = (D % 4 == 0 && sizeof(T) == 4) ? 4 : (D % 2 == 0 ? 2 : 1);   // elements per store
+    typedef typename CVec<T, EW>::type evec_t;
+    // flattened over (n2_out, run element): exactly TOT/64 stores per lane when 64 | TOT,
+    // so the store count is static and the next chunk's loads are waited for by count
+    constexpr int RUNV = CH * D * D / EW;          // vectors per n2_out run
+    constexpr int TOT = D * RUNV;
+    constexpr int NIT = (TOT + 63) / 64;
+    int64_t co[D];
+#pragma unroll
+    for (int no = 0; no < D; ++no) co[no] = offCo[no];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int q = lane + 64 * it;
+      if (TOT % 64 == 0 || q < TOT) {
+        const int no = q / RUNV, e = (q - no * RUNV) * EW;
         const int ml = e / (D * D), rem = e - ml * (D * D);
         const int x = rem / D, ni = rem - x * D;
-        T val = Xt[x * RS + (no * CH + ml) * D + ni];
-        T a = val < T(0) ? -val : val;
-        vmax = a > vmax ? a : vmax;
-        crow[e] = val;
+        evec_t val = *reinterpret_cast<const evec_t*>(Xt + x * RS + (no * CH + ml) * D + ni);
+        if constexpr (EW == 1) {
+          T a = val < T(0) ? -val : val;
+          vmax = a > vmax ? a : vmax;
+        } else {
+#pragma unroll
+          for (int i = 0; i < EW; ++i) {
+            T a = val[i] < T(0) ? -val[i] : val[i];
+            vmax = a > vmax ? a : vmax;
+          }
+        }
+        int64_t cof = co[0];
+#pragma unroll
+        for (int n = 1; n < D; ++n) cof = (no == n) ? co[n] : cof;
+        if (!(abl & 1)) *reinterpret_cast<evec_t*>(C + cbase + cof + e) = val;
       }
     }
     __builtin_amdgcn_wave_barrier();
@@ -321,6 +358,7 @@ static int launch_chain2_t(int D, int V, const Chain2Args& a, const void* A, con
 
 // chunk size the kernel uses for (dtype, D); 0 = unsupported
 extern "C" int qamd_chain2_chunk(int dtype, int D) {
+  if (dtype == 0 && getenv("QAMD_CHAIN2_V1") && getenv("QAMD_CHAIN2_V1")[0] == '1') return (D >= 2 && D <= 7) ? 16 : 0;
   if (dtype == 0) return (D >= 2 && D <= 6) ? 32 : (D == 7 ? 16 : 0);   // LDS: W1+W2 + 4 wave tiles <= 160 KiB
   if (dtype == 1) return (D >= 2 && D <= 6) ? 16 : 0;
   return 0;

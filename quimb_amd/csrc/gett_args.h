@@ -45,6 +45,7 @@ struct Chain2Args {
   int64_t sa_m[QAMD_G], sc_m[QAMD_G];
   int64_t sa_v;  // A stride of the carried index v
   uint32_t chunks, chunks_per_block, grid;
+  uint32_t ablate;  // debug/ablation bits (QAMD_CHAIN2_ABLATE): 1 no stores, 2 no stage-1 scatter, 4 no loads, 8 no stage 2
 };
 
 struct KtabArgs {

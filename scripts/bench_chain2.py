@@ -1,0 +1,35 @@
+#!/usr/bin/env python
+"""Time the fused-pair kernel alone on the headline shape (optionally with ablation bits)."""
+import os, sys
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import quimb_amd as qa
+from quimb_amd.pairwise import plan_chain2
+from quimb_amd.ops import _apply_pre
+dev = qa.default_device()
+D, nm = 6, 8
+la = ("h", "u", "v") + tuple(f"m{i}" for i in range(nm))
+l1 = ("h", "y", "u", "x")
+lx = ("v", "y") + la[3:] + ("x",)
+l2 = ("y", "yy", "v", "xx")
+lc = (la[3], "yy") + la[4:] + ("x", "xx")
+size = {i: D for i in set(la) | set(l1) | set(l2)}
+c2 = plan_chain2(la, l1, lx, l2, lc, size, "float32")
+assert c2 is not None
+rnd = lambda n: torch.rand(n, device=dev.tdev) - 0.5
+A = qa.Array(dev, rnd(D ** len(la)), (D,) * len(la), "float32")
+W1 = qa.Array(dev, rnd(D**4), (D,) * 4, "float32")
+W2 = qa.Array(dev, rnd(D**4), (D,) * 4, "float32")
+w1p, w2p = _apply_pre(W1, (c2.w1_pack,)), _apply_pre(W2, (c2.w2_pack,))
+out = qa.Array.empty(c2.out_shape, "float32", dev)
+def run():
+    dev.contract_chain2(c2, "float32", A._buf, w1p._buf, w2p._buf, out._buf)
+for _ in range(3): run()
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(10): run()
+e1.record(); torch.cuda.synchronize()
+t = e0.elapsed_time(e1) / 10 * 1e-3
+print(f"ablate={os.environ.get('QAMD_CHAIN2_ABLATE','0')} V1={os.environ.get('QAMD_CHAIN2_V1','')} {t*1e3:.3f} ms  {2*c2.mults/t/1e12:.1f} TF  {4*(c2.a_size+c2.c_size)/t/1e9:.0f} GB/s")

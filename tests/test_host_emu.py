@@ -94,7 +94,11 @@ def test_fused_pairs_in_sweeps(emu, Lx, Ly, D, dtype):
     size = {ix: D for t in inputs for ix in t}
     tree = qa.ContractionTree(inputs, (), size, path=qa.sweep_path_2d(Lx, Ly))
     want = orc.oracle_array_contract([a.astype(np.float64) for a in arrays], inputs, (), path=tree.get_path())
-    ex = qa.TreeExecutor(tree, dtype)
+    os.environ["QAMD_CHAIN2"] = "1"
+    try:
+        ex = qa.TreeExecutor(tree, dtype)
+    finally:
+        del os.environ["QAMD_CHAIN2"]
     nfused = sum(1 for e in ex.plan if e[0] == "chain2")
     assert nfused >= 1, ex.plan
     assert ex.flops() == tree.total_flops(dtype)  # fusion does not change the FLOP count
