@@ -23,6 +23,7 @@ from .contract import (  # noqa: F401
     set_tensor_linop_backend, tensor_contract, tensor_linop_backend,
 )
 from .executor import TreeExecutor
+from .linop import TNLinearOperator
 from .pathfind import find_path, find_slices, greedy_path, random_greedy, sweep_path_2d
 from .tree import ContractionTree
 from .device import HipDevice, default_device

@@ -142,7 +142,7 @@ class ContractExpression:
             it = iter(arrays)
             n = len(self.tree.inputs)
             arrays = [self._const_dev[i] if i in self._const_dev else next(it) for i in range(n)]
-        host_in = not any(isinstance(a, Array) for a in arrays)
+        host_in = not any(isinstance(a, Array) for a in arrays if not any(a is c for c in self._const_dev.values()))
         out = self.executor(arrays, strip_exponent=self.strip_exponent, slices=slices)
         if self.strip_exponent:
             out, e = out

@@ -58,9 +58,11 @@ static int pick_vec(int64_t inner_dim, int64_t align_bytes, int esize, const std
   return 1;
 }
 
-static const int kTileBM[5] = {128, 64, 256, 256, 128};
-static const int kTileBN[5] = {128, 64, 48, 16, 32};
-static const int kBK = 16;
+static const int kNumTileCfg = 6;
+static const int kTileBM[kNumTileCfg] = {128, 64, 256, 256, 128, 128};
+static const int kTileBN[kNumTileCfg] = {128, 64, 48, 16, 32, 128};
+static const int kTileBK[kNumTileCfg] = {16, 16, 16, 16, 16, 32};
+static const int kBK = 32;  // k-offset tables are padded to the largest k-tile
 static const int kNumCU = 256;
 
 // size of the trailing block of N groups that is contiguous (stride-1 run) in C
@@ -160,14 +162,15 @@ extern "C" int qamd_pair_plan_finalize(qamd_pair_plan* p, int64_t align_a, int64
   }
 
   // ---- tile shape -----------------------------------------------------------
-  if (p->tile_cfg < 0 || p->tile_cfg > 4) {
+  if (p->tile_cfg < 0 || p->tile_cfg >= kNumTileCfg) {
     int cfg;
     if (d.N <= 16) cfg = 3;
     else if (d.N <= 32) cfg = 4;
     else if (d.N <= 48) cfg = 2;
     else {
-      int64_t big = ((d.M + 127) / 128) * ((d.N + 127) / 128) * d.B;
-      cfg = (big >= 2 * kNumCU) ? 0 : 1;
+      // measured (profiles/r01_microbench.txt): the 64x64 tile (more workgroups in flight)
+      // beats 128x128x16 and 128x128x32 at every size from 1024^3 to 8192^3, f32 and f64
+      cfg = 1;
     }
     p->tile_cfg = cfg;
   }
@@ -175,7 +178,8 @@ extern "C" int qamd_pair_plan_finalize(qamd_pair_plan* p, int64_t align_a, int64
   if (p->split_k < 1) {
     int bm = kTileBM[p->tile_cfg], bn = kTileBN[p->tile_cfg];
     int64_t tiles = ((d.M + bm - 1) / bm) * ((d.N + bn - 1) / bn) * d.B;
-    int64_t ksteps = (d.K + kBK - 1) / kBK;
+    const int bk = kTileBK[p->tile_cfg];
+    int64_t ksteps = (d.K + bk - 1) / bk;
     int64_t s = 1;
     if (tiles < kNumCU && ksteps >= 8) {
       s = (2 * kNumCU + tiles - 1) / tiles;
@@ -267,7 +271,7 @@ static void fill_stream_args(const qamd_pair_plan* p, const PairDims& d, StreamA
   s.M = (uint32_t)d.M; s.N = (uint32_t)d.N; s.K = (uint32_t)d.K;
   s.KS = (uint32_t)((d.K + 3) / 4);
   s.Kpad = 4 * s.KS;
-  s.KpadTab = (uint32_t)(((d.K + 15) / 16) * 16);
+  s.KpadTab = (uint32_t)kpad_of(d.K);
   s.NT = (uint32_t)((d.N + 15) / 16);
   const int V = p->vec_c;
   s.zmode = (p->kernel == 2) ? 1 : 0;
@@ -313,7 +317,7 @@ extern "C" int qamd_contract_pair_ex(const qamd_pair_plan* p, const void* A, con
   int rc = pair_dims(p, d);
   if (rc) return rc;
   if (p->dtype != QAMD_F32 && p->dtype != QAMD_F64) return QAMD_EUNSUPPORTED;
-  if (p->tile_cfg < 0 || p->tile_cfg > 4 || p->split_k < 1) return QAMD_EINVAL;
+  if (p->tile_cfg < 0 || p->tile_cfg >= kNumTileCfg || p->split_k < 1) return QAMD_EINVAL;
   if (!A || !B || !C || !ktab) return QAMD_EINVAL;
   if (p->kernel == 1 || p->kernel == 2) return launch_stream(p, d, A, B, C, ktab, ep, stream);
   const int bm = kTileBM[p->tile_cfg], bn = kTileBN[p->tile_cfg];
@@ -339,12 +343,14 @@ extern "C" int qamd_contract_pair_ex(const qamd_pair_plan* p, const void* A, con
   a.B = (uint32_t)d.B; a.M = (uint32_t)d.M; a.N = (uint32_t)d.N; a.K = (uint32_t)d.K;
   a.Kpad = (uint32_t)kpad_of(d.K);
   int split = p->split_k;
-  int64_t ksteps = a.Kpad / kBK;
+  const int bk = kTileBK[p->tile_cfg];
+  a.Kloop = (uint32_t)(((d.K + bk - 1) / bk) * bk);
+  int64_t ksteps = (d.K + bk - 1) / bk;
   if (split > ksteps) split = (int)std::max<int64_t>(ksteps, 1);
   int64_t steps_per = (ksteps + split - 1) / split;
   split = (int)((ksteps + steps_per - 1) / steps_per);
   if (split < 1) split = 1;
-  a.Kc = (uint32_t)(steps_per * kBK);
+  a.Kc = (uint32_t)(steps_per * bk);
   a.split_k = (uint32_t)split;
   a.tiles_m = (uint32_t)((d.M + bm - 1) / bm);
   a.tiles_n = (uint32_t)((d.N + bn - 1) / bn);
@@ -537,9 +543,11 @@ extern "C" int qamd_pair_describe(const qamd_pair_plan* p, char* buf, int32_t bu
     else
       snprintf(buf, buflen, "stream_kernel<%s, %d, %u, 8, %s>", T, p->vec_c, s.NT, s.zmode ? "true" : "false");
   } else {
-    static const char* cfg[5] = {"2, 2, 4, 4", "2, 2, 2, 2", "4, 1, 4, 3", "4, 1, 4, 1", "4, 1, 2, 2"};
-    snprintf(buf, buflen, "gett_kernel<%s, %s, 16, %s> split_k=%d", T,
-             (p->tile_cfg >= 0 && p->tile_cfg < 5) ? cfg[p->tile_cfg] : "?", p->c_ncontig ? "false" : "true", p->split_k);
+    static const char* cfg[kNumTileCfg] = {"2, 2, 4, 4, 16", "2, 2, 2, 2, 16", "4, 1, 4, 3, 16", "4, 1, 4, 1, 16",
+                                           "4, 1, 2, 2, 16", "2, 2, 4, 4, 32"};
+    snprintf(buf, buflen, "gett_kernel<%s, %s, %s> split_k=%d", T,
+             (p->tile_cfg >= 0 && p->tile_cfg < kNumTileCfg) ? cfg[p->tile_cfg] : "?", p->c_ncontig ? "false" : "true",
+             p->split_k);
   }
   return QAMD_OK;
 }

@@ -239,8 +239,9 @@ __global__ __launch_bounds__(256) void gett_kernel(const GettArgs p, const T* __
   int64_t* offCm = offAm + BM;
   int64_t* offBn = offCm + BM;
   int64_t* offCn = offBn + BN;
+  // double-buffered operand tiles: [2][BK][LDA] and [2][BK][LDB]
   T* As = reinterpret_cast<T*>(offCn + BN);
-  T* Bs = As + BK * LDA;
+  T* Bs = As + 2 * BK * LDA;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -295,7 +296,7 @@ __global__ __launch_bounds__(256) void gett_kernel(const GettArgs p, const T* __
 
   const uint32_t kbeg = ks * p.Kc;
   uint32_t kend = kbeg + p.Kc;
-  if (kend > p.Kpad) kend = p.Kpad;
+  if (kend > p.Kloop) kend = p.Kloop;
   const int nkt = (int)((kend - kbeg) / BK);
 
   acc_t acc[WM][WN];
@@ -321,20 +322,27 @@ __global__ __launch_bounds__(256) void gett_kernel(const GettArgs p, const T* __
   const T* Arow = As + fk * LDA + wm * (WM * 16) + fr;
   const T* Brow = Bs + fk * LDB + wn * (WN * 16) + fr;
 
+  // one barrier per k-step: while tile kt is consumed from buffer kt&1, tile kt+1 is
+  // fetched into registers and written to the other buffer; the barrier at the end of
+  // the step both publishes it and retires every read of the buffer that the step
+  // after next will overwrite.
   for (int kt = 0; kt < nkt; ++kt) {
     const bool more = (kt + 1 < nkt);
+    const int cur = kt & 1;
     if (more) {
       uint32_t k0 = kbeg + (kt + 1) * BK;
       LA::load(ra, Ab, offAm, ktA, k0, p.a_kcontig, p.vec_a, tid);
       LB::load(rb, Bb, offBn, ktB, k0, p.b_kcontig, p.vec_b, tid);
     }
+    const T* Ac = Arow + cur * (BK * LDA);
+    const T* Bc = Brow + cur * (BK * LDB);
 #pragma unroll
     for (int k4 = 0; k4 < BK / 4; ++k4) {
       T af[WM], bf[WN];
 #pragma unroll
-      for (int i = 0; i < WM; ++i) af[i] = Arow[k4 * 4 * LDA + i * 16];
+      for (int i = 0; i < WM; ++i) af[i] = Ac[k4 * 4 * LDA + i * 16];
 #pragma unroll
-      for (int j = 0; j < WN; ++j) bf[j] = Brow[k4 * 4 * LDB + j * 16];
+      for (int j = 0; j < WN; ++j) bf[j] = Bc[k4 * 4 * LDB + j * 16];
 #pragma unroll
       for (int i = 0; i < WM; ++i)
 #pragma unroll
@@ -343,12 +351,11 @@ __global__ __launch_bounds__(256) void gett_kernel(const GettArgs p, const T* __
           else acc[i][j] = Mfma<T>::run(af[i], bf[j], acc[i][j]);
         }
     }
-    __syncthreads();
     if (more) {
-      LA::store(ra, As, p.a_kcontig, tid);
-      LB::store(rb, Bs, p.b_kcontig, tid);
-      __syncthreads();
+      LA::store(ra, As + (cur ^ 1) * (BK * LDA), p.a_kcontig, tid);
+      LB::store(rb, Bs + (cur ^ 1) * (BK * LDB), p.b_kcontig, tid);
     }
+    __syncthreads();
   }
 
   // ---- epilogue: direct stores, lanes along C's contiguous bundle -------
@@ -441,7 +448,11 @@ static int launch_cfg(const GettArgs& a, bool swap, const void* A, const void* B
                       const void* ktab, const void* sa, const void* sb, void* amax, hipStream_t st) {
   constexpr int BM = WAVES_M * WM * 16;
   constexpr int BN = WAVES_N * WN * 16;
-  size_t lds = (size_t)(2 * BM + 2 * BN) * 8 + (size_t)BK * (lds_pitch(BM) + lds_pitch(BN)) * sizeof(T);
+  size_t lds = (size_t)(2 * BM + 2 * BN) * 8 + (size_t)2 * BK * (lds_pitch(BM) + lds_pitch(BN)) * sizeof(T);
+  if (lds > 64 * 1024) {
+    if (swap) (void)hipFuncSetAttribute((const void*)gett_kernel<T, WAVES_M, WAVES_N, WM, WN, BK, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    else (void)hipFuncSetAttribute((const void*)gett_kernel<T, WAVES_M, WAVES_N, WM, WN, BK, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  }
   uint64_t grid = (uint64_t)a.tiles_m * a.tiles_n * a.split_k * a.B;
   if (grid == 0 || grid > 0x7fffffffull) return -1;
   if (swap)
@@ -464,6 +475,7 @@ static int launch_T(int cfg, const GettArgs& a, bool swap, const void* A, const 
     case 2: return launch_cfg<T, 4, 1, 4, 3, 16>(a, swap, A, B, C, ktab, sa, sb, amax, st);  // 256 x  48
     case 3: return launch_cfg<T, 4, 1, 4, 1, 16>(a, swap, A, B, C, ktab, sa, sb, amax, st);  // 256 x  16
     case 4: return launch_cfg<T, 4, 1, 2, 2, 16>(a, swap, A, B, C, ktab, sa, sb, amax, st);  // 128 x  32
+    case 5: return launch_cfg<T, 2, 2, 4, 4, 32>(a, swap, A, B, C, ktab, sa, sb, amax, st);  // 128 x 128, k-tile 32
     default: return -1;
   }
 }
@@ -478,8 +490,8 @@ extern "C" int qamd_gett_launch(int dtype, int cfg, const GettArgs* a, int swap,
 }
 
 extern "C" void qamd_gett_tile_dims(int cfg, int* bm, int* bn, int* bk) {
-  static const int t[5][3] = {{128, 128, 16}, {64, 64, 16}, {256, 48, 16}, {256, 16, 16}, {128, 32, 16}};
-  if (cfg < 0 || cfg > 4) { *bm = *bn = *bk = 0; return; }
+  static const int t[6][3] = {{128, 128, 16}, {64, 64, 16}, {256, 48, 16}, {256, 16, 16}, {128, 32, 16}, {128, 128, 32}};
+  if (cfg < 0 || cfg > 5) { *bm = *bn = *bk = 0; return; }
   *bm = t[cfg][0]; *bn = t[cfg][1]; *bk = t[cfg][2];
 }
 

@@ -12,7 +12,8 @@ struct GettArgs {
   int64_t sa_m[QAMD_G], sc_m[QAMD_G];
   int64_t sb_n[QAMD_G], sc_n[QAMD_G];
   uint32_t B, M, N, K;
-  uint32_t Kpad;  // K rounded up to the k-tile
+  uint32_t Kpad;  // stride between the A and B halves of the k-offset table
+  uint32_t Kloop; // K rounded up to this kernel's k-tile
   uint32_t Kc;    // k range per split (multiple of the k-tile)
   uint32_t tiles_m, tiles_n, split_k;
   int32_t vec_a, vec_b, a_kcontig, b_kcontig;

@@ -1,0 +1,101 @@
+"""``TNLinearOperator`` -- a tensor network viewed as a linear operator, with the
+operator tensors resident on the device and one cached contraction expression per
+call signature.  Mirror of the reference class (quimb/tensor/tensor_core.py:12297-12549):
+``_matvec`` reshapes the vector to ``rdims``, runs the cached expression with the
+operator tensors as constants (``constants=range(n)``, :12378-12381) and ravels the
+result (:12393-12417); ``_matmat`` does the same with one extra column index
+(:12427-12443).  This is the hot loop of DMRG's local eigensolve
+(quimb/tensor/tn1d/dmrg.py:681-732, ARPACK calling ``A.matvec``).
+"""
+
+import numpy as np
+
+from .array import Array, asarray
+from .contract import array_contract_expression
+from .pairwise import prod
+
+
+class TNLinearOperator:
+    def __init__(self, tensors, left_inds, right_inds, ldims=None, rdims=None, optimize=None, dtype=None):
+        """``tensors``: sequence of (array, inds) -- or objects with ``.data`` / ``.inds``."""
+        arrs, inds = [], []
+        for t in tensors:
+            a, i = (t.data, t.inds) if hasattr(t, "inds") else t
+            arrs.append(a)
+            inds.append(tuple(i))
+        self.left_inds, self.right_inds = tuple(left_inds), tuple(right_inds)
+        size = {}
+        for a, i in zip(arrs, inds):
+            for ix, d in zip(i, np.shape(a) if not isinstance(a, Array) else a.shape):
+                size[ix] = int(d)
+        self.ldims = tuple(ldims) if ldims is not None else tuple(size[ix] for ix in self.left_inds)
+        self.rdims = tuple(rdims) if rdims is not None else tuple(size[ix] for ix in self.right_inds)
+        for ix, d in zip(self.right_inds, self.rdims):
+            size.setdefault(ix, d)
+        self.shape = (prod(self.ldims), prod(self.rdims))
+        if dtype is None:
+            dtype = np.result_type(*[a.dtype for a in arrs])
+        self.dtype = np.dtype(dtype)
+        self._arrays = [asarray(a).astype(self.dtype) for a in arrs]  # uploaded once
+        self._inds = inds
+        self._size = size
+        self._optimize = optimize
+        self._exprs = {}
+        self.is_conj = False
+
+    def _expr(self, ncols):
+        ex = self._exprs.get(ncols)
+        if ex is None:
+            n = len(self._arrays)
+            vin = self.right_inds + (("__col__",) if ncols else ())
+            out = self.left_inds + (("__col__",) if ncols else ())
+            size = dict(self._size)
+            if ncols:
+                size["__col__"] = ncols
+            ex = array_contract_expression(
+                list(self._inds) + [vin], out, size_dict=size, optimize=self._optimize, dtype=self.dtype,
+                constants={i: self._arrays[i] for i in range(n)}, cache=False,
+            )
+            self._exprs[ncols] = ex
+        return ex
+
+    def _apply(self, x, ncols):
+        host = not isinstance(x, Array)
+        xd = asarray(x).astype(self.dtype)
+        xd = xd.reshape(self.rdims + ((ncols,) if ncols else ()))
+        if self.is_conj:
+            xd = xd.conj()
+        out = self._expr(ncols)(xd)
+        if isinstance(out, np.ndarray):
+            out = asarray(out)
+        if self.is_conj:
+            out = out.conj()
+        out = out.reshape((self.shape[0], ncols) if ncols else (self.shape[0],))
+        return out.to_numpy() if host else out
+
+    def matvec(self, vec):
+        return self._apply(vec, 0)
+
+    _matvec = matvec
+
+    def matmat(self, mat):
+        ncols = mat.shape[-1]
+        return self._apply(mat, ncols)
+
+    _matmat = matmat
+
+    def __matmul__(self, x):
+        return self.matvec(x) if len(x.shape) == 1 else self.matmat(x)
+
+    dot = __matmul__
+
+    def conj(self):
+        import copy
+
+        new = copy.copy(self)
+        new.is_conj = not self.is_conj
+        return new
+
+    def to_dense(self):
+        eye = np.eye(self.shape[1], dtype=self.dtype)
+        return self.matmat(eye)

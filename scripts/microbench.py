@@ -55,11 +55,11 @@ def bench_pair(name, ai, ash, bi, bsh, oi, fixed=True, dtype="float32", cfgs=(-1
 quick = "--quick" in sys.argv
 print("== GETT fp32: square GEMMs (compute-bound)")
 for n in ([2048, 4096] if quick else [1024, 2048, 4096, 8192]):
-    bench_pair(f"gemm {n}^3 NN", "mk", (n, n), "kn", (n, n), "mn", cfgs=(0, 1))
+    bench_pair(f"gemm {n}^3 NN", "mk", (n, n), "kn", (n, n), "mn", cfgs=(0, 1, 5))
 bench_pair("gemm 4096^3 TN (A k-major)", "km", (4096, 4096), "kn", (4096, 4096), "mn", cfgs=(0,))
 bench_pair("gemm 4096^3 NT", "mk", (4096, 4096), "nk", (4096, 4096), "mn", cfgs=(0,))
 print("== GETT fp64")
-bench_pair("dgemm 4096^3 NN", "mk", (4096, 4096), "kn", (4096, 4096), "mn", dtype="float64", cfgs=(0, 1))
+bench_pair("dgemm 4096^3 NN", "mk", (4096, 4096), "kn", (4096, 4096), "mn", dtype="float64", cfgs=(0, 1, 5))
 print("== PEPS sweep steps, D=6 (HBM-bound): A[L,h,v,R] x S[h,x,v,y] -> C[L,y?,x?,R]")
 for (L, R) in [(6**4, 6**5), (6**8, 6), (6**9, 1), (1, 6**9), (6**2, 6**7)]:
     bench_pair(f"sweep L=6^{round(np.log(L)/np.log(6))} R=6^{round(np.log(R)/np.log(6))}", "lhvr", (L, 6, 6, R), "hxvy", (6, 6, 6, 6), "lxyr", fixed=False, cfgs=(-1, "T1"))
@@ -87,3 +87,14 @@ bench_perm("6^11 reverse", (6,) * 11, tuple(reversed(range(11))))
 bench_perm("6^11 swap last two", (6,) * 11, tuple(range(9)) + (10, 9))
 bench_perm("6^11 rotate", (6,) * 11, tuple(range(1, 11)) + (0,))
 bench_perm("[L,36,R] -> [L,R,36]", (6**4, 36, 6**5), (0, 2, 1))
+print("== DMRG2 effective-Hamiltonian matvec (BASELINE config #5): chi=512, MPO bond 5, d=2, fp64")
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import checks
+tensors, left, right = checks.dmrg_effective_ham(512, dtype="float64")
+A = qa.TNLinearOperator(tensors, left, right, optimize="random-greedy")
+x = rnd((512 * 2 * 2 * 512,), "float64")
+t = timeit(lambda: A.matvec(x), reps=10, warm=3)
+tree = A._expr(0).tree
+fl = tree.total_flops("float64")
+print(f"matvec {t*1e3:8.3f} ms   {fl/t/1e12:6.2f} TF fp64   tree flops {fl:.3e} (survey: 1.095e10)   steps: "
+      + ", ".join(f"({i.M}x{i.N}x{i.K})" for i in A._expr(0).executor.info), flush=True)

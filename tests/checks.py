@@ -446,3 +446,92 @@ def check_golden(contract, tensor_contract=None, fuse=None, transpose=None, geti
         np.testing.assert_array_equal(np.asarray(fuse(t, (1, 2))), L["f2"])
         np.testing.assert_array_equal(np.asarray(transpose(t, (4, 2, 0, 3, 1))), L["tr"])
         np.testing.assert_array_equal(np.asarray(getitem(t, (1, slice(None), 2))), L["sl"])
+
+
+def random_circuit_network(n, depth, rng, dtype="complex64"):
+    """Brickwork random circuit as a tensor network for one amplitude <b|U|0..0>
+    (cf. quimb Circuit.amplitude, quimb/tensor/circuit/exact.py:417-501): |0> vectors,
+    random single-qubit unitaries, CZ-like two-qubit gates, <b| projectors.  Returns
+    (arrays, inputs, exact_amplitude) with the amplitude from a dense state-vector
+    simulation."""
+    def runitary(k):
+        q, r = np.linalg.qr(rng.normal(size=(k, k)) + 1j * rng.normal(size=(k, k)))
+        return q * (np.diag(r) / np.abs(np.diag(r)))
+
+    arrays, inputs = [], []
+    cur = [f"q{i}_0" for i in range(n)]
+    cnt = [0] * n
+    psi = np.zeros((2,) * n, dtype=np.complex128)
+    psi[(0,) * n] = 1.0
+    for i in range(n):
+        arrays.append(np.array([1.0, 0.0]))
+        inputs.append((cur[i],))
+    for d in range(depth):
+        for i in range(n):
+            U = runitary(2)
+            cnt[i] += 1
+            new = f"q{i}_{cnt[i]}"
+            arrays.append(U)
+            inputs.append((new, cur[i]))
+            cur[i] = new
+            psi = np.moveaxis(np.tensordot(U, psi, axes=([1], [i])), 0, i)
+        for i in range(d % 2, n - 1, 2):
+            G = runitary(4).reshape(2, 2, 2, 2)
+            cnt[i] += 1
+            cnt[i + 1] += 1
+            n1, n2 = f"q{i}_{cnt[i]}", f"q{i+1}_{cnt[i+1]}"
+            arrays.append(G)
+            inputs.append((n1, n2, cur[i], cur[i + 1]))
+            psi = np.moveaxis(np.tensordot(G, psi, axes=([2, 3], [i, i + 1])), [0, 1], [i, i + 1])
+            cur[i], cur[i + 1] = n1, n2
+    bits = rng.integers(0, 2, size=n)
+    for i in range(n):
+        v = np.zeros(2)
+        v[bits[i]] = 1.0
+        arrays.append(v)
+        inputs.append((cur[i],))
+    amp = psi[tuple(bits)]
+    return [a.astype(dtype) for a in arrays], inputs, amp
+
+
+def check_circuit_amplitude(dtype, n=10, depth=6, seed=17):
+    """BASELINE config #2 in miniature: a circuit amplitude, complex dtype, O(100) small
+    tensors, greedy path -- dispatch-bound, exercises the complex GETT path."""
+    rng = np.random.default_rng(seed)
+    arrays, inputs, amp = random_circuit_network(n, depth, rng, dtype)
+    got = qa.array_contract(arrays, inputs, (), optimize="greedy")
+    tol = 2e-4 if np.dtype(dtype) == np.dtype("complex64") else 1e-10
+    assert abs(np.asarray(got).item() - amp) <= tol * max(abs(amp), 2.0 ** (-n / 2))
+    ts = [qa.Tensor(a, t) for a, t in zip(arrays, inputs)]
+    z = qa.tensor_contract(*ts, optimize="random-greedy")
+    assert abs(z - amp) <= tol * max(abs(amp), 2.0 ** (-n / 2))
+
+
+def dmrg_effective_ham(chi, d=2, w=5, seed=23, dtype="float64"):
+    """The 2-site DMRG effective Hamiltonian network of BASELINE config #5 (reference
+    quimb/tensor/tn1d/dmrg.py:681-732): L[a,p,a'] W1[p,q,s1,s1'] W2[q,r,s2,s2'] R[b,r,b']."""
+    rng = np.random.default_rng(seed)
+    L = rand(rng, (chi, w, chi), dtype)
+    R = rand(rng, (chi, w, chi), dtype)
+    W1 = rand(rng, (w, w, d, d), dtype)
+    W2 = rand(rng, (w, w, d, d), dtype)
+    tensors = [(L, ("a", "p", "A")), (W1, ("p", "q", "s1", "S1")), (W2, ("q", "r", "s2", "S2")), (R, ("b", "r", "B"))]
+    return tensors, ("a", "s1", "s2", "b"), ("A", "S1", "S2", "B")
+
+
+def check_linop(dtype, chi=12):
+    """TNLinearOperator vs its dense matrix (reference tests/test_tensor/test_tensor_core.py:2181-2215)."""
+    tensors, left, right = dmrg_effective_ham(chi, dtype=dtype)
+    A = qa.TNLinearOperator(tensors, left, right)
+    n = chi * 2 * 2 * chi
+    assert A.shape == (n, n)
+    dense = np.einsum("apA,pqsS,qrtT,brB->astbASTB", *[t[0].astype(np.float64) for t in tensors]).reshape(n, n)
+    rng = np.random.default_rng(1)
+    x = rand(rng, (n,), dtype)
+    assert_close(A.matvec(x), dense @ x, dtype)
+    X = rand(rng, (n, 3), dtype)
+    assert_close(A.matmat(X), dense @ X, dtype)
+    xd = qa.asarray(x)
+    y = A @ xd
+    assert isinstance(y, qa.Array)
+    assert_close(y.to_numpy(), dense @ x, dtype)

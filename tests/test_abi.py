@@ -47,7 +47,7 @@ def test_load_and_plan_finalize():
     assert p.vec_a == 4 and p.a_kcontig == 0 and p.c_ncontig == 1
     # big x small, A's stride-1 index in M, C = [.., m, y] -> streaming kernel with transposed stores
     assert p.kernel == 2 and p.vec_c == 4
-    assert lib.qamd_pair_ktab_len(C.byref(p)) == 2 * 48
+    assert lib.qamd_pair_ktab_len(C.byref(p)) == 2 * 64  # K = 36 padded to the largest k-tile (32)
     assert lib.qamd_pair_workspace_bytes(C.byref(p)) == 0
     # caller can force the tiled kernel
     p.kernel = -1

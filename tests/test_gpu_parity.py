@@ -96,6 +96,17 @@ def test_fused_pairs(hip, Lx, Ly, D, dtype):
     assert ex0(arrays).to_numpy().item() == pytest.approx(want, rel=rel)
 
 
+@pytest.mark.parametrize("dtype", ["complex64", "complex128"])
+def test_circuit_amplitude(hip, dtype):
+    checks.check_circuit_amplitude(dtype, n=12, depth=8)
+
+
+@pytest.mark.parametrize("dtype,chi", [("float64", 48), ("float32", 32)])
+def test_linop_dmrg_effective_hamiltonian(hip, dtype, chi):
+    """BASELINE config #5's hot loop (effective-Hamiltonian matvec) at reduced bond dimension."""
+    checks.check_linop(dtype, chi=chi)
+
+
 def test_hyper_network(hip):
     checks.check_hyper_network("float64")
     checks.check_hyper_network("float32")

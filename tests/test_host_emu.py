@@ -123,3 +123,11 @@ def test_chain2_chunk_table_matches_library():
     for D in range(1, 10):
         assert lib.qamd_chain2_chunk(0, D) == chain2_chunk("float32", D)
         assert lib.qamd_chain2_chunk(1, D) == chain2_chunk("float64", D)
+
+
+def test_circuit_amplitude(emu):
+    checks.check_circuit_amplitude("complex128", n=8, depth=4)
+
+
+def test_linop(emu):
+    checks.check_linop("float64")
