@@ -278,6 +278,13 @@ class TreeExecutor:
             dev.slots_log10_sum(slots, self.dtype, exponent)
         return out
 
+    def graph(self, arrays, strip_exponent=False):
+        """Capture one whole (unsliced) contraction into a HIP graph and return a
+        ``GraphedContraction``: ``g.replay()`` re-launches the recorded kernel sequence
+        with one host call (dispatch-bound networks: circuits, DMRG matvecs).  The inputs
+        are static device buffers -- refresh them in place with ``g.update(i, array)``."""
+        return GraphedContraction(self, arrays, strip_exponent)
+
     def __call__(self, arrays, strip_exponent=False, slices=None, hoist=True):
         """Contract.  ``slices``: iterable of slice numbers to evaluate (default
         all); the partial sum over exactly those slices is returned, which is what
@@ -330,3 +337,47 @@ class TreeExecutor:
             acc = Array.full([tree.size_dict[ix] for ix in tree.output], 0.0, self.dtype, dev)
             acc_e = float("-inf") if strip_exponent else None
         return (acc, acc_e) if strip_exponent else acc
+
+
+class GraphedContraction:
+    """A contraction recorded as a hipGraph (via torch's stream capture -- plumbing; every
+    node is one of this library's HIP kernels)."""
+
+    def __init__(self, executor, arrays, strip_exponent=False):
+        if executor.tree.nslices != 1:
+            raise ValueError("graph capture supports unsliced trees")
+        self.executor = executor
+        self.strip_exponent = strip_exponent
+        self.inputs = [asarray(x).astype(executor.dtype).copy() for x in arrays]
+        dev = self.inputs[0]._dev
+        if not hasattr(dev, "torch"):
+            raise RuntimeError("graph capture needs the HIP device")
+        torch = dev.torch
+        self._dev = dev
+        # warm-up on a side stream: compiles every plan / table before capture
+        s = torch.cuda.Stream(device=dev.tdev)
+        s.wait_stream(torch.cuda.current_stream(dev.tdev))
+        with torch.cuda.stream(s):
+            for _ in range(2):
+                executor._run_core(self.inputs, dev.new_exponent() if strip_exponent else None, None)
+        torch.cuda.current_stream(dev.tdev).wait_stream(s)
+        torch.cuda.synchronize(dev.tdev)
+        self._graph = torch.cuda.CUDAGraph()
+        self._exponent = dev.new_exponent() if strip_exponent else None
+        with torch.cuda.graph(self._graph):
+            if strip_exponent:
+                self._exponent.zero_()
+            self.output = executor._run_core(self.inputs, self._exponent, None)
+
+    def update(self, i, array):
+        """Overwrite static input ``i`` in place (device-to-device or host-to-device copy)."""
+        src = asarray(array).astype(self.executor.dtype)
+        if src.shape != self.inputs[i].shape:
+            raise ValueError("shape mismatch")
+        self.inputs[i]._buf[: src.size].copy_(src._buf[: src.size])
+
+    def replay(self):
+        self._graph.replay()
+        if self.strip_exponent:
+            return self.output, self._dev.read_exponent(self._exponent)
+        return self.output

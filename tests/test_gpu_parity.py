@@ -107,6 +107,27 @@ def test_linop_dmrg_effective_hamiltonian(hip, dtype, chi):
     checks.check_linop(dtype, chi=chi)
 
 
+def test_hipgraph_replay(hip):
+    """A whole contraction captured as a hipGraph replays to the same result, and static
+    inputs can be refreshed in place."""
+    import quimb_amd as qa
+
+    rng = np.random.default_rng(4)
+    arrays, inputs, output = checks.rand_reg_network(10, 3, 3, rng, "float32", 1)
+    want = qa.array_contract(arrays, inputs, output)
+    tree = qa.array_contract_tree(inputs, output, shapes=[a.shape for a in arrays])
+    ex = qa.TreeExecutor(tree, "float32")
+    g = ex.graph(arrays)
+    checks.assert_close(g.replay().to_numpy(), want, "float32")
+    checks.assert_close(g.replay().to_numpy(), want, "float32")
+    arrays2 = [a.copy() for a in arrays]
+    arrays2[3] = arrays2[3] * 2.0
+    g.update(3, arrays2[3])
+    checks.assert_close(g.replay().to_numpy(), 2.0 * want, "float32")
+    m, e = ex.graph(arrays, strip_exponent=True).replay()
+    checks.assert_close(m.to_numpy() * 10.0**e, want, "float32")
+
+
 def test_hyper_network(hip):
     checks.check_hyper_network("float64")
     checks.check_hyper_network("float32")
