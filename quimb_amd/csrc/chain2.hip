@@ -179,7 +179,11 @@ __global__ __launch_bounds__(256, (V == 1 ? 2 : 1)) void chain2_kernel(const Cha
   T areg[D][KS1][V];
   T vmax = T(0);
 
+#ifdef QAMD_CHAIN2_ABLATION   // debugging builds only: runtime ablation bits cost scalar branches
   const uint32_t abl = p.ablate;
+#else
+  constexpr uint32_t abl = 0;
+#endif
   auto issue = [&]() {
     if (abl & 4) return;
     // wave-uniform base per v (SGPR pair) + the 32-bit per-lane row offset: KS1 address

@@ -82,7 +82,11 @@ __device__ __forceinline__ void gload16(VT& dst, uint32_t voff, uint64_t sbase) 
   asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(voff), "s"(sbase) : "memory");
 #else
   typedef const __attribute__((address_space(1))) char* gptr_t;   // global (not flat) address space
+#ifndef QAMD_SWEEP_NO_NT  // streamed once: non-temporal (+3-4% measured)
+  dst = __builtin_nontemporal_load(reinterpret_cast<const __attribute__((address_space(1))) VT*>(reinterpret_cast<gptr_t>(sbase) + voff));
+#else
   dst = *reinterpret_cast<const __attribute__((address_space(1))) VT*>(reinterpret_cast<gptr_t>(sbase) + voff);
+#endif
 #endif
 }
 // wait until at most N vector-memory operations are outstanding, and tie the
@@ -245,7 +249,11 @@ __global__ __launch_bounds__(256, QAMD_SWEEP_WAVES) void sweep_kernel(const Stre
             T a = o[e] < T(0) ? -o[e] : o[e];
             vmax = a > vmax ? a : vmax;
           }
+#ifndef QAMD_SWEEP_NO_NT  // streamed once: non-temporal (+3-4% measured)
+          __builtin_nontemporal_store(o, reinterpret_cast<vec_t*>(C + cbase + offCn[no * p.d_in] + (int64_t)wv * V));
+#else
           *reinterpret_cast<vec_t*>(C + cbase + offCn[no * p.d_in] + (int64_t)wv * V) = o;
+#endif
         }
       }
       __builtin_amdgcn_wave_barrier();
