@@ -24,6 +24,7 @@ from .contract import (  # noqa: F401
 )
 from .executor import TreeExecutor
 from .linop import TNLinearOperator
+from .network import TensorNetwork
 from .pathfind import find_path, find_slices, greedy_path, random_greedy, sweep_path_2d
 from .tree import ContractionTree
 from .device import HipDevice, default_device

@@ -57,8 +57,9 @@ class Array:
         dev = dev or _device.default_device()
         x = np.asarray(x)
         dt = _coerce_dtype(dtype if dtype is not None else x.dtype)
+        shape = x.shape  # (ascontiguousarray would promote 0-d to 1-d)
         x = np.ascontiguousarray(x, dtype=dt)
-        return cls(dev, dev.from_host(x), x.shape, dt)
+        return cls(dev, dev.from_host(x), shape, dt)
 
     @classmethod
     def empty(cls, shape, dtype, dev=None):

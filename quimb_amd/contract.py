@@ -247,6 +247,11 @@ class Tensor:
     def __matmul__(self, other):
         return tensor_contract(self, other)
 
+    def __and__(self, other):
+        from .network import TensorNetwork
+
+        return TensorNetwork((self,)) & other
+
     def __repr__(self):
         return f"Tensor(shape={self.shape}, inds={self.inds}, tags={self.tags})"
 

@@ -535,3 +535,54 @@ def check_linop(dtype, chi=12):
     y = A @ xd
     assert isinstance(y, qa.Array)
     assert_close(y.to_numpy(), dense @ x, dtype)
+
+
+def check_tensor_network_semantics():
+    """Restatement of the reference's TensorNetwork contraction tests
+    (tests/test_tensor/test_tensor_core.py:1128-1169, :318-330)."""
+    rng = np.random.default_rng(31)
+    T, TN = qa.Tensor, qa.TensorNetwork
+    a = T(rng.normal(size=(2, 3, 4)), inds=[0, 1, 2], tags="red")
+    b = T(rng.normal(size=(3, 4, 5)), inds=[1, 2, 3], tags="blue")
+    c = T(rng.normal(size=(5, 2, 6)), inds=[3, 0, 4], tags="blue")
+    a_b_c = a & b & c
+    assert isinstance(a_b_c, TN) and len(a_b_c.tensors) == 3
+    a_bc = a_b_c ^ "blue"
+    assert isinstance(a_bc, TN) and len(a_bc.tensors) == 2
+    abc = a_bc ^ ["red", "blue"]
+    assert isinstance(abc, T)
+    full = a_b_c.contract()
+    assert_close(np.asarray(abc.data), np.asarray(full.data), "float64")
+    assert_close(np.asarray(full.data), np.einsum("abc,bcd,dae->e", a.data, b.data, c.data), "float64")
+    assert len(a_b_c.tensors) == 3
+    a_b_c ^= "blue"
+    assert len(a_b_c.tensors) == 2
+
+    c2 = T(c.data, inds=[3, 0, 4], tags="green")
+    d = a & b & c2
+    cd = d >> ["red", "green", "blue"]
+    assert isinstance(cd, T) and cd.shape == (6,) and cd.inds == (4,)
+    assert len(d.tensors) == 3  # not inplace
+    d >>= ["red", "green", "blue"]
+    assert isinstance(d, TN)
+
+    # isel (reference :318-323)
+    t5 = rng.normal(size=(2, 3, 4, 5, 6))
+    tn = TN([T(t5, inds=["a", "b", "c", "d", "e"])])
+    sel = tn.isel({"d": 2, "b": 0}).tensors[0]
+    assert sel.shape == (2, 4, 6) and sel.inds == ("a", "c", "e")
+    assert_close(np.asarray(sel.data), t5[:, 0, :, 2, :], "float64")
+
+    # cut_iter: the slices sum to the whole (reference :325-330), on device-resident data too
+    arrays, inputs = orc.tn2d_rand(3, 3, 3, seed=2, dtype="float64")
+    tn = TN([T(x, t) for x, t in zip(arrays, inputs)])
+    whole = tn ^ all
+    cut = tn.inner_inds()[:2]
+    assert sum(s ^ all for s in tn.cut_iter(*cut)) == pytest.approx(whole, rel=1e-10)
+    tnd = tn.copy().to_device()
+    assert tnd ^ all == pytest.approx(whole, rel=1e-10)
+    # exponent is re-inserted (tensor_core.py:330-340)
+    tne = TN(tn.tensors, exponent=2.0)
+    assert tne ^ all == pytest.approx(whole * 100.0, rel=1e-10)
+    m, e = tne.contract(all, strip_exponent=True)
+    assert m * 10**e == pytest.approx(whole * 100.0, rel=1e-10)

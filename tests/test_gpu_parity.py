@@ -128,6 +128,10 @@ def test_hipgraph_replay(hip):
     checks.assert_close(m.to_numpy() * 10.0**e, want, "float32")
 
 
+def test_tensor_network_semantics(hip):
+    checks.check_tensor_network_semantics()
+
+
 def test_hyper_network(hip):
     checks.check_hyper_network("float64")
     checks.check_hyper_network("float32")

@@ -131,3 +131,7 @@ def test_circuit_amplitude(emu):
 
 def test_linop(emu):
     checks.check_linop("float64")
+
+
+def test_tensor_network_semantics(emu):
+    checks.check_tensor_network_semantics()
