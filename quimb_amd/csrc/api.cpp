@@ -251,13 +251,15 @@ static bool sweep_config(const qamd_pair_plan* p, const StreamArgs& s, int V, in
   for (int i = 0; i < 6; ++i) if (kPS[i] >= (int)s.KS) { PS = kPS[i]; break; }
   // chunks per workgroup: a divisor of the innermost group's chunk count, near the target
   const uint32_t ic = s.inner_chunks;
-  const uint32_t target = std::max<uint32_t>(8, (s.chunks + 256 * 6 - 1) / (256 * 6));
+  // aim at ~12 workgroups per CU so that the dispatcher can balance the chip (a grid of
+  // only 1-2 workgroups per CU leaves SIMDs with a single wave and CUs with uneven work)
+  const uint32_t target = std::max<uint32_t>(8, (s.chunks + 256 * 12 - 1) / (256 * 12));
   uint32_t best = 0;
   for (uint32_t dlo = 1; (uint64_t)dlo * dlo <= ic; ++dlo) {
     if (ic % dlo) continue;
     uint32_t cand[2] = {dlo, ic / dlo};
     for (uint32_t c : cand)
-      if (c <= 4 * target && c > best) best = c;
+      if (c <= target && c > best) best = c;
   }
   cpb = best;
   return best >= 4;
@@ -578,13 +580,13 @@ extern "C" int qamd_contract_chain2(const qamd_chain2_plan* p, const void* A, co
   a.sa_v = p->sa_v;
   a.chunks = (uint32_t)(M / ch);
   const uint32_t ic = (uint32_t)(inner / ch);
-  const uint32_t target = std::max<uint32_t>(4, (a.chunks + 256 * 4 - 1) / (256 * 4));
+  const uint32_t target = std::max<uint32_t>(4, (a.chunks + 256 * 12 - 1) / (256 * 12));
   uint32_t best = 0;
   for (uint32_t dlo = 1; (uint64_t)dlo * dlo <= ic; ++dlo) {
     if (ic % dlo) continue;
     uint32_t cand[2] = {dlo, ic / dlo};
     for (uint32_t c : cand)
-      if (c <= 4 * target && c > best) best = c;
+      if (c <= target && c > best) best = c;
   }
   if (best < 1) return QAMD_EUNSUPPORTED;
   a.chunks_per_block = best;

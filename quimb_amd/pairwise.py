@@ -360,7 +360,11 @@ def parse_einsum(eq, nops):
 def chain2_chunk(dtype_name, D):
     """m-chunk of the fused pair kernel; mirrors ``qamd_chain2_chunk`` (0 = unsupported)."""
     if dtype_name == "float32":
-        return 32 if 2 <= D <= 6 else (16 if D == 7 else 0)
+        import os
+
+        if os.environ.get("QAMD_CHAIN2_V2", "")[:1] == "1":
+            return 32 if 2 <= D <= 6 else (16 if D == 7 else 0)
+        return 16 if 2 <= D <= 7 else 0
     if dtype_name == "float64":
         return 16 if 2 <= D <= 6 else 0
     return 0

@@ -88,11 +88,11 @@ def test_fused_pairs(hip, Lx, Ly, D, dtype):
     rel = 5e-6 if dtype == "float32" else 1e-11
     assert m.to_numpy().item() * 10.0**e == pytest.approx(want, rel=rel)
     assert ex(arrays).to_numpy().item() == pytest.approx(want, rel=rel)
-    os.environ["QAMD_NO_CHAIN2"] = "1"
+    os.environ["QAMD_CHAIN2"] = "0"
     try:
         ex0 = qa.TreeExecutor(tree, dtype)
     finally:
-        del os.environ["QAMD_NO_CHAIN2"]
+        del os.environ["QAMD_CHAIN2"]
     assert ex0(arrays).to_numpy().item() == pytest.approx(want, rel=rel)
 
 

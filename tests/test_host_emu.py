@@ -106,11 +106,11 @@ def test_fused_pairs_in_sweeps(emu, Lx, Ly, D, dtype):
     assert emu.calls.get("chain2", 0) == nfused
     m, e = ex(arrays, strip_exponent=True)
     checks.assert_close(m.to_numpy() * 10.0**e, want, dtype)
-    os.environ["QAMD_NO_CHAIN2"] = "1"
+    os.environ["QAMD_CHAIN2"] = "0"
     try:
         ex0 = qa.TreeExecutor(tree, dtype)
     finally:
-        del os.environ["QAMD_NO_CHAIN2"]
+        del os.environ["QAMD_CHAIN2"]
     assert not any(e[0] == "chain2" for e in ex0.plan)
     checks.assert_close(ex0(arrays).to_numpy(), want, dtype)
 
