@@ -141,13 +141,18 @@ int qamd_contract_pair_ex(const qamd_pair_plan* plan, const void* A, const void*
  * stride D*D and is followed by the contiguous block [x][n2_in]; n2_out at element
  * offset offCo_dev[n2_out].  scale_* / absmax_out: slots as described for the epilogue struct above; any may be NULL.
  */
+#define QAMD_CHAIN2_C_ALIGNED16 1
 typedef struct {
-  int32_t dtype, D, nm, reserved;
+  int32_t dtype, D, nm;
+  int32_t flags;   /* QAMD_CHAIN2_C_ALIGNED16: every offCo_dev entry and every sc_m of the outer m groups is a multiple of 4
+                      elements (with a 16-byte aligned C this lets fp32 use the register-resident kernel) */
   int64_t dim_m[QAMD_MAX_GROUPS], sa_m[QAMD_MAX_GROUPS], sc_m[QAMD_MAX_GROUPS];
   int64_t sa_v;
 } qamd_chain2_plan;
 /* m-chunk the fused kernel works in for (dtype, D); 0 = combination not supported */
 int qamd_chain2_chunk(int32_t dtype, int32_t D);
+/* kernel instantiation the fused pair would run (matches rocprofv3's kernel names) */
+int qamd_chain2_describe(const qamd_chain2_plan* plan, char* buf, int32_t buflen);
 int qamd_contract_chain2(const qamd_chain2_plan* plan, const void* A, const void* W1p, const void* W2p, void* C,
                          const void* offK1_dev, const void* offCo_dev, const void* scale_a, const void* scale_1,
                          const void* scale_2, void* absmax_out, void* stream);

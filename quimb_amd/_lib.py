@@ -45,7 +45,7 @@ class Chain2PlanStruct(C.Structure):
     """Mirror of ``qamd_chain2_plan``."""
 
     _fields_ = [
-        ("dtype", C.c_int32), ("D", C.c_int32), ("nm", C.c_int32), ("reserved", C.c_int32),
+        ("dtype", C.c_int32), ("D", C.c_int32), ("nm", C.c_int32), ("flags", C.c_int32),
         ("dim_m", _I64G), ("sa_m", _I64G), ("sc_m", _I64G),
         ("sa_v", C.c_int64),
     ]
@@ -74,6 +74,7 @@ SYMBOLS = [
     ("qamd_pair_describe", C.c_int, [_pplan, C.c_char_p, _i32]),
     ("qamd_contract_pair_ex", C.c_int, [_pplan, _vp, _vp, _vp, _vp, _vp, _i64, C.POINTER(Epilogue), _vp]),
     ("qamd_chain2_chunk", C.c_int, [_i32, _i32]),
+    ("qamd_chain2_describe", C.c_int, [C.POINTER(Chain2PlanStruct), C.c_char_p, _i32]),
     ("qamd_contract_chain2", C.c_int, [C.POINTER(Chain2PlanStruct), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     ("qamd_absmax_log10_sum", C.c_int, [_vp, _i64, _i32, _vp, _vp]),
     ("qamd_div_by_absmax", C.c_int, [_vp, _i64, _vp, _i32, _vp]),

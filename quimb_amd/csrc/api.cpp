@@ -557,6 +557,26 @@ extern "C" int qamd_pair_describe(const qamd_pair_plan* p, char* buf, int32_t bu
 // ---------------------------------------------------------------------------
 // fused pair of streaming contractions
 // ---------------------------------------------------------------------------
+// the register-resident variant (chain2r.hip) serves fp32 D <= 6 at the 16-m chunk;
+// QAMD_CHAIN2R=0 keeps the LDS-tile kernel (chain2.hip)
+static bool chain2_uses_registers(const qamd_chain2_plan* p, const void* C) {
+  const char* e = getenv("QAMD_CHAIN2R");
+  if (e && e[0] == '0') return false;
+  if (!(p->flags & QAMD_CHAIN2_C_ALIGNED16) || ((uintptr_t)C & 15)) return false;   // 16-byte stores
+  return qamd_chain2r_supported(p->dtype, p->D) && qamd_chain2_chunk(p->dtype, p->D) == 16;
+}
+
+extern "C" int qamd_chain2_describe(const qamd_chain2_plan* p, char* buf, int32_t buflen) {
+  if (!p || !buf || buflen <= 0) return QAMD_EINVAL;
+  const int ch = qamd_chain2_chunk(p->dtype, p->D);
+  if (!ch) return QAMD_EUNSUPPORTED;
+  if (chain2_uses_registers(p, nullptr))
+    snprintf(buf, buflen, "chain2r_kernel<%d>", p->D);
+  else
+    snprintf(buf, buflen, "chain2_kernel<%s, %d, %d>", p->dtype == QAMD_F32 ? "float" : "double", p->D, ch / 16);
+  return QAMD_OK;
+}
+
 extern "C" int qamd_contract_chain2(const qamd_chain2_plan* p, const void* A, const void* W1p, const void* W2p,
                                     void* C, const void* offK1_dev, const void* offCo_dev, const void* scale_a,
                                     const void* scale_1, const void* scale_2, void* absmax_out, void* stream) {
@@ -592,6 +612,9 @@ extern "C" int qamd_contract_chain2(const qamd_chain2_plan* p, const void* A, co
   a.chunks_per_block = best;
   a.grid = a.chunks / best;
   if (const char* e = getenv("QAMD_CHAIN2_ABLATE")) a.ablate = (uint32_t)atoi(e);
+  if (chain2_uses_registers(p, C))
+    return qamd_chain2r_launch(p->D, &a, A, W1p, W2p, C, offK1_dev, offCo_dev, scale_a, scale_1, scale_2, absmax_out,
+                               stream);
   return qamd_chain2_launch(p->dtype, p->D, &a, A, W1p, W2p, C, offK1_dev, offCo_dev, scale_a, scale_1, scale_2,
                             absmax_out, stream);
 }

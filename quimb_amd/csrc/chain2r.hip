@@ -1,0 +1,334 @@
+// chain2r.hip -- the fused pair of site absorptions (see chain2.hip for the maths) with the
+// intermediate kept in REGISTERS (gfx950 only, fp32, D <= 6).
+//
+//   X[x, y, v, m] = sum_k1      A[k1, v, m] * W1[k1, (x, y)]
+//   C[x, n2,  m]  = sum_{y, v}  X[x, y, v, m] * W2[(y, v), n2]          n2 = (no, ni)
+//
+// chain2_kernel moves X through a wave-private LDS tile (scatter, re-read, in-place
+// rewrite, transposing copy-out: ~225 LDS instructions and ~700 address VALU ops per
+// 16-m chunk, MFMA pipe 48% busy).  Here the stage-1 accumulators ARE the stage-2 B
+// operands, which works because both the order of W1's columns and the order of the
+// stage-2 contraction index are free:
+//
+//  * v_mfma_f32_16x16x4: lane (j, q) [j = lane & 15, q = lane >> 4] of the D registers
+//    holds rows 4q + r of column j; as a B operand the same lane supplies k = q of
+//    column j.  So register r of a stage-1 tile can be fed straight back as one k-step
+//    of stage 2, provided its four lane groups q hold k values of ONE output x.
+//  * W1's columns are therefore ordered in "slots": slot = 4*tile + r belongs to one x
+//    (slot / SX, SX = ceil(D/4) slots per x) and lane group q holds y = 4*(slot % SX) + q
+//    (a zero column when y >= D).  W2's rows are read in the matching order
+//    (y = 4*sg + q, v), and W2's columns are ordered the same way for the output
+//    (register R <-> no = R / SX, lane group q <-> ni = 4*(R % SX) + q), which makes the
+//    64 lanes of every result write hit 64 different LDS banks at D = 6.
+//  * the only LDS traffic left is the result tile Ot[no][m][x][ni] -- exactly the order
+//    of C in HBM -- written once (ds_write_b32, immediate offsets) and copied out with
+//    ds_read_b128 + 16-byte stores whose addresses are SGPR base + lane*16 + immediate.
+//
+// Cost: slots of the last sub-block of y carry zeros (D = 6: 12 k-steps per x instead
+// of 9), i.e. 378 instead of 324 MFMAs per chunk, in exchange for ~3x fewer LDS
+// instructions and almost no address arithmetic.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include "gett_args.h"
+
+#define QAMD_LAUNCH(...) do { (void)hipGetLastError(); hipLaunchKernelGGL(__VA_ARGS__); } while (0)
+
+namespace qamd {
+
+typedef __attribute__((ext_vector_type(4))) float r_acc_t;
+typedef float r_vec4 __attribute__((ext_vector_type(4), aligned(16)));
+typedef const __attribute__((address_space(1))) char* r_gptr_t;
+
+__device__ __forceinline__ float rload(uint64_t sbase, uint32_t voff) {
+  return __builtin_nontemporal_load(
+      reinterpret_cast<const __attribute__((address_space(1))) float*>(reinterpret_cast<r_gptr_t>(sbase) + voff));
+}
+
+__device__ __forceinline__ float rread_scale(const float* slots) {
+  if (!slots) return 1.f;
+  float m = 0.f;
+  for (int i = 0; i < QAMD_SLOTS; ++i) {
+    float v = slots[i];
+    m = v > m ? v : m;
+  }
+  return m > 0.f ? m : 1.f;
+}
+
+__device__ __forceinline__ void rdecomp2(uint32_t idx, int n, const uint32_t* dims, const int64_t* s1,
+                                         const int64_t* s2, int64_t* o) {
+  int64_t o1 = 0, o2 = 0;
+  for (int g = n - 1; g >= 0; --g) {
+    uint32_t d = dims[g];
+    uint32_t q = idx / d, r = idx - q * d;
+    o1 += (int64_t)r * s1[g];
+    o2 += (int64_t)r * s2[g];
+    idx = q;
+  }
+  o[0] = o1;
+  o[1] = o2;
+}
+
+template <int D>
+__global__ __launch_bounds__(256, 2) void chain2r_kernel(const Chain2Args p, const float* __restrict__ A,
+                                                         const float* __restrict__ W1p,
+                                                         const float* __restrict__ W2p, float* __restrict__ C,
+                                                         const int64_t* __restrict__ offK1,
+                                                         const int64_t* __restrict__ offCo,
+                                                         const float* __restrict__ scale_a,
+                                                         const float* __restrict__ scale_1,
+                                                         const float* __restrict__ scale_2,
+                                                         float* __restrict__ absmax_out) {
+  constexpr int N = D * D, K1 = D * D, KS1 = (K1 + 3) / 4;
+  constexpr int SX = (D + 3) / 4;        // slots (registers) per x / per no
+  constexpr int NSLOT = D * SX;          // used rows of the permuted W1 / W2 column order, in units of 4 lane groups
+  constexpr int NT = (NSLOT + 3) / 4;    // 16-row MFMA tiles
+  constexpr int XPT = 4 / SX;            // x values per tile
+  constexpr int CH = 16;                 // m values per chunk (one per lane j)
+  constexpr int RUN = CH * N;            // contiguous C elements per (no, chunk):  [m][x][ni]
+  constexpr int TILE = D * RUN;          // result tile of one wave
+  constexpr uint32_t CSTRIDE = 4;        // the 4 waves of a workgroup interleave chunks
+  static_assert(D >= 2 && D <= 8 && (4 % SX) == 0, "slot scheme needs ceil(D/4) in {1, 2}");
+
+  extern __shared__ __attribute__((aligned(16))) float r_smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane & 15, kq = lane >> 4;
+
+  // ---- W fragments, straight from global into registers (they stay for the whole kernel) ----
+  float wf1[KS1][NT];
+#pragma unroll
+  for (int s = 0; s < KS1; ++s)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int g = j >> 2, r = j & 3;
+      const int slot = 4 * nt + r, x = slot / SX, y = 4 * (slot % SX) + g, k1 = 4 * s + kq;
+      const bool ok = slot < NSLOT && y < D && k1 < K1;
+      const float w = W1p[ok ? k1 * N + x * D + y : 0];
+      wf1[s][nt] = ok ? w : 0.f;
+    }
+  float wf2[SX][D][NT];
+#pragma unroll
+  for (int sg = 0; sg < SX; ++sg)
+#pragma unroll
+    for (int v = 0; v < D; ++v)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const int g = j >> 2, r = j & 3;
+        const int R = 4 * nt + r, no = R / SX, ni = 4 * (R % SX) + g, y = 4 * sg + kq;
+        const bool ok = R < NSLOT && ni < D && y < D;
+        const float w = W2p[ok ? (y * D + v) * N + no * D + ni : 0];
+        wf2[sg][v][nt] = ok ? w : 0.f;
+      }
+  const float alpha = 1.f / (rread_scale(scale_a) * rread_scale(scale_1) * rread_scale(scale_2));
+
+  const uint32_t blk_first = blockIdx.x * p.chunks_per_block;
+  uint32_t c_end = blk_first + p.chunks_per_block;
+  if (c_end > p.chunks) c_end = p.chunks;
+  const uint32_t c_begin = blk_first + wave;
+  if (c_begin >= c_end) return;
+  const uint32_t my_chunks = (c_end - c_begin + CSTRIDE - 1) / CSTRIDE;
+
+  int64_t o2[2];
+  rdecomp2(c_begin * CH, p.nm, p.dim_m, p.sa_m, p.sc_m, o2);
+  uint64_t sbase;
+  {
+    uint64_t b = (uint64_t)(A + o2[0]);
+    uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)b);
+    uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(b >> 32));
+    sbase = ((uint64_t)hi << 32) | lo;
+  }
+  int64_t cbase = o2[1];
+  const int64_t cstep = (int64_t)(CSTRIDE * CH) * N;   // C stride of m is D*D (block [x][ni])
+  const uint32_t svb = (uint32_t)(p.sa_v * (int64_t)sizeof(float));
+
+  // per-lane byte offsets of the k1 rows this lane loads (padded rows -> row 0, zero W1 rows)
+  uint32_t koff[KS1];
+#pragma unroll
+  for (int s = 0; s < KS1; ++s) {
+    int k = 4 * s + kq;
+    koff[s] = (uint32_t)(((k < K1 ? offK1[k] : offK1[0]) + j) * (int64_t)sizeof(float));
+  }
+  int64_t co[D];
+#pragma unroll
+  for (int no = 0; no < D; ++no) co[no] = offCo[no];
+
+  float* Ow = r_smem + wave * TILE;          // this wave's result tile  [no][m][x][ni]
+  float* Ol = Ow + j * N + kq;               // lane part of the write address; the rest is immediate
+  const bool last_ok = (4 * (SX - 1) + kq) < D;   // lane group valid in the last ni sub-block
+
+  float vmax = 0.f;
+#ifdef QAMD_CHAIN2_ABLATION   // debugging builds only (bits: 1 no stores, 4 no loads in the loop)
+  const uint32_t abl = p.ablate;
+#else
+  constexpr uint32_t abl = 0;
+#endif
+
+#ifdef QAMD_CHAIN2_TIMING   // experiment builds only: s_memtime stamps per phase, written to absmax_out
+  uint64_t tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  uint64_t tlast = __builtin_amdgcn_s_memtime();
+#define QAMD_STAMP(i) do { uint64_t now_ = __builtin_amdgcn_s_memtime(); tacc[i] += now_ - tlast; tlast = now_; } while (0)
+#else
+#define QAMD_STAMP(i) do {} while (0)
+#endif
+
+  // copy-out of the tile written by the previous chunk's stage 2: for every no, RUN contiguous
+  // elements of C.  It runs inside the NEXT chunk (after its first stage-1 tile), so its stores
+  // are never the newest VMEM operations a wait has to look past.
+  auto copy_out = [&]() {
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int no = 0; no < D; ++no) {
+      float* cp = C + cbase + co[no];      // wave-uniform, 16-byte aligned (host contract)
+#pragma unroll
+      for (int it = 0; it < (RUN + 255) / 256; ++it) {
+        const int e = it * 256 + lane * 4;
+        if (RUN % 256 == 0 || e < RUN) {
+          r_vec4 val = *reinterpret_cast<const r_vec4*>(Ow + no * RUN + e);
+          vmax = fmaxf(vmax, fmaxf(fmaxf(fabsf(val[0]), fabsf(val[1])), fmaxf(fabsf(val[2]), fabsf(val[3]))));
+          if (!(abl & 1)) __builtin_nontemporal_store(val, reinterpret_cast<r_vec4*>(cp + e));
+        }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    cbase += cstep;
+  };
+
+  // A registers, double buffered: the loads of chunk u+1 are issued before chunk u is touched
+  // and stay in flight for a whole chunk time (the memory-level parallelism of the kernel)
+  float bufA[D][KS1], bufB[D][KS1];
+  auto issue_v = [&](float (&dst)[D][KS1], uint64_t base, int v) {
+    if (abl & 4) return;
+#pragma unroll
+    for (int s = 0; s < KS1; ++s) dst[v][s] = rload(base + (uint64_t)v * svb, koff[s]);
+    __builtin_amdgcn_sched_barrier(0);   // keep this batch where it is written
+  };
+  auto issue = [&](float (&dst)[D][KS1], uint64_t base) {
+#pragma unroll
+    for (int v = 0; v < D; ++v) issue_v(dst, base, v);
+  };
+
+  // One chunk.  VMEM order per chunk: [18 stores of the previous tile] ... [54 loads of the next
+  // chunk]: a wave can have at most 64 vector-memory instructions outstanding, so stores must not
+  // be issued right behind a fresh batch of loads (54 + 18 > 64 would park the wave, MFMAs and
+  // all, until HBM answers) -- the loads go out one stage-2 block after the stores instead.
+  auto chunk = [&](float (&cur)[D][KS1], float (&nxt)[D][KS1], uint64_t nbase, bool copy_prev) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      // ---- stage 1: one 16-row tile of X for every v; D independent accumulator chains --------
+      r_acc_t X[D];
+#pragma unroll
+      for (int v = 0; v < D; ++v) X[v] = r_acc_t{0, 0, 0, 0};
+#pragma unroll
+      for (int s = 0; s < KS1; ++s)
+#pragma unroll
+        for (int v = 0; v < D; ++v)
+          X[v] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf1[s][nt], cur[v][s], X[v], 0, 0, 0);
+      QAMD_STAMP(nt == 0 ? 0 : (nt == 1 ? 4 : 6));      // stage 1 of tile nt
+      if (nt == 0 && copy_prev) copy_out();
+      if (nt == 0) QAMD_STAMP(1);                       // copy-out
+      if (NT == 1) issue(nxt, nbase);
+      QAMD_STAMP(2);
+      // ---- stage 2 for the x values of this tile: the stage-1 registers are the B operands ----
+#pragma unroll
+      for (int xl = 0; xl < XPT; ++xl) {
+        const int x = nt * XPT + xl;
+        if (x < D) {
+          // the next chunk's loads go out in D batches of KS1, one in front of every stage-2 block
+          // (a 54-load burst parks the wave at VMEM issue while the CU's memory pipe is busy)
+          if (NT > 1) issue_v(nxt, nbase, x);
+          r_acc_t acc[NT];
+#pragma unroll
+          for (int t = 0; t < NT; ++t) acc[t] = r_acc_t{0, 0, 0, 0};
+#pragma unroll
+          for (int sg = 0; sg < SX; ++sg)
+#pragma unroll
+            for (int v = 0; v < D; ++v)
+#pragma unroll
+              for (int t = 0; t < NT; ++t)
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf2[sg][v][t], X[v][xl * SX + sg], acc[t], 0, 0, 0);
+#pragma unroll
+          for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int R = 4 * t + r, no = R / SX, s2 = R % SX;
+              if (R < NSLOT && (s2 < SX - 1 || D % 4 == 0)) Ol[no * RUN + x * D + 4 * s2] = acc[t][r] * alpha;
+            }
+          if (D % 4 != 0 && last_ok) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                const int R = 4 * t + r, no = R / SX, s2 = R % SX;
+                if (R < NSLOT && s2 == SX - 1) Ol[no * RUN + x * D + 4 * s2] = acc[t][r] * alpha;
+              }
+          }
+        }
+      }
+      QAMD_STAMP(nt == 0 ? 3 : (nt == 1 ? 5 : 7));      // stage 2 of tile nt
+    }
+  };
+
+  constexpr uint64_t STEP = (uint64_t)(CSTRIDE * CH * sizeof(float));
+  issue(bufA, sbase);
+  uint32_t u = 0;
+  for (; u + 2 <= my_chunks; u += 2) {
+    sbase += STEP;
+    chunk(bufA, bufB, sbase, u > 0);                     // chunk u   (prefetches u+1)
+    sbase += (u + 2 < my_chunks) ? STEP : 0;             // (the last pair re-loads its own chunk: no branch)
+    chunk(bufB, bufA, sbase, true);                      // chunk u+1 (prefetches u+2)
+  }
+  if (u < my_chunks) chunk(bufA, bufB, sbase, u > 0);    // odd tail (its prefetch re-loads itself)
+  copy_out();
+
+#ifdef QAMD_CHAIN2_TIMING
+  if (absmax_out && lane == 0) {
+    for (int i = 0; i < 8; ++i) absmax_out[(blockIdx.x * 4 + wave) * 8 + i] = (float)tacc[i];
+  }
+  return;
+#endif
+  if (absmax_out) {
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) vmax = fmaxf(vmax, __shfl_down(vmax, d, 64));
+    if (lane == 0)
+      atomicMax(reinterpret_cast<unsigned int*>(absmax_out) + ((blockIdx.x * 4 + wave) % QAMD_SLOTS),
+                __float_as_uint(vmax));
+  }
+}
+
+}  // namespace qamd
+
+using namespace qamd;
+
+template <int D>
+static int launch_chain2r_d(const Chain2Args& a, const void* A, const void* W1p, const void* W2p, void* C,
+                            const void* offK1, const void* offCo, const void* sa, const void* s1, const void* s2,
+                            void* amax, hipStream_t st) {
+  size_t lds = (size_t)4 * D * 16 * D * D * sizeof(float);
+  if (lds > 160 * 1024) return -2;
+  if (lds > 64 * 1024)
+    (void)hipFuncSetAttribute((const void*)chain2r_kernel<D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  QAMD_LAUNCH((chain2r_kernel<D>), dim3(a.grid), dim3(256), lds, st, a, (const float*)A, (const float*)W1p,
+              (const float*)W2p, (float*)C, (const int64_t*)offK1, (const int64_t*)offCo, (const float*)sa,
+              (const float*)s1, (const float*)s2, (float*)amax);
+  return hipGetLastError() == hipSuccess ? 0 : -4;
+}
+
+// register-resident variant available for (dtype, D)?
+extern "C" int qamd_chain2r_supported(int dtype, int D) { return dtype == 0 && D >= 2 && D <= 6; }
+
+extern "C" int qamd_chain2r_launch(int D, const Chain2Args* a, const void* A, const void* W1p, const void* W2p,
+                                   void* C, const void* offK1, const void* offCo, const void* scale_a,
+                                   const void* scale_1, const void* scale_2, void* absmax_out, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  switch (D) {
+    case 2: return launch_chain2r_d<2>(*a, A, W1p, W2p, C, offK1, offCo, scale_a, scale_1, scale_2, absmax_out, st);
+    case 3: return launch_chain2r_d<3>(*a, A, W1p, W2p, C, offK1, offCo, scale_a, scale_1, scale_2, absmax_out, st);
+    case 4: return launch_chain2r_d<4>(*a, A, W1p, W2p, C, offK1, offCo, scale_a, scale_1, scale_2, absmax_out, st);
+    case 5: return launch_chain2r_d<5>(*a, A, W1p, W2p, C, offK1, offCo, scale_a, scale_1, scale_2, absmax_out, st);
+    case 6: return launch_chain2r_d<6>(*a, A, W1p, W2p, C, offK1, offCo, scale_a, scale_1, scale_2, absmax_out, st);
+  }
+  return -2;
+}

@@ -197,6 +197,8 @@ class HipDevice:
             for i, (d, sa, sc) in enumerate(c2.m):
                 pl.dim_m[i], pl.sa_m[i], pl.sc_m[i] = d, sa, sc
             pl.sa_v = c2.sa_v
+            if all(o % 4 == 0 for o in c2.off_co) and all(sc % 4 == 0 for (_, _, sc) in c2.m[:-1]):
+                pl.flags = 1  # QAMD_CHAIN2_C_ALIGNED16
             k1 = self.torch.tensor(c2.off_k1, dtype=self.torch.int64, device=self.tdev)
             co = self.torch.tensor(c2.off_co, dtype=self.torch.int64, device=self.tdev)
             ent = (pl, k1, co)
@@ -220,9 +222,9 @@ class HipDevice:
         )
         if prof is not None:
             e1.record()
-            tname = "float" if np.dtype(dtype) == np.dtype("float32") else "double"
-            ch = self.lib.qamd_chain2_chunk(dtype_code(dtype), c2.D)
-            prof.append((c2, np.dtype(dtype), f"chain2_kernel<{tname}, {c2.D}, {ch // 16}>", 1, e0, e1))
+            buf = C.create_string_buffer(128)
+            _lib.check(self.lib.qamd_chain2_describe(C.byref(pl), buf, 128), "qamd_chain2_describe")
+            prof.append((c2, np.dtype(dtype), buf.value.decode(), 1, e0, e1))
 
     # ---- layout / elementwise -----------------------------------------------
     def permute(self, dst, src, shape, strides, offset, dtype):

@@ -33,3 +33,29 @@ for _ in range(10): run()
 e1.record(); torch.cuda.synchronize()
 t = e0.elapsed_time(e1) / 10 * 1e-3
 print(f"ablate={os.environ.get('QAMD_CHAIN2_ABLATE','0')} V1={os.environ.get('QAMD_CHAIN2_V1','')} {t*1e3:.3f} ms  {2*c2.mults/t/1e12:.1f} TF  {4*(c2.a_size+c2.c_size)/t/1e9:.0f} GB/s")
+# single-launch timing (one event pair per launch) and host-side cost of a launch
+import time
+ts = []
+for _ in range(5):
+    torch.cuda.synchronize()
+    e0.record(); run(); e1.record(); torch.cuda.synchronize()
+    ts.append(e0.elapsed_time(e1))
+t0 = time.perf_counter()
+for _ in range(20): run()
+host = (time.perf_counter() - t0) / 20
+torch.cuda.synchronize()
+print(f"single-launch ms: {' '.join(f'{x:.3f}' for x in ts)}   host per launch: {host*1e6:.0f} us")
+
+if os.environ.get("QAMD_TIMING"):
+    # library built with -DQAMD_CHAIN2_TIMING: per-wave phase cycle sums come back through absmax_out
+    nblk = 4096
+    tb = torch.zeros(nblk * 4 * 8, device=dev.tdev)
+    dev.contract_chain2(c2, "float32", A._buf, w1p._buf, w2p._buf, out._buf, ep=(None, None, None, tb))
+    torch.cuda.synchronize()
+    t = tb.cpu().numpy().reshape(-1, 8)
+    t = t[t.sum(1) > 0]
+    names = ["s1 t0", "copyout", "ld issue", "s2 t0", "s1 t1", "s2 t1", "s1 t2", "s2 t2"]
+    tot = t.sum(1).mean()
+    print(f"waves {len(t)}  mean total cycles/wave {tot:.0f}")
+    for i, n in enumerate(names):
+        print(f"  {n:9s} {t[:, i].mean():10.0f}  {100 * t[:, i].mean() / tot:5.1f}%   (p10 {np.percentile(t[:, i], 10):.0f}  p90 {np.percentile(t[:, i], 90):.0f})")

@@ -84,7 +84,20 @@ def test_fused_pairs(hip, Lx, Ly, D, dtype):
     m, e = ex(arrays, strip_exponent=True)
     names = {n.split("<")[0] for (_, _, n, _, _, _) in hip.profile}
     hip.profile = None
-    assert "chain2_kernel" in names
+    assert names & {"chain2_kernel", "chain2r_kernel"}
+    if dtype == "float32":
+        # fp32 runs the register-resident variant; the LDS-tile kernel must agree too
+        assert "chain2r_kernel" in names
+        os.environ["QAMD_CHAIN2R"] = "0"
+        try:
+            hip.profile = []
+            v1 = ex(arrays).to_numpy().item()
+            names1 = {n.split("<")[0] for (_, _, n, _, _, _) in hip.profile}
+        finally:
+            del os.environ["QAMD_CHAIN2R"]
+            hip.profile = None
+        assert "chain2_kernel" in names1
+        assert v1 == pytest.approx(want, rel=5e-6)
     rel = 5e-6 if dtype == "float32" else 1e-11
     assert m.to_numpy().item() * 10.0**e == pytest.approx(want, rel=rel)
     assert ex(arrays).to_numpy().item() == pytest.approx(want, rel=rel)
