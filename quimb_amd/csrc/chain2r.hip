@@ -41,8 +41,14 @@ typedef float r_vec4 __attribute__((ext_vector_type(4), aligned(16)));
 typedef const __attribute__((address_space(1))) char* r_gptr_t;
 
 __device__ __forceinline__ float rload(uint64_t sbase, uint32_t voff) {
+#ifdef QAMD_C2R_NT_LOADS
   return __builtin_nontemporal_load(
       reinterpret_cast<const __attribute__((address_space(1))) float*>(reinterpret_cast<r_gptr_t>(sbase) + voff));
+#else
+  // plain (cached) loads: a wave uses only 64 B of every 128-B line, the other half belongs to the
+  // neighbouring wave of the workgroup -- the line has to survive in L2 until that wave asks for it
+  return *reinterpret_cast<const __attribute__((address_space(1))) float*>(reinterpret_cast<r_gptr_t>(sbase) + voff);
+#endif
 }
 
 __device__ __forceinline__ float rread_scale(const float* slots) {
@@ -215,6 +221,9 @@ __global__ __launch_bounds__(256, 2) void chain2r_kernel(const Chain2Args p, con
   // be issued right behind a fresh batch of loads (54 + 18 > 64 would park the wave, MFMAs and
   // all, until HBM answers) -- the loads go out one stage-2 block after the stores instead.
   auto chunk = [&](float (&cur)[D][KS1], float (&nxt)[D][KS1], uint64_t nbase, bool copy_prev) {
+#ifdef QAMD_C2R_SYNC
+    __builtin_amdgcn_s_barrier();   // keep the 4 waves (adjacent 64-B halves of the same lines) in step
+#endif
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
       // ---- stage 1: one 16-row tile of X for every v; D independent accumulator chains --------

@@ -1,0 +1,77 @@
+#!/usr/bin/env python
+"""Build profiles/<tag>_traffic.json from the FETCH_SIZE / WRITE_SIZE rocprofv3 summaries of
+bench.py (scripts/collect_profiles.sh): per-launch HBM bytes of the dominant kernel, with the
+gfx950 correction (FETCH_SIZE tallies wide coalesced reads at half size -> x2), next to the
+algorithmic bytes bench.py prices the same launch at."""
+import json, re, sys
+
+out, tag = sys.argv[1], sys.argv[2]
+
+
+def rows(path):
+    dur, pmc = {}, {}
+    for ln in open(path):
+        m = re.match(r"^(\S.*?\S)\s+(\d+)\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)\s*$", ln)
+        if m:
+            dur[m.group(1)] = (int(m.group(2)), float(m.group(3)), float(m.group(4)))
+            continue
+        m = re.match(r"^(\S.*?\S)\s+([A-Z_0-9a-z]+)\s+(\d+)\s+([\d.]+)\s+([\d.]+)\s*$", ln)
+        if m:
+            pmc[(m.group(1), m.group(2))] = (int(m.group(3)), float(m.group(4)), float(m.group(5)))
+    return dur, pmc
+
+
+bench = json.loads(open(f"{out}/{tag}_bench_stats.json").read().strip().splitlines()[-1])
+roof = bench["roofline"]
+kern = roof["kernel"]
+dur, _ = rows(f"{out}/{tag}_bench_stats.txt")
+_, pf = rows(f"{out}/{tag}_bench_fetch.txt")
+_, pw = rows(f"{out}/{tag}_bench_write.txt")
+
+
+def pick(d, counter=None):
+    best = None
+    for k, v in d.items():
+        name = k[0] if counter else k
+        if counter and k[1] != counter:
+            continue
+        if name.split(" grid=")[0] == kern and (best is None or v[1] > best[1][1]):
+            best = (k, v)
+    return best
+
+
+kd = pick(dur)
+kf, kw = pick(pf, "FETCH_SIZE"), pick(pw, "WRITE_SIZE")
+_, pr = rows(f"{out}/{tag}_bench_rdreq.txt")
+rq = {c: pick(pr, c) for c in ("TCC_EA0_RDREQ_sum", "TCC_EA0_RDREQ_128B_sum", "TCC_EA0_RDREQ_32B_sum")}
+# the counters are per (dispatch, XCD-instance) samples: sum / launches = per-launch total
+launches = kd[1][0]
+fetch_kb = kf[1][1] / launches
+write_kb = kw[1][1] / launches
+# (a counter that stayed at zero may have dropped off the bottom of the summary)
+n_all, n128, n32 = ((rq[c][1][1] / rq[c][1][0]) if rq[c] else 0.0
+                    for c in ("TCC_EA0_RDREQ_sum", "TCC_EA0_RDREQ_128B_sum", "TCC_EA0_RDREQ_32B_sum"))
+read_bytes = 128 * n128 + 32 * n32 + 64 * (n_all - n128 - n32)
+res = {
+    "kernel": kern,
+    "shape": roof["shape"],
+    "source": f"profiles/{tag}_bench_fetch.txt + profiles/{tag}_bench_write.txt (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, "
+              "separate passes, same bench command); durations from profiles/%s_bench_stats.txt" % tag,
+    "launches_profiled": launches,
+    "rocprof_avg_launch_us": kd[1][2],
+    "bench_hip_event_avg_launch_us": roof["avg_launch_ms"] * 1e3,
+    "fetch_size_kb_per_launch": fetch_kb,
+    "write_size_kb_per_launch": write_kb,
+    "read_requests_per_launch": {"all": n_all, "128B": n128, "32B": n32},
+    "read_bytes": read_bytes,
+    "write_bytes": write_kb * 1024,
+    "hbm_bytes_per_launch": read_bytes + write_kb * 1024,
+    "algorithmic_bytes_per_launch": roof["algorithmic_bytes_per_launch"],
+    "note": "gfx950 correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE = RDREQ x 64 B tallies 128-B requests at half size. "
+            "Wide 16 B/lane streaming reads are all 128-B requests (FETCH_SIZE x 2); this kernel's 4 B/lane loads are a mix, so "
+            "the read bytes are taken from the size-resolved request counters (128*n128 + 32*n32 + 64*rest), a separate --pmc pass, "
+            "validated on a known byte count in profiles/%s_fetch_calibration.txt" % tag,
+}
+res["traffic_over_algorithmic"] = res["hbm_bytes_per_launch"] / res["algorithmic_bytes_per_launch"]
+json.dump(res, open(f"{out}/{tag}_traffic.json", "w"), indent=1)
+print(json.dumps(res, indent=1))
