@@ -95,6 +95,12 @@ __global__ __launch_bounds__(256, 2) void chain2r_kernel(const Chain2Args p, con
   constexpr int TILE = D * RUN;          // result tile of one wave
   constexpr uint32_t CSTRIDE = 4;        // the 4 waves of a workgroup interleave chunks
   static_assert(D >= 2 && D <= 8 && (4 % SX) == 0, "slot scheme needs ceil(D/4) in {1, 2}");
+  // D % 4 == 2: the last y sub-block fills only lane groups 0, 1.  v_permlane32_swap packs the
+  // half-filled registers of two v values into one, so those k-steps are halved (D = 6: 9 instead of
+  // 12 k-steps per x, 324 instead of 378 MFMAs per chunk).
+  constexpr bool MERGE = (D % 4) == 2;
+  constexpr int SXF = MERGE ? SX - 1 : SX;   // sub-blocks consumed unmerged
+  constexpr int NPAIR = MERGE ? D / 2 : 0;   // merged k-steps of the last sub-block
 
   extern __shared__ __attribute__((aligned(16))) float r_smem[];
 
@@ -115,9 +121,9 @@ __global__ __launch_bounds__(256, 2) void chain2r_kernel(const Chain2Args p, con
       const float w = W1p[ok ? k1 * N + x * D + y : 0];
       wf1[s][nt] = ok ? w : 0.f;
     }
-  float wf2[SX][D][NT];
+  float wf2[SXF > 0 ? SXF : 1][D][NT];
 #pragma unroll
-  for (int sg = 0; sg < SX; ++sg)
+  for (int sg = 0; sg < SXF; ++sg)
 #pragma unroll
     for (int v = 0; v < D; ++v)
 #pragma unroll
@@ -128,6 +134,19 @@ __global__ __launch_bounds__(256, 2) void chain2r_kernel(const Chain2Args p, con
         const float w = W2p[ok ? (y * D + v) * N + no * D + ni : 0];
         wf2[sg][v][nt] = ok ? w : 0.f;
       }
+  // merged steps: lane groups 0, 1 <-> (y = 4*(SX-1) + q, v = 2p); groups 2, 3 <-> (y = 4*(SX-1) + q - 2, v = 2p + 1)
+  float wf2m[NPAIR > 0 ? NPAIR : 1][NT];
+#pragma unroll
+  for (int pr = 0; pr < NPAIR; ++pr)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int g = j >> 2, r = j & 3;
+      const int R = 4 * nt + r, no = R / SX, ni = 4 * (R % SX) + g;
+      const int y = 4 * (SX - 1) + (kq & 1), v = 2 * pr + (kq >> 1);
+      const bool ok = R < NSLOT && ni < D && y < D;
+      const float w = W2p[ok ? (y * D + v) * N + no * D + ni : 0];
+      wf2m[pr][nt] = ok ? w : 0.f;
+    }
   const float alpha = 1.f / (rread_scale(scale_a) * rread_scale(scale_1) * rread_scale(scale_2));
 
   const uint32_t blk_first = blockIdx.x * p.chunks_per_block;
@@ -252,12 +271,21 @@ __global__ __launch_bounds__(256, 2) void chain2r_kernel(const Chain2Args p, con
 #pragma unroll
           for (int t = 0; t < NT; ++t) acc[t] = r_acc_t{0, 0, 0, 0};
 #pragma unroll
-          for (int sg = 0; sg < SX; ++sg)
+          for (int sg = 0; sg < SXF; ++sg)
 #pragma unroll
             for (int v = 0; v < D; ++v)
 #pragma unroll
               for (int t = 0; t < NT; ++t)
                 acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf2[sg][v][t], X[v][xl * SX + sg], acc[t], 0, 0, 0);
+#pragma unroll
+          for (int pr = 0; pr < NPAIR; ++pr) {
+            // lanes 0-31 of X[2p] | lanes 0-31 of X[2p+1] (their lanes 32-63 hold the zero rows y >= D)
+            const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(X[2 * pr][xl * SX + SX - 1]),
+                                                             __float_as_uint(X[2 * pr + 1][xl * SX + SX - 1]), false, false);
+            const float xm = __uint_as_float(sw[0]);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf2m[pr][t], xm, acc[t], 0, 0, 0);
+          }
 #pragma unroll
           for (int t = 0; t < NT; ++t)
 #pragma unroll
