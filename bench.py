@@ -155,8 +155,8 @@ def main():
         agg = {}
         for spec, dt_, name, sk, e0, e1 in prof:
             if hasattr(spec, "off_k1"):  # fused pair of steps (Chain2Spec)
-                shape = {"fused_steps": 2, "M": spec.M, "D": spec.D, "K": spec.D**2, "N": spec.D**2}
-                nbytes = 4 * (spec.a_size + spec.c_size + 2 * spec.D**4)
+                shape = {"fused_steps": 2, "M": spec.M, "D": spec.D, "K": spec.K1, "N": spec.NO * spec.D}
+                nbytes = 4 * (spec.a_size + spec.c_size + spec.K1 * spec.D**2 + spec.D**3 * spec.NO)
                 nflops = 2 * spec.mults
             else:
                 shape = {"B": spec.B, "M": spec.M, "N": spec.N, "K": spec.K}

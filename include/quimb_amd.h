@@ -142,6 +142,10 @@ int qamd_contract_pair_ex(const qamd_pair_plan* plan, const void* A, const void*
  * offset offCo_dev[n2_out].  scale_* / absmax_out: slots as described for the epilogue struct above; any may be NULL.
  */
 #define QAMD_CHAIN2_C_ALIGNED16 1
+/* row-start shape: k1 is ONE index of size D (offK1_dev has D entries, W1p is [D][D*D]) */
+#define QAMD_CHAIN2_K1_SINGLE 2
+/* row-end shape: n2 = n2_in only (W2p is [D*D][D], offCo_dev has one entry, C ends [.., m_inner, x, n2_in]) */
+#define QAMD_CHAIN2_NO_N2OUT 4
 typedef struct {
   int32_t dtype, D, nm;
   int32_t flags;   /* QAMD_CHAIN2_C_ALIGNED16: every offCo_dev entry and every sc_m of the outer m groups is a multiple of 4

@@ -570,8 +570,11 @@ extern "C" int qamd_chain2_describe(const qamd_chain2_plan* p, char* buf, int32_
   if (!p || !buf || buflen <= 0) return QAMD_EINVAL;
   const int ch = qamd_chain2_chunk(p->dtype, p->D);
   if (!ch) return QAMD_EUNSUPPORTED;
+  const bool variant = (p->flags & (QAMD_CHAIN2_K1_SINGLE | QAMD_CHAIN2_NO_N2OUT)) != 0;
+  if (variant && !chain2_uses_registers(p, nullptr)) return QAMD_EUNSUPPORTED;
   if (chain2_uses_registers(p, nullptr))
-    snprintf(buf, buflen, "chain2r_kernel<%d>", p->D);
+    snprintf(buf, buflen, "chain2r_kernel<%d, %d, %d>", p->D, (p->flags & QAMD_CHAIN2_K1_SINGLE) ? 1 : 2,
+             (p->flags & QAMD_CHAIN2_NO_N2OUT) ? 0 : 1);
   else
     snprintf(buf, buflen, "chain2_kernel<%s, %d, %d>", p->dtype == QAMD_F32 ? "float" : "double", p->D, ch / 16);
   return QAMD_OK;
@@ -612,9 +615,12 @@ extern "C" int qamd_contract_chain2(const qamd_chain2_plan* p, const void* A, co
   a.chunks_per_block = best;
   a.grid = a.chunks / best;
   if (const char* e = getenv("QAMD_CHAIN2_ABLATE")) a.ablate = (uint32_t)atoi(e);
+  const int k1_single = (p->flags & QAMD_CHAIN2_K1_SINGLE) ? 1 : 0, no_n2out = (p->flags & QAMD_CHAIN2_NO_N2OUT) ? 1 : 0;
+  if (k1_single && no_n2out) return QAMD_EUNSUPPORTED;
   if (chain2_uses_registers(p, C))
-    return qamd_chain2r_launch(p->D, &a, A, W1p, W2p, C, offK1_dev, offCo_dev, scale_a, scale_1, scale_2, absmax_out,
-                               stream);
+    return qamd_chain2r_launch(p->D, k1_single, no_n2out, &a, A, W1p, W2p, C, offK1_dev, offCo_dev, scale_a, scale_1,
+                               scale_2, absmax_out, stream);
+  if (k1_single || no_n2out) return QAMD_EUNSUPPORTED;   // the row-start / row-end shapes exist in chain2r only
   return qamd_chain2_launch(p->dtype, p->D, &a, A, W1p, W2p, C, offK1_dev, offCo_dev, scale_a, scale_1, scale_2,
                             absmax_out, stream);
 }

@@ -75,7 +75,9 @@ __device__ __forceinline__ void rdecomp2(uint32_t idx, int n, const uint32_t* di
   o[1] = o2;
 }
 
-template <int D>
+// K1D: number of size-D indices in k1 (2 = (h, u) interior site, 1 = row start: no h yet);
+// NOD: 1 = n2 = (no, ni) interior site, 0 = row end: n2 = ni only (no new horizontal bond).
+template <int D, int K1D, int NOD>
 __global__ __launch_bounds__(256, 2) void chain2r_kernel(const Chain2Args p, const float* __restrict__ A,
                                                          const float* __restrict__ W1p,
                                                          const float* __restrict__ W2p, float* __restrict__ C,
@@ -85,14 +87,17 @@ __global__ __launch_bounds__(256, 2) void chain2r_kernel(const Chain2Args p, con
                                                          const float* __restrict__ scale_1,
                                                          const float* __restrict__ scale_2,
                                                          float* __restrict__ absmax_out) {
-  constexpr int N = D * D, K1 = D * D, KS1 = (K1 + 3) / 4;
+  constexpr int N = D * D, K1 = (K1D == 2 ? D * D : D), KS1 = (K1 + 3) / 4;
+  constexpr int NO = NOD ? D : 1, N2 = NO * D;
   constexpr int SX = (D + 3) / 4;        // slots (registers) per x / per no
-  constexpr int NSLOT = D * SX;          // used rows of the permuted W1 / W2 column order, in units of 4 lane groups
-  constexpr int NT = (NSLOT + 3) / 4;    // 16-row MFMA tiles
+  constexpr int NSLOT = D * SX;          // stage 1: used rows of the permuted W1 column order, in units of 4 lane groups
+  constexpr int NT = (NSLOT + 3) / 4;    // stage 1: 16-row MFMA tiles
+  constexpr int NSLOT2 = NO * SX;        // stage 2: registers of the permuted W2 column order
+  constexpr int NT2 = (NSLOT2 + 3) / 4;  // stage 2: 16-row MFMA tiles
   constexpr int XPT = 4 / SX;            // x values per tile
   constexpr int CH = 16;                 // m values per chunk (one per lane j)
   constexpr int RUN = CH * N;            // contiguous C elements per (no, chunk):  [m][x][ni]
-  constexpr int TILE = D * RUN;          // result tile of one wave
+  constexpr int TILE = NO * RUN;         // result tile of one wave
   constexpr uint32_t CSTRIDE = 4;        // the 4 waves of a workgroup interleave chunks
   static_assert(D >= 2 && D <= 8 && (4 % SX) == 0, "slot scheme needs ceil(D/4) in {1, 2}");
   // D % 4 == 2: the last y sub-block fills only lane groups 0, 1.  v_permlane32_swap packs the
@@ -121,30 +126,30 @@ __global__ __launch_bounds__(256, 2) void chain2r_kernel(const Chain2Args p, con
       const float w = W1p[ok ? k1 * N + x * D + y : 0];
       wf1[s][nt] = ok ? w : 0.f;
     }
-  float wf2[SXF > 0 ? SXF : 1][D][NT];
+  float wf2[SXF > 0 ? SXF : 1][D][NT2];
 #pragma unroll
   for (int sg = 0; sg < SXF; ++sg)
 #pragma unroll
     for (int v = 0; v < D; ++v)
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) {
+      for (int nt = 0; nt < NT2; ++nt) {
         const int g = j >> 2, r = j & 3;
         const int R = 4 * nt + r, no = R / SX, ni = 4 * (R % SX) + g, y = 4 * sg + kq;
-        const bool ok = R < NSLOT && ni < D && y < D;
-        const float w = W2p[ok ? (y * D + v) * N + no * D + ni : 0];
+        const bool ok = R < NSLOT2 && ni < D && y < D;
+        const float w = W2p[ok ? (y * D + v) * N2 + no * D + ni : 0];
         wf2[sg][v][nt] = ok ? w : 0.f;
       }
   // merged steps: lane groups 0, 1 <-> (y = 4*(SX-1) + q, v = 2p); groups 2, 3 <-> (y = 4*(SX-1) + q - 2, v = 2p + 1)
-  float wf2m[NPAIR > 0 ? NPAIR : 1][NT];
+  float wf2m[NPAIR > 0 ? NPAIR : 1][NT2];
 #pragma unroll
   for (int pr = 0; pr < NPAIR; ++pr)
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
+    for (int nt = 0; nt < NT2; ++nt) {
       const int g = j >> 2, r = j & 3;
       const int R = 4 * nt + r, no = R / SX, ni = 4 * (R % SX) + g;
       const int y = 4 * (SX - 1) + (kq & 1), v = 2 * pr + (kq >> 1);
-      const bool ok = R < NSLOT && ni < D && y < D;
-      const float w = W2p[ok ? (y * D + v) * N + no * D + ni : 0];
+      const bool ok = R < NSLOT2 && ni < D && y < D;
+      const float w = W2p[ok ? (y * D + v) * N2 + no * D + ni : 0];
       wf2m[pr][nt] = ok ? w : 0.f;
     }
   const float alpha = 1.f / (rread_scale(scale_a) * rread_scale(scale_1) * rread_scale(scale_2));
@@ -176,9 +181,9 @@ __global__ __launch_bounds__(256, 2) void chain2r_kernel(const Chain2Args p, con
     int k = 4 * s + kq;
     koff[s] = (uint32_t)(((k < K1 ? offK1[k] : offK1[0]) + j) * (int64_t)sizeof(float));
   }
-  int64_t co[D];
+  int64_t co[NO];
 #pragma unroll
-  for (int no = 0; no < D; ++no) co[no] = offCo[no];
+  for (int no = 0; no < NO; ++no) co[no] = offCo[no];
 
   float* Ow = r_smem + wave * TILE;          // this wave's result tile  [no][m][x][ni]
   float* Ol = Ow + j * N + kq;               // lane part of the write address; the rest is immediate
@@ -205,7 +210,7 @@ __global__ __launch_bounds__(256, 2) void chain2r_kernel(const Chain2Args p, con
   auto copy_out = [&]() {
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
-    for (int no = 0; no < D; ++no) {
+    for (int no = 0; no < NO; ++no) {
       float* cp = C + cbase + co[no];      // wave-uniform, 16-byte aligned (host contract)
 #pragma unroll
       for (int it = 0; it < (RUN + 255) / 256; ++it) {
@@ -267,15 +272,15 @@ __global__ __launch_bounds__(256, 2) void chain2r_kernel(const Chain2Args p, con
           // the next chunk's loads go out in D batches of KS1, one in front of every stage-2 block
           // (a 54-load burst parks the wave at VMEM issue while the CU's memory pipe is busy)
           if (NT > 1) issue_v(nxt, nbase, x);
-          r_acc_t acc[NT];
+          r_acc_t acc[NT2];
 #pragma unroll
-          for (int t = 0; t < NT; ++t) acc[t] = r_acc_t{0, 0, 0, 0};
+          for (int t = 0; t < NT2; ++t) acc[t] = r_acc_t{0, 0, 0, 0};
 #pragma unroll
           for (int sg = 0; sg < SXF; ++sg)
 #pragma unroll
             for (int v = 0; v < D; ++v)
 #pragma unroll
-              for (int t = 0; t < NT; ++t)
+              for (int t = 0; t < NT2; ++t)
                 acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf2[sg][v][t], X[v][xl * SX + sg], acc[t], 0, 0, 0);
 #pragma unroll
           for (int pr = 0; pr < NPAIR; ++pr) {
@@ -284,22 +289,22 @@ __global__ __launch_bounds__(256, 2) void chain2r_kernel(const Chain2Args p, con
                                                              __float_as_uint(X[2 * pr + 1][xl * SX + SX - 1]), false, false);
             const float xm = __uint_as_float(sw[0]);
 #pragma unroll
-            for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf2m[pr][t], xm, acc[t], 0, 0, 0);
+            for (int t = 0; t < NT2; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf2m[pr][t], xm, acc[t], 0, 0, 0);
           }
 #pragma unroll
-          for (int t = 0; t < NT; ++t)
+          for (int t = 0; t < NT2; ++t)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
               const int R = 4 * t + r, no = R / SX, s2 = R % SX;
-              if (R < NSLOT && (s2 < SX - 1 || D % 4 == 0)) Ol[no * RUN + x * D + 4 * s2] = acc[t][r] * alpha;
+              if (R < NSLOT2 && (s2 < SX - 1 || D % 4 == 0)) Ol[no * RUN + x * D + 4 * s2] = acc[t][r] * alpha;
             }
           if (D % 4 != 0 && last_ok) {
 #pragma unroll
-            for (int t = 0; t < NT; ++t)
+            for (int t = 0; t < NT2; ++t)
 #pragma unroll
               for (int r = 0; r < 4; ++r) {
                 const int R = 4 * t + r, no = R / SX, s2 = R % SX;
-                if (R < NSLOT && s2 == SX - 1) Ol[no * RUN + x * D + 4 * s2] = acc[t][r] * alpha;
+                if (R < NSLOT2 && s2 == SX - 1) Ol[no * RUN + x * D + 4 * s2] = acc[t][r] * alpha;
               }
           }
         }
@@ -339,33 +344,39 @@ __global__ __launch_bounds__(256, 2) void chain2r_kernel(const Chain2Args p, con
 
 using namespace qamd;
 
-template <int D>
+template <int D, int K1D, int NOD>
 static int launch_chain2r_d(const Chain2Args& a, const void* A, const void* W1p, const void* W2p, void* C,
                             const void* offK1, const void* offCo, const void* sa, const void* s1, const void* s2,
                             void* amax, hipStream_t st) {
-  size_t lds = (size_t)4 * D * 16 * D * D * sizeof(float);
+  size_t lds = (size_t)4 * (NOD ? D : 1) * 16 * D * D * sizeof(float);
   if (lds > 160 * 1024) return -2;
   if (lds > 64 * 1024)
-    (void)hipFuncSetAttribute((const void*)chain2r_kernel<D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  QAMD_LAUNCH((chain2r_kernel<D>), dim3(a.grid), dim3(256), lds, st, a, (const float*)A, (const float*)W1p,
+    (void)hipFuncSetAttribute((const void*)chain2r_kernel<D, K1D, NOD>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)lds);
+  QAMD_LAUNCH((chain2r_kernel<D, K1D, NOD>), dim3(a.grid), dim3(256), lds, st, a, (const float*)A, (const float*)W1p,
               (const float*)W2p, (float*)C, (const int64_t*)offK1, (const int64_t*)offCo, (const float*)sa,
               (const float*)s1, (const float*)s2, (float*)amax);
   return hipGetLastError() == hipSuccess ? 0 : -4;
 }
 
-// register-resident variant available for (dtype, D)?
+// register-resident variant available for (dtype, D)?  It is the only implementation of the
+// row-start (k1 = one index) and row-end (n2 = one index) pair shapes.
 extern "C" int qamd_chain2r_supported(int dtype, int D) { return dtype == 0 && D >= 2 && D <= 6; }
 
-extern "C" int qamd_chain2r_launch(int D, const Chain2Args* a, const void* A, const void* W1p, const void* W2p,
-                                   void* C, const void* offK1, const void* offCo, const void* scale_a,
-                                   const void* scale_1, const void* scale_2, void* absmax_out, void* stream) {
+extern "C" int qamd_chain2r_launch(int D, int k1_single, int no_n2out, const Chain2Args* a, const void* A,
+                                   const void* W1p, const void* W2p, void* C, const void* offK1, const void* offCo,
+                                   const void* scale_a, const void* scale_1, const void* scale_2, void* absmax_out,
+                                   void* stream) {
   hipStream_t st = (hipStream_t)stream;
+  if (k1_single && no_n2out) return -2;
+#define QAMD_C2R(DD)                                                                                                 \
+  case DD:                                                                                                           \
+    if (k1_single) return launch_chain2r_d<DD, 1, 1>(*a, A, W1p, W2p, C, offK1, offCo, scale_a, scale_1, scale_2, absmax_out, st); \
+    if (no_n2out) return launch_chain2r_d<DD, 2, 0>(*a, A, W1p, W2p, C, offK1, offCo, scale_a, scale_1, scale_2, absmax_out, st);  \
+    return launch_chain2r_d<DD, 2, 1>(*a, A, W1p, W2p, C, offK1, offCo, scale_a, scale_1, scale_2, absmax_out, st);
   switch (D) {
-    case 2: return launch_chain2r_d<2>(*a, A, W1p, W2p, C, offK1, offCo, scale_a, scale_1, scale_2, absmax_out, st);
-    case 3: return launch_chain2r_d<3>(*a, A, W1p, W2p, C, offK1, offCo, scale_a, scale_1, scale_2, absmax_out, st);
-    case 4: return launch_chain2r_d<4>(*a, A, W1p, W2p, C, offK1, offCo, scale_a, scale_1, scale_2, absmax_out, st);
-    case 5: return launch_chain2r_d<5>(*a, A, W1p, W2p, C, offK1, offCo, scale_a, scale_1, scale_2, absmax_out, st);
-    case 6: return launch_chain2r_d<6>(*a, A, W1p, W2p, C, offK1, offCo, scale_a, scale_1, scale_2, absmax_out, st);
+    QAMD_C2R(2) QAMD_C2R(3) QAMD_C2R(4) QAMD_C2R(5) QAMD_C2R(6)
   }
+#undef QAMD_C2R
   return -2;
 }

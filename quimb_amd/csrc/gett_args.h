@@ -73,9 +73,9 @@ int qamd_chain2_launch(int dtype, int D, const Chain2Args* a, const void* A, con
                        void* C, const void* offK1, const void* offCo, const void* scale_a, const void* scale_1,
                        const void* scale_2, void* absmax_out, void* stream);
 int qamd_chain2r_supported(int dtype, int D);
-int qamd_chain2r_launch(int D, const Chain2Args* a, const void* A, const void* W1p, const void* W2p, void* C,
-                        const void* offK1, const void* offCo, const void* scale_a, const void* scale_1,
-                        const void* scale_2, void* absmax_out, void* stream);
+int qamd_chain2r_launch(int D, int k1_single, int no_n2out, const Chain2Args* a, const void* A, const void* W1p,
+                        const void* W2p, void* C, const void* offK1, const void* offCo, const void* scale_a,
+                        const void* scale_1, const void* scale_2, void* absmax_out, void* stream);
 void qamd_gett_tile_dims(int cfg, int* bm, int* bn, int* bk);
 int qamd_splitk_reduce_launch(int dtype, void* C, const void* ws, int64_t n, int split_k,
                               const void* scale_a, const void* scale_b, void* absmax_out, void* stream);

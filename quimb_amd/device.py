@@ -199,6 +199,10 @@ class HipDevice:
             pl.sa_v = c2.sa_v
             if all(o % 4 == 0 for o in c2.off_co) and all(sc % 4 == 0 for (_, _, sc) in c2.m[:-1]):
                 pl.flags = 1  # QAMD_CHAIN2_C_ALIGNED16
+            if c2.k1_single:
+                pl.flags |= 2  # QAMD_CHAIN2_K1_SINGLE
+            if c2.no_n2out:
+                pl.flags |= 4  # QAMD_CHAIN2_NO_N2OUT
             k1 = self.torch.tensor(c2.off_k1, dtype=self.torch.int64, device=self.tdev)
             co = self.torch.tensor(c2.off_co, dtype=self.torch.int64, device=self.tdev)
             ent = (pl, k1, co)

@@ -370,6 +370,16 @@ def chain2_chunk(dtype_name, D):
     return 0
 
 
+def chain2_variants_ok(dtype_name, D):
+    """Row-start / row-end pair shapes: mirrors ``qamd_chain2r_supported`` (fp32, D <= 6, 16-m chunk;
+    ``QAMD_CHAIN2R=0`` switches the register kernel off in the library, and with it these shapes)."""
+    import os
+
+    if os.environ.get("QAMD_CHAIN2R", "")[:1] == "0":
+        return False
+    return dtype_name == "float32" and 2 <= D <= 6 and chain2_chunk(dtype_name, D) == 16
+
+
 @dataclass(frozen=True)
 class Chain2Spec:
     """Two consecutive big-x-small steps fused:  X = A.W1 ; C = X.W2  (see chain2.hip)."""
@@ -386,6 +396,16 @@ class Chain2Spec:
     mults: int        # scalar multiplications of both steps
     a_size: int
     c_size: int
+    K1: int = 0       # rows of step 1: D*D (interior site: k1 = (h, u)) or D (row start: no h yet)
+    NO: int = 0       # values of n2_out: D (interior site) or 1 (row end: n2 = n2_in only)
+
+    @property
+    def k1_single(self):
+        return self.K1 == self.D
+
+    @property
+    def no_n2out(self):
+        return self.NO == 1
 
     @property
     def M(self):
@@ -415,10 +435,15 @@ def plan_chain2(la, l1, lx, l2, lc, size, dtype_name):
     n2 = [ix for ix in l2 if ix not in k2]
     if any(ix not in sc_ for ix in n2) or any(ix not in sc_ for ix in lx if ix not in k2):
         return None
-    if not (len(k2m) == 1 and len(k2n) == 1 and len(xs) == 1 and len(n2) == 2):
+    if not (len(k2m) == 1 and len(k2n) == 1 and len(xs) == 1 and len(n2) in (1, 2)):
         return None
     D = size[k2m[0]]
-    if any(size[ix] != D for ix in k2n + xs + n2) or prod(size[ix] for ix in k1) != D * D or not k1:
+    K1 = prod(size[ix] for ix in k1)
+    if any(size[ix] != D for ix in k2n + xs + n2) or not k1 or any(size[ix] != D for ix in k1) or len(k1) > 2:
+        return None
+    # row-start (k1 = one index) and row-end (n2 = one index) shapes exist in the register kernel only
+    variant = len(k1) == 1 or len(n2) == 1
+    if variant and (len(k1) == 1 and len(n2) == 1 or not chain2_variants_ok(dtype_name, D)):
         return None
     chunk = chain2_chunk(dtype_name, D)
     if not chunk:
@@ -433,7 +458,8 @@ def plan_chain2(la, l1, lx, l2, lc, size, dtype_name):
     n2in = lc[-1]
     if n2in not in n2 or lc[-2] != x:
         return None
-    n2out = [ix for ix in n2 if ix != n2in][0]
+    n2out = ([ix for ix in n2 if ix != n2in] or [None])[0]
+    NO = D if n2out is not None else 1
     gm = _fuse(mm, size, [sa, sc])
     if not gm or len(gm) > MAX_GROUPS:
         return None
@@ -450,18 +476,21 @@ def plan_chain2(la, l1, lx, l2, lc, size, dtype_name):
         return None
     s1d = dict(zip(l1, contig_strides(tuple(size[i] for i in l1))))
     s2d = dict(zip(l2, contig_strides(tuple(size[i] for i in l2))))
+    off_co = tuple(i * sc[n2out] for i in range(D)) if n2out is not None else (0,)
+    if variant and (any(o % 4 for o in off_co) or any(st[1] % 4 for _, st in gm[:-1])):
+        return None                                    # the register kernel stores 16-byte vectors
     o1 = tuple(k1) + (x, y)
-    o2 = (y, v, n2out, n2in)
+    o2 = (y, v, n2out, n2in) if n2out is not None else (y, v, n2in)
     w1_pack = PermuteSpec(o1, tuple(size[i] for i in o1), tuple(s1d[i] for i in o1))
     w2_pack = PermuteSpec(o2, tuple(size[i] for i in o2), tuple(s2d[i] for i in o2))
     M = prod(size[i] for i in mm)
-    mults = M * D * (D * D) * (D * D) * 2   # step 1: M*D columns x K1 x N1 ; step 2: M*D columns x K2 x N2
+    mults = M * D * K1 * (D * D) + M * D * (D * D) * (NO * D)   # step 1: M*D columns x K1 x N1 ; step 2: M*D (x) columns x K2 x N2
     return Chain2Spec(
         D=D,
         m=tuple((d, st[0], st[1]) for d, st in gm),
         sa_v=sa[v],
         off_k1=tuple(off_k1),
-        off_co=tuple(i * sc[n2out] for i in range(D)),
+        off_co=off_co,
         w1_pack=w1_pack,
         w2_pack=w2_pack,
         out_inds=tuple(lc),
@@ -469,4 +498,6 @@ def plan_chain2(la, l1, lx, l2, lc, size, dtype_name):
         mults=mults,
         a_size=prod(size[i] for i in la),
         c_size=prod(size[i] for i in lc),
+        K1=K1,
+        NO=NO,
     )

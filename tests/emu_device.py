@@ -75,8 +75,9 @@ class EmuDevice:
         ok1 = np.asarray(c2.off_k1, dtype=np.int64)
         ov = np.arange(D, dtype=np.int64) * c2.sa_v
         A = a[ok1[:, None, None] + ov[None, :, None] + om_a[None, None, :]]          # [k1, v, m]
-        W1 = w1p[: D**4].reshape(D * D, D, D)                                          # [k1, x, y]
-        W2 = w2p[: D**4].reshape(D, D, D, D)                                           # [y, v, no, ni]
+        K1, NO = c2.K1, c2.NO
+        W1 = w1p[: K1 * D * D].reshape(K1, D, D)                                       # [k1, x, y]
+        W2 = w2p[: D * D * NO * D].reshape(D, D, NO, D)                                # [y, v, no, ni]
         X = np.einsum("kvm,kxy->xyvm", A, W1)
         Cv = np.einsum("xyvm,yvoi->omxi", X, W2)                                       # [no, m, x, ni]
         if ep is not None:

@@ -80,6 +80,9 @@ def test_fused_pairs(hip, Lx, Ly, D, dtype):
     finally:
         del os.environ["QAMD_CHAIN2"]
     assert any(e[0] == "chain2" for e in ex.plan)
+    if dtype == "float32":   # row-start and row-end pairs are fused too (register kernel only)
+        assert any(e[0] == "chain2" and e[5].k1_single for e in ex.plan)
+        assert any(e[0] == "chain2" and e[5].no_n2out for e in ex.plan)
     hip.profile = []
     m, e = ex(arrays, strip_exponent=True)
     names = {n.split("<")[0] for (_, _, n, _, _, _) in hip.profile}
@@ -91,7 +94,7 @@ def test_fused_pairs(hip, Lx, Ly, D, dtype):
         os.environ["QAMD_CHAIN2R"] = "0"
         try:
             hip.profile = []
-            v1 = ex(arrays).to_numpy().item()
+            v1 = qa.TreeExecutor(tree, dtype)(arrays).to_numpy().item()
             names1 = {n.split("<")[0] for (_, _, n, _, _, _) in hip.profile}
         finally:
             del os.environ["QAMD_CHAIN2R"]
