@@ -59,6 +59,7 @@ def test_sweep_3x8_D6_streams(hip):
 
 
 @pytest.mark.parametrize("Lx,Ly,D,dtype", [(4, 8, 2, "float64"), (4, 8, 2, "float32"), (3, 6, 4, "float32"),
+                                           (4, 10, 4, "float32"), (5, 12, 2, "float32"),
                                            (3, 5, 4, "float64"), (3, 8, 6, "float32"), (3, 7, 6, "float64")])
 def test_fused_pairs(hip, Lx, Ly, D, dtype):
     """Two adjacent site absorptions in ONE launch (chain2 kernel): same value as the
