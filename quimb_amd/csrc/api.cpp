@@ -49,7 +49,7 @@ static int pair_dims(const qamd_pair_plan* p, PairDims& d) {
 static int pick_vec(int64_t inner_dim, int64_t align_bytes, int esize, const std::vector<int64_t>& others) {
   for (int v = 4; v >= 2; v >>= 1) {
     if (inner_dim % v) continue;
-    if (align_bytes % ((int64_t)v * esize)) continue;
+    if (align_bytes % std::min<int64_t>((int64_t)v * esize, 16)) continue;   // no access is wider than 16 bytes
     bool ok = true;
     for (int64_t s : others)
       if (s % v) { ok = false; break; }
@@ -58,12 +58,21 @@ static int pick_vec(int64_t inner_dim, int64_t align_bytes, int esize, const std
   return 1;
 }
 
-static const int kNumTileCfg = 6;
-static const int kTileBM[kNumTileCfg] = {128, 64, 256, 256, 128, 128};
-static const int kTileBN[kNumTileCfg] = {128, 64, 48, 16, 32, 128};
-static const int kTileBK[kNumTileCfg] = {16, 16, 16, 16, 16, 32};
-static const int kBK = 32;  // k-offset tables are padded to the largest k-tile
 static const int kNumCU = 256;
+static const int kNumTileCfg = 8;
+static const int kFastCfg = 6;    // gettf.hip: full 128x128x16 tiles, compile-time loader
+static const int kFastCfgN = 7;   // gettf.hip: full 128x64x16 tiles
+static const int kTileBM[kNumTileCfg] = {128, 64, 256, 256, 128, 128, 128, 128};
+static const int kTileBN[kNumTileCfg] = {128, 64, 48, 16, 32, 128, 128, 64};
+static const int kTileBK[kNumTileCfg] = {16, 16, 16, 16, 16, 32, 16, 16};
+
+// full-tile fast path: every tile whole, 4-element vector loads on both operands, enough
+// tiles to fill the chip without split-K
+static bool fast_tile_ok(const qamd_pair_plan* p, const PairDims& d, int cfg) {
+  const int bn = kTileBN[cfg];
+  return d.M % 128 == 0 && d.N % bn == 0 && d.K % 16 == 0 && p->vec_a == 4 && p->vec_b == 4;
+}
+static const int kBK = 32;  // k-offset tables are padded to the largest k-tile
 
 // size of the trailing block of N groups that is contiguous (stride-1 run) in C
 static int64_t n_inner_block(const qamd_pair_plan* p) {
@@ -81,6 +90,8 @@ static int stream_lds_bytes(int64_t K, int64_t N, int es) {
   int64_t ldw = npad + ((48 - npad % 32) % 32);
   return (int)((2 * npad + kpad) * 8 + kpad * ldw * es);
 }
+
+static int64_t c_extent(const qamd_pair_plan* p);
 
 extern "C" int qamd_pair_plan_finalize(qamd_pair_plan* p, int64_t align_a, int64_t align_b, int64_t align_c) {
   PairDims d;
@@ -169,11 +180,22 @@ extern "C" int qamd_pair_plan_finalize(qamd_pair_plan* p, int64_t align_a, int64
     else if (d.N <= 48) cfg = 2;
     else {
       // measured (profiles/r01_microbench.txt): the 64x64 tile (more workgroups in flight)
-      // beats 128x128x16 and 128x128x32 at every size from 1024^3 to 8192^3, f32 and f64
+      // beats 128x128x16 and 128x128x32 at every size from 1024^3 to 8192^3, f32 and f64;
+      // the compile-time 128x128 kernel (gettf.hip) beats both wherever its preconditions hold
+      const char* fe = getenv("QAMD_FAST_TILE");   // 0 disables the fast path, 6 / 7 pin a shape
+      const int want = fe ? atoi(fe) : -1;
       cfg = 1;
+      if (want != 0) {
+        // 128x128 once it fills the chip twice over, else 128x64 (more workgroups, split-K on top if needed)
+        const bool big = (d.M / 128) * (d.N / 128) * d.B >= 2 * kNumCU;
+        if ((want == kFastCfg || (want < 0 && big)) && fast_tile_ok(p, d, kFastCfg)) cfg = kFastCfg;
+        else if ((want == kFastCfgN || want < 0) && fast_tile_ok(p, d, kFastCfgN)) cfg = kFastCfgN;
+      }
     }
     p->tile_cfg = cfg;
   }
+  if ((p->tile_cfg == kFastCfg || p->tile_cfg == kFastCfgN) && !fast_tile_ok(p, d, p->tile_cfg))
+    return QAMD_EUNSUPPORTED;
   // ---- split-K for launches that cannot fill the chip ------------------------
   if (p->split_k < 1) {
     int bm = kTileBM[p->tile_cfg], bn = kTileBN[p->tile_cfg];
@@ -181,12 +203,15 @@ extern "C" int qamd_pair_plan_finalize(qamd_pair_plan* p, int64_t align_a, int64
     const int bk = kTileBK[p->tile_cfg];
     int64_t ksteps = (d.K + bk - 1) / bk;
     int64_t s = 1;
-    if (tiles < kNumCU && ksteps >= 8) {
-      s = (2 * kNumCU + tiles - 1) / tiles;
-      s = std::min<int64_t>(s, ksteps / 4);
+    // aim at ~4 workgroups per CU (several are resident per CU at these register counts; a
+    // grid of one workgroup per CU leaves 3/4 of the wave slots empty), >= 8 k-tiles per split
+    if (tiles < 3 * kNumCU && ksteps >= 16) {
+      s = (4 * kNumCU + tiles - 1) / tiles;
+      s = std::min<int64_t>(s, ksteps / 8);
       s = std::min<int64_t>(s, 1024);
       s = std::max<int64_t>(s, 1);
     }
+    if (c_extent(p) != d.B * d.M * d.N) s = 1;   // the slab reduction needs a compact C
     p->split_k = (int32_t)s;
   }
   return QAMD_OK;
@@ -360,6 +385,20 @@ extern "C" int qamd_contract_pair_ex(const qamd_pair_plan* p, const void* A, con
   a.a_kcontig = p->a_kcontig; a.b_kcontig = p->b_kcontig;
   const int swap = p->c_ncontig ? 0 : 1;
 
+  if (p->tile_cfg == kFastCfg || p->tile_cfg == kFastCfgN) {
+    if (!fast_tile_ok(p, d, p->tile_cfg) || ((uintptr_t)A & 15) || ((uintptr_t)B & 15)) return QAMD_EINVAL;
+    if (split == 1) {
+      a.slab_stride = 0;
+      return qamd_gettf_launch(p->dtype, bn, &a, swap, A, B, C, ktab, sa, sb, amax, stream);
+    }
+    const int64_t csz = d.B * d.M * d.N;
+    if (c_extent(p) != csz) return QAMD_EUNSUPPORTED;  // split-K needs a compact C
+    if (!ws || ws_bytes < (int64_t)split * csz * kEsize[p->dtype]) return QAMD_EWORKSPACE;
+    a.slab_stride = csz;
+    rc = qamd_gettf_launch(p->dtype, bn, &a, swap, A, B, ws, ktab, nullptr, nullptr, nullptr, stream);
+    if (rc) return rc;
+    return qamd_splitk_reduce_launch(p->dtype, C, ws, csz, split, sa, sb, amax, stream);
+  }
   if (split == 1) {
     a.slab_stride = 0;
     return qamd_gett_launch(p->dtype, p->tile_cfg, &a, swap, A, B, C, ktab, sa, sb, amax, stream);
@@ -544,9 +583,12 @@ extern "C" int qamd_pair_describe(const qamd_pair_plan* p, char* buf, int32_t bu
       snprintf(buf, buflen, "sweep_kernel<%s, %u, %d, %s>", T, s.NT, PS, s.zmode ? "true" : "false");
     else
       snprintf(buf, buflen, "stream_kernel<%s, %d, %u, 8, %s>", T, p->vec_c, s.NT, s.zmode ? "true" : "false");
+  } else if (p->tile_cfg == kFastCfg || p->tile_cfg == kFastCfgN) {
+    snprintf(buf, buflen, "gettf_kernel<%s, %d, %s, %s, %s>", T, p->tile_cfg == kFastCfg ? 4 : 2,
+             p->a_kcontig ? "true" : "false", p->b_kcontig ? "true" : "false", p->c_ncontig ? "false" : "true");
   } else {
     static const char* cfg[kNumTileCfg] = {"2, 2, 4, 4, 16", "2, 2, 2, 2, 16", "4, 1, 4, 3, 16", "4, 1, 4, 1, 16",
-                                           "4, 1, 2, 2, 16", "2, 2, 4, 4, 32"};
+                                           "4, 1, 2, 2, 16", "2, 2, 4, 4, 32", "fast", "fast"};
     snprintf(buf, buflen, "gett_kernel<%s, %s, %s> split_k=%d", T,
              (p->tile_cfg >= 0 && p->tile_cfg < kNumTileCfg) ? cfg[p->tile_cfg] : "?", p->c_ncontig ? "false" : "true",
              p->split_k);

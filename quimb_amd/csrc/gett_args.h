@@ -62,6 +62,8 @@ extern "C" {
 int qamd_gett_launch(int dtype, int cfg, const GettArgs* a, int swap, const void* A, const void* B,
                      void* C, const void* ktab, const void* scale_a, const void* scale_b, void* absmax_out,
                      void* stream);
+int qamd_gettf_launch(int dtype, int bn, const GettArgs* a, int swap, const void* A, const void* B, void* C,
+                      const void* ktab, const void* scale_a, const void* scale_b, void* absmax_out, void* stream);
 int qamd_stream_launch(int dtype, int V, const StreamArgs* a, const void* A, const void* B, void* C,
                        const void* ktab, const void* scale_a, const void* scale_b, void* absmax_out,
                        void* stream);

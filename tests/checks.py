@@ -358,6 +358,32 @@ def check_stream_kernels(dtype, seed=8):
         assert_close(got.to_numpy(), want, dtype)
 
 
+FAST_TILE_CASES = [
+    # full 128 x {128, 64} x 16 tiles + 4-element vector loads -> gettf_kernel (every loader orientation)
+    ("mk,kn->mn", dict(m=256, k=64, n=256)),          # A k-contiguous, B n-contiguous, C n-contiguous
+    ("km,nk->mn", dict(m=256, k=64, n=128)),          # A m-contiguous, B k-contiguous
+    ("mk,nk->nm", dict(m=128, k=48, n=256)),          # both k-contiguous, C m-contiguous (operand roles swapped)
+    ("km,kn->nm", dict(m=384, k=32, n=64)),           # both free-contiguous, 128x64 tiles only
+    ("aibj,jcid->acbd", dict(a=16, b=16, i=8, j=8, c=8, d=16)),   # two groups per bundle: tensor addressing
+    ("bmk,bkn->bmn", dict(b=3, m=128, k=32, n=128)),  # batch bundle
+    ("mk,kn->mn", dict(m=128, k=4096, n=128)),        # one tile, long K: split-K + slab reduction
+    ("xmk,kny->xmny", dict(x=2, m=64, k=256, n=32, y=4)),         # M = (x, m), N = (n, y)
+]
+
+
+def check_fast_tiles(dtype, seed=12):
+    """GEMM-shaped contractions that qualify for the full-tile fast path."""
+    rng = np.random.default_rng(seed)
+    for eq, dims in FAST_TILE_CASES:
+        lhs, out = eq.split("->")
+        ai, bi = lhs.split(",")
+        a = rand(rng, [dims[c] for c in ai], dtype)
+        b = rand(rng, [dims[c] for c in bi], dtype)
+        want = np.einsum(eq, a.astype(np.float64), b.astype(np.float64))
+        got = qa.einsum(eq, qa.asarray(a), qa.asarray(b))
+        assert_close(got.to_numpy(), want, dtype)
+
+
 # ---------------------------------------------------------------------------
 # golden vectors generated by the real quimb (tests/golden/make_golden.py)
 # ---------------------------------------------------------------------------

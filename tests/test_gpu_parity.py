@@ -58,6 +58,20 @@ def test_sweep_3x8_D6_streams(hip):
     assert out.to_numpy().item() == pytest.approx(wm.item() * 10.0**we, rel=5e-6)
 
 
+@pytest.mark.parametrize("dtype", ["float32", "float64"])
+def test_fast_tiles(hip, dtype):
+    """Full-tile GETT fast path (gettf.hip): all loader orientations, batch, split-K."""
+    hip.profile = []
+    try:
+        checks.check_fast_tiles(dtype)
+        names = [n for (_, _, n, _, _, _) in hip.profile]
+        splits = [sk for (_, _, n, sk, _, _) in hip.profile if n.startswith("gettf_kernel")]
+    finally:
+        hip.profile = None
+    assert sum(n.startswith("gettf_kernel") for n in names) >= len(checks.FAST_TILE_CASES) - 1, names
+    assert any(s > 1 for s in splits), splits
+
+
 @pytest.mark.parametrize("Lx,Ly,D,dtype", [(4, 8, 2, "float64"), (4, 8, 2, "float32"), (3, 6, 4, "float32"),
                                            (4, 10, 4, "float32"), (5, 12, 2, "float32"),
                                            (3, 5, 4, "float64"), (3, 8, 6, "float32"), (3, 7, 6, "float64")])

@@ -28,6 +28,11 @@ def test_tree_executor(emu, dtype):
     checks.check_tree_executor(dtype)
 
 
+def test_fast_tile_shapes(emu):
+    checks.check_fast_tiles("float64")
+    checks.check_fast_tiles("float32")
+
+
 def test_hyper_network(emu):
     checks.check_hyper_network("float64")
 
