@@ -70,7 +70,7 @@ static const int kTileBK[kNumTileCfg] = {16, 16, 16, 16, 16, 32, 16, 16};
 // tiles to fill the chip without split-K
 static bool fast_tile_ok(const qamd_pair_plan* p, const PairDims& d, int cfg) {
   const int bn = kTileBN[cfg];
-  return d.M % 128 == 0 && d.N % bn == 0 && d.K % 16 == 0 && p->vec_a == 4 && p->vec_b == 4;
+  return d.M % 128 == 0 && d.N % bn == 0 && d.K % 16 == 0 && p->vec_a >= 2 && p->vec_b >= 2;
 }
 static const int kBK = 32;  // k-offset tables are padded to the largest k-tile
 
@@ -205,7 +205,8 @@ extern "C" int qamd_pair_plan_finalize(qamd_pair_plan* p, int64_t align_a, int64
     int64_t s = 1;
     // aim at ~4 workgroups per CU (several are resident per CU at these register counts; a
     // grid of one workgroup per CU leaves 3/4 of the wave slots empty), >= 8 k-tiles per split
-    if (tiles < 3 * kNumCU && ksteps >= 16) {
+    // (the slab reduction moves (2s + 1) x |C|: only worth it when K is long or the chip is under-filled)
+    if (tiles < 3 * kNumCU && (ksteps >= 64 || (tiles < kNumCU && ksteps >= 16))) {
       s = (4 * kNumCU + tiles - 1) / tiles;
       s = std::min<int64_t>(s, ksteps / 8);
       s = std::min<int64_t>(s, 1024);
@@ -386,7 +387,9 @@ extern "C" int qamd_contract_pair_ex(const qamd_pair_plan* p, const void* A, con
   const int swap = p->c_ncontig ? 0 : 1;
 
   if (p->tile_cfg == kFastCfg || p->tile_cfg == kFastCfgN) {
-    if (!fast_tile_ok(p, d, p->tile_cfg) || ((uintptr_t)A & 15) || ((uintptr_t)B & 15)) return QAMD_EINVAL;
+    const uintptr_t es_ = (uintptr_t)kEsize[p->dtype];
+    const uintptr_t ma = std::min<uintptr_t>(16, p->vec_a * es_) - 1, mb = std::min<uintptr_t>(16, p->vec_b * es_) - 1;
+    if (!fast_tile_ok(p, d, p->tile_cfg) || ((uintptr_t)A & ma) || ((uintptr_t)B & mb)) return QAMD_EINVAL;
     if (split == 1) {
       a.slab_stride = 0;
       return qamd_gettf_launch(p->dtype, bn, &a, swap, A, B, C, ktab, sa, sb, amax, stream);
@@ -584,8 +587,9 @@ extern "C" int qamd_pair_describe(const qamd_pair_plan* p, char* buf, int32_t bu
     else
       snprintf(buf, buflen, "stream_kernel<%s, %d, %u, 8, %s>", T, p->vec_c, s.NT, s.zmode ? "true" : "false");
   } else if (p->tile_cfg == kFastCfg || p->tile_cfg == kFastCfgN) {
-    snprintf(buf, buflen, "gettf_kernel<%s, %d, %s, %s, %s>", T, p->tile_cfg == kFastCfg ? 4 : 2,
-             p->a_kcontig ? "true" : "false", p->b_kcontig ? "true" : "false", p->c_ncontig ? "false" : "true");
+    snprintf(buf, buflen, "gettf_kernel<%s, %d, %d, %d, %s, %s, %s>", T, p->tile_cfg == kFastCfg ? 4 : 2,
+             p->vec_a >= 4 ? 4 : 2, p->vec_b >= 4 ? 4 : 2, p->a_kcontig ? "true" : "false",
+             p->b_kcontig ? "true" : "false", p->c_ncontig ? "false" : "true");
   } else {
     static const char* cfg[kNumTileCfg] = {"2, 2, 4, 4, 16", "2, 2, 2, 2, 16", "4, 1, 4, 3, 16", "4, 1, 4, 1, 16",
                                            "4, 1, 2, 2, 16", "2, 2, 4, 4, 32", "fast", "fast"};

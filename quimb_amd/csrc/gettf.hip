@@ -99,16 +99,32 @@ __device__ __forceinline__ T fread_scale(const T* slots) {
   return m > T(0) ? m : T(1);
 }
 
-// One operand's global -> register -> LDS path.  XC = false: lanes run along the free bundle x
-// (16-byte pieces along x, LDS image written with one vector store); XC = true ("k-contiguous"):
-// lanes run along k, 4 lanes cover one row's 16 k values, the LDS image is written transposed.
-template <typename T, bool KC, int BX, int LD>
+template <typename T, int V>
+__device__ __forceinline__ void floadv(T* dst, const T* p) {
+  if constexpr (V * sizeof(T) == 32) {          // 4 doubles: two 16-byte loads
+    typedef T v2 __attribute__((ext_vector_type(2), aligned(16)));
+    v2 a = *reinterpret_cast<const v2*>(p), b = *reinterpret_cast<const v2*>(p + 2);
+    dst[0] = a[0]; dst[1] = a[1]; dst[2] = b[0]; dst[3] = b[1];
+  } else {
+    typedef T vv __attribute__((ext_vector_type(V), aligned(V * sizeof(T))));
+    vv a = *reinterpret_cast<const vv*>(p);
+#pragma unroll
+    for (int i = 0; i < V; ++i) dst[i] = a[i];
+  }
+}
+
+// One operand's global -> register -> LDS path, in pieces of V (4 or 2) contiguous elements.
+// KC = false: lanes run along the free bundle x (the LDS image is written with vector stores);
+// KC = true ("k-contiguous"): lanes run along k, 4 lanes cover one row's 16 k values, the LDS
+// image is written transposed.
+template <typename T, bool KC, int V, int BX, int LD>
 struct FLoader {
-  static constexpr int NQ = BX * 16 / 1024;   // 4-element pieces per thread and k-tile
-  static constexpr int XQ = BX / 4;           // pieces per k row
-  const T* base[NQ];    // k-contiguous: rows x, x + 64; else one row offset, NQ k rows
+  static constexpr int NQ = BX * 16 / 1024;   // 4-element groups per thread and k-tile
+  static constexpr int XQ = BX / 4;           // groups per k row
+  static constexpr int NP = 4 / V;            // pieces per group
+  const T* base[KC ? NQ : NP];   // k-contiguous: rows x, x + 64; else the NP pieces of this thread's x group
   int lds_off[NQ];
-  int ktoff[NQ];        // index into the k-offset table relative to the tile's k0
+  int ktoff[NQ];                 // index into the k-offset table relative to the tile's k0
 
   __device__ __forceinline__ void init(const T* op, uint32_t tile_x0, int nx, const uint32_t* dim_x,
                                        const int64_t* stride_x, int tid) {
@@ -122,10 +138,10 @@ struct FLoader {
       }
     } else {
       const int x = 4 * (tid % XQ), k = tid / XQ;
-      const T* b = op + fdecomp(tile_x0 + x, nx, dim_x, stride_x);
+#pragma unroll
+      for (int pc = 0; pc < NP; ++pc) base[pc] = op + fdecomp(tile_x0 + x + V * pc, nx, dim_x, stride_x);
 #pragma unroll
       for (int qi = 0; qi < NQ; ++qi) {
-        base[qi] = b;
         lds_off[qi] = (k + (256 / XQ) * qi) * LD + x;
         ktoff[qi] = k + (256 / XQ) * qi;
       }
@@ -133,7 +149,12 @@ struct FLoader {
   }
   __device__ __forceinline__ void load(FQuad<T> (&r)[NQ], const int64_t* __restrict__ kt, uint32_t k0) const {
 #pragma unroll
-    for (int qi = 0; qi < NQ; ++qi) fload4(r[qi], base[qi] + kt[k0 + ktoff[qi]]);
+    for (int qi = 0; qi < NQ; ++qi)
+#pragma unroll
+      for (int pc = 0; pc < NP; ++pc) {
+        if constexpr (KC) floadv<T, V>(r[qi].v + V * pc, base[qi] + kt[k0 + ktoff[qi] + V * pc]);
+        else floadv<T, V>(r[qi].v + V * pc, base[pc] + kt[k0 + ktoff[qi]]);
+      }
   }
   __device__ __forceinline__ void store(const FQuad<T> (&r)[NQ], T* __restrict__ tile) const {
 #pragma unroll
@@ -154,7 +175,7 @@ struct FLoader {
 #ifndef QAMD_GF_MINB_F64
 #define QAMD_GF_MINB_F64 2   // 2 workgroups per CU measured 63 vs 44 TFLOP/s at 4096^3 (register cap 256)
 #endif
-template <typename T, int WN, bool AKC, bool BKC, bool SWAP>
+template <typename T, int WN, int VA, int VB, bool AKC, bool BKC, bool SWAP>
 __global__ __launch_bounds__(256, (sizeof(T) == 4 ? QAMD_GF_MINB_F32 : QAMD_GF_MINB_F64)) void gettf_kernel(const GettArgs p, const T* __restrict__ A,
                                                      const T* __restrict__ B, T* __restrict__ C,
                                                      const int64_t* __restrict__ ktab,
@@ -204,8 +225,8 @@ __global__ __launch_bounds__(256, (sizeof(T) == 4 ? QAMD_GF_MINB_F32 : QAMD_GF_M
   if (tid < BM) offCm[tid] = fdecomp(tm * BM + tid, p.nm, p.dim_m, p.sc_m);
   else if (tid - BM < BN) offCn[tid - BM] = fdecomp(tn * BN + (tid - BM), p.nn, p.dim_n, p.sc_n);
 
-  FLoader<T, AKC, BM, LD> la;
-  FLoader<T, BKC, BN, LDB> lb;
+  FLoader<T, AKC, VA, BM, LD> la;
+  FLoader<T, BKC, VB, BN, LDB> lb;
   la.init(A + boffA, tm * BM, p.nm, p.dim_m, p.sa_m, tid);
   lb.init(B + boffB, tn * BN, p.nn, p.dim_n, p.sb_n, tid);
   const int64_t* ktA = ktab;
@@ -220,7 +241,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 4 ? QAMD_GF_MINB_F32 : QAMD_GF_M
 #pragma unroll
     for (int j = 0; j < WN; ++j) acc[i][j] = acc_t{0, 0, 0, 0};
 
-  FQuad<T> ra[FLoader<T, AKC, BM, LD>::NQ], rb[FLoader<T, BKC, BN, LDB>::NQ];
+  FQuad<T> ra[FLoader<T, AKC, VA, BM, LD>::NQ], rb[FLoader<T, BKC, VB, BN, LDB>::NQ];
   la.load(ra, ktA, kbeg);
   lb.load(rb, ktB, kbeg);
   la.store(ra, As);
@@ -301,45 +322,55 @@ __global__ __launch_bounds__(256, (sizeof(T) == 4 ? QAMD_GF_MINB_F32 : QAMD_GF_M
 
 using namespace qamd;
 
-template <typename T, int WN, bool AKC, bool BKC>
+template <typename T, int WN, int VA, int VB, bool AKC, bool BKC>
 static int launch_gettf_ab(const GettArgs& a, int swap, const void* A, const void* B, void* C, const void* ktab,
                            const void* sa, const void* sb, void* amax, hipStream_t st) {
   const size_t lds = (128 + 32 * WN) * sizeof(int64_t) + (size_t)2 * 16 * (144 + 32 * WN + 16) * sizeof(T);
   const unsigned grid = a.tiles_m * a.tiles_n * a.B * a.split_k;
   if (swap) {
     if (lds > 64 * 1024)
-      (void)hipFuncSetAttribute((const void*)gettf_kernel<T, WN, AKC, BKC, true>,
+      (void)hipFuncSetAttribute((const void*)gettf_kernel<T, WN, VA, VB, AKC, BKC, true>,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    QAMD_LAUNCH((gettf_kernel<T, WN, AKC, BKC, true>), dim3(grid), dim3(256), lds, st, a, (const T*)A, (const T*)B,
-                (T*)C, (const int64_t*)ktab, (const T*)sa, (const T*)sb, (T*)amax);
+    QAMD_LAUNCH((gettf_kernel<T, WN, VA, VB, AKC, BKC, true>), dim3(grid), dim3(256), lds, st, a, (const T*)A,
+                (const T*)B, (T*)C, (const int64_t*)ktab, (const T*)sa, (const T*)sb, (T*)amax);
   } else {
     if (lds > 64 * 1024)
-      (void)hipFuncSetAttribute((const void*)gettf_kernel<T, WN, AKC, BKC, false>,
+      (void)hipFuncSetAttribute((const void*)gettf_kernel<T, WN, VA, VB, AKC, BKC, false>,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    QAMD_LAUNCH((gettf_kernel<T, WN, AKC, BKC, false>), dim3(grid), dim3(256), lds, st, a, (const T*)A, (const T*)B,
-                (T*)C, (const int64_t*)ktab, (const T*)sa, (const T*)sb, (T*)amax);
+    QAMD_LAUNCH((gettf_kernel<T, WN, VA, VB, AKC, BKC, false>), dim3(grid), dim3(256), lds, st, a, (const T*)A,
+                (const T*)B, (T*)C, (const int64_t*)ktab, (const T*)sa, (const T*)sb, (T*)amax);
   }
   return hipGetLastError() == hipSuccess ? 0 : -4;
+}
+
+template <typename T, int WN, int VA, int VB>
+static int launch_gettf_v(const GettArgs& a, int swap, const void* A, const void* B, void* C, const void* ktab,
+                          const void* sa, const void* sb, void* amax, hipStream_t st) {
+  if (a.a_kcontig) {
+    if (a.b_kcontig) return launch_gettf_ab<T, WN, VA, VB, true, true>(a, swap, A, B, C, ktab, sa, sb, amax, st);
+    return launch_gettf_ab<T, WN, VA, VB, true, false>(a, swap, A, B, C, ktab, sa, sb, amax, st);
+  }
+  if (a.b_kcontig) return launch_gettf_ab<T, WN, VA, VB, false, true>(a, swap, A, B, C, ktab, sa, sb, amax, st);
+  return launch_gettf_ab<T, WN, VA, VB, false, false>(a, swap, A, B, C, ktab, sa, sb, amax, st);
 }
 
 template <typename T, int WN>
 static int launch_gettf_t(const GettArgs& a, int swap, const void* A, const void* B, void* C, const void* ktab,
                           const void* sa, const void* sb, void* amax, hipStream_t st) {
-  if (a.a_kcontig) {
-    if (a.b_kcontig) return launch_gettf_ab<T, WN, true, true>(a, swap, A, B, C, ktab, sa, sb, amax, st);
-    return launch_gettf_ab<T, WN, true, false>(a, swap, A, B, C, ktab, sa, sb, amax, st);
-  }
-  if (a.b_kcontig) return launch_gettf_ab<T, WN, false, true>(a, swap, A, B, C, ktab, sa, sb, amax, st);
-  return launch_gettf_ab<T, WN, false, false>(a, swap, A, B, C, ktab, sa, sb, amax, st);
+  const bool a4 = a.vec_a >= 4, b4 = a.vec_b >= 4;
+  if (a4 && b4) return launch_gettf_v<T, WN, 4, 4>(a, swap, A, B, C, ktab, sa, sb, amax, st);
+  if (a4) return launch_gettf_v<T, WN, 4, 2>(a, swap, A, B, C, ktab, sa, sb, amax, st);
+  if (b4) return launch_gettf_v<T, WN, 2, 4>(a, swap, A, B, C, ktab, sa, sb, amax, st);
+  return launch_gettf_v<T, WN, 2, 2>(a, swap, A, B, C, ktab, sa, sb, amax, st);
 }
 
 // Preconditions (checked by the host planner): M % 128 == 0, N % bn == 0 (bn = 128 or 64), K % 16 == 0,
-// split_k == 1, vec_a == vec_b == 4 with 16-byte aligned operands.
+// vec_a, vec_b in {2, 4} with operands aligned to min(16, vec * itemsize) bytes.
 extern "C" int qamd_gettf_launch(int dtype, int bn, const GettArgs* a, int swap, const void* A, const void* B, void* C,
                                  const void* ktab, const void* scale_a, const void* scale_b, void* absmax_out,
                                  void* stream) {
   hipStream_t st = (hipStream_t)stream;
-  if (bn != 128 && bn != 64) return -2;
+  if ((bn != 128 && bn != 64) || a->vec_a < 2 || a->vec_b < 2) return -2;
   if (dtype == 0)
     return bn == 128 ? launch_gettf_t<float, 4>(*a, swap, A, B, C, ktab, scale_a, scale_b, absmax_out, st)
                      : launch_gettf_t<float, 2>(*a, swap, A, B, C, ktab, scale_a, scale_b, absmax_out, st);

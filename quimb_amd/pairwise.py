@@ -263,6 +263,10 @@ def plan_pair(a_inds, a_shape, b_inds, b_shape, out_inds, out_fixed=True, death=
     # C for n (so stores along n run through memory in order)
     m_order = sorted(mm, key=lambda ix: -sa[ix])
     k_order = sorted(kk, key=lambda ix: -sa[ix])
+    if not any(sa[ix] == 1 for ix in kk) and any(sb[ix] == 1 for ix in kk):
+        # A is contiguous along a free index, B along a contracted one: the order of the k groups
+        # is free for A, so let B's stride-1 group be the innermost (vector loads along k for B)
+        k_order = sorted(kk, key=lambda ix: -sb[ix])
     b_order = sorted(batch, key=lambda ix: -sa[ix])
     n_order = sorted(nn, key=lambda ix: -sc[ix])
     gm = _fuse(m_order, size, [sa, sc])

@@ -98,3 +98,11 @@ tree = A._expr(0).tree
 fl = tree.total_flops("float64")
 print(f"matvec {t*1e3:8.3f} ms   {fl/t/1e12:6.2f} TF fp64   tree flops {fl:.3e} (survey: 1.095e10)   steps: "
       + ", ".join(f"({i.M}x{i.N}x{i.K})" for i in A._expr(0).executor.info), flush=True)
+# per-step kernels and HIP-event times of the matvec
+dev.profile = []
+A.matvec(x)
+dev.tdev and __import__("torch").cuda.synchronize()
+for spec, dt_, name, sk, e0, e1 in dev.profile:
+    shp = f"M={getattr(spec, 'M', '?')} N={getattr(spec, 'N', '?')} K={getattr(spec, 'K', '?')}"
+    print(f"   {e0.elapsed_time(e1)*1e3:8.1f} us  {name}  split_k={sk}  {shp}")
+dev.profile = None

@@ -368,6 +368,8 @@ FAST_TILE_CASES = [
     ("bmk,bkn->bmn", dict(b=3, m=128, k=32, n=128)),  # batch bundle
     ("mk,kn->mn", dict(m=128, k=4096, n=128)),        # one tile, long K: split-K + slab reduction
     ("xmk,kny->xmny", dict(x=2, m=64, k=256, n=32, y=4)),         # M = (x, m), N = (n, y)
+    ("kms,ksn->mn", dict(k=32, m=128, s=2, n=128)),   # A k-contiguous through a size-2 index: 2-element pieces
+    ("mka,kny->many", dict(m=64, k=64, a=2, n=32, y=2)),          # both free-contiguous through size-2 indices
 ]
 
 
