@@ -146,12 +146,16 @@ int qamd_contract_pair_ex(const qamd_pair_plan* plan, const void* A, const void*
 #define QAMD_CHAIN2_K1_SINGLE 2
 /* row-end shape: n2 = n2_in only (W2p is [D*D][D], offCo_dev has one entry, C ends [.., m_inner, x, n2_in]) */
 #define QAMD_CHAIN2_NO_N2OUT 4
+/* W1p / W2p are the ORIGINAL small tensors, addressed with w1_strides (k1 groups outermost first, x, y) and
+ * w2_strides (y, v, n2_out, n2_in) in elements -- no packed copies (register kernel only) */
+#define QAMD_CHAIN2_W_STRIDED 8
 typedef struct {
   int32_t dtype, D, nm;
   int32_t flags;   /* QAMD_CHAIN2_C_ALIGNED16: every offCo_dev entry and every sc_m of the outer m groups is a multiple of 4
                       elements (with a 16-byte aligned C this lets fp32 use the register-resident kernel) */
   int64_t dim_m[QAMD_MAX_GROUPS], sa_m[QAMD_MAX_GROUPS], sc_m[QAMD_MAX_GROUPS];
   int64_t sa_v;
+  int64_t w1_strides[4], w2_strides[4];   /* read only with QAMD_CHAIN2_W_STRIDED */
 } qamd_chain2_plan;
 /* m-chunk the fused kernel works in for (dtype, D); 0 = combination not supported */
 int qamd_chain2_chunk(int32_t dtype, int32_t D);

@@ -48,6 +48,7 @@ class Chain2PlanStruct(C.Structure):
         ("dtype", C.c_int32), ("D", C.c_int32), ("nm", C.c_int32), ("flags", C.c_int32),
         ("dim_m", _I64G), ("sa_m", _I64G), ("sc_m", _I64G),
         ("sa_v", C.c_int64),
+        ("w1_strides", C.c_int64 * 4), ("w2_strides", C.c_int64 * 4),
     ]
 
 

@@ -663,6 +663,14 @@ extern "C" int qamd_contract_chain2(const qamd_chain2_plan* p, const void* A, co
   if (const char* e = getenv("QAMD_CHAIN2_ABLATE")) a.ablate = (uint32_t)atoi(e);
   const int k1_single = (p->flags & QAMD_CHAIN2_K1_SINGLE) ? 1 : 0, no_n2out = (p->flags & QAMD_CHAIN2_NO_N2OUT) ? 1 : 0;
   if (k1_single && no_n2out) return QAMD_EUNSUPPORTED;
+  if (p->flags & QAMD_CHAIN2_W_STRIDED) {
+    if (!chain2_uses_registers(p, C)) return QAMD_EUNSUPPORTED;   // the LDS-tile kernel wants packed W
+    for (int i = 0; i < 4; ++i) { a.w1s[i] = p->w1_strides[i]; a.w2s[i] = p->w2_strides[i]; }
+  } else {   // dense packed copies: [k1][x][y] and [y][v][n2_out][n2_in]
+    const int64_t N2 = (no_n2out ? 1 : p->D) * (int64_t)p->D;
+    a.w1s[0] = k1_single ? DD : (int64_t)p->D * DD; a.w1s[1] = DD; a.w1s[2] = p->D; a.w1s[3] = 1;
+    a.w2s[0] = (int64_t)p->D * N2; a.w2s[1] = N2; a.w2s[2] = p->D; a.w2s[3] = 1;
+  }
   if (chain2_uses_registers(p, C))
     return qamd_chain2r_launch(p->D, k1_single, no_n2out, &a, A, W1p, W2p, C, offK1_dev, offCo_dev, scale_a, scale_1,
                                scale_2, absmax_out, stream);

@@ -88,7 +88,7 @@ __global__ __launch_bounds__(256, 2) void chain2r_kernel(const Chain2Args p, con
                                                          const float* __restrict__ scale_2,
                                                          float* __restrict__ absmax_out) {
   constexpr int N = D * D, K1 = (K1D == 2 ? D * D : D), KS1 = (K1 + 3) / 4;
-  constexpr int NO = NOD ? D : 1, N2 = NO * D;
+  constexpr int NO = NOD ? D : 1;
   constexpr int SX = (D + 3) / 4;        // slots (registers) per x / per no
   constexpr int NSLOT = D * SX;          // stage 1: used rows of the permuted W1 column order, in units of 4 lane groups
   constexpr int NT = (NSLOT + 3) / 4;    // stage 1: 16-row MFMA tiles
@@ -123,7 +123,8 @@ __global__ __launch_bounds__(256, 2) void chain2r_kernel(const Chain2Args p, con
       const int g = j >> 2, r = j & 3;
       const int slot = 4 * nt + r, x = slot / SX, y = 4 * (slot % SX) + g, k1 = 4 * s + kq;
       const bool ok = slot < NSLOT && y < D && k1 < K1;
-      const float w = W1p[ok ? k1 * N + x * D + y : 0];
+      const int64_t ko = (K1D == 2) ? (k1 / D) * p.w1s[0] + (k1 % D) * p.w1s[1] : k1 * p.w1s[0];
+      const float w = W1p[ok ? ko + x * p.w1s[2] + y * p.w1s[3] : 0];
       wf1[s][nt] = ok ? w : 0.f;
     }
   float wf2[SXF > 0 ? SXF : 1][D][NT2];
@@ -136,7 +137,7 @@ __global__ __launch_bounds__(256, 2) void chain2r_kernel(const Chain2Args p, con
         const int g = j >> 2, r = j & 3;
         const int R = 4 * nt + r, no = R / SX, ni = 4 * (R % SX) + g, y = 4 * sg + kq;
         const bool ok = R < NSLOT2 && ni < D && y < D;
-        const float w = W2p[ok ? (y * D + v) * N2 + no * D + ni : 0];
+        const float w = W2p[ok ? y * p.w2s[0] + v * p.w2s[1] + no * p.w2s[2] + ni * p.w2s[3] : 0];
         wf2[sg][v][nt] = ok ? w : 0.f;
       }
   // merged steps: lane groups 0, 1 <-> (y = 4*(SX-1) + q, v = 2p); groups 2, 3 <-> (y = 4*(SX-1) + q - 2, v = 2p + 1)
@@ -149,7 +150,7 @@ __global__ __launch_bounds__(256, 2) void chain2r_kernel(const Chain2Args p, con
       const int R = 4 * nt + r, no = R / SX, ni = 4 * (R % SX) + g;
       const int y = 4 * (SX - 1) + (kq & 1), v = 2 * pr + (kq >> 1);
       const bool ok = R < NSLOT2 && ni < D && y < D;
-      const float w = W2p[ok ? (y * D + v) * N2 + no * D + ni : 0];
+      const float w = W2p[ok ? y * p.w2s[0] + v * p.w2s[1] + no * p.w2s[2] + ni * p.w2s[3] : 0];
       wf2m[pr][nt] = ok ? w : 0.f;
     }
   const float alpha = 1.f / (rread_scale(scale_a) * rread_scale(scale_1) * rread_scale(scale_2));

@@ -13,7 +13,7 @@ import os
 import numpy as np
 
 from . import _lib
-from .pairwise import GettSpec
+from .pairwise import GettSpec, prod
 
 _DT_CODE = {
     np.dtype("float32"): _lib.QAMD_F32,
@@ -186,9 +186,10 @@ class HipDevice:
             prof.append((spec, np.dtype(dtype), self.describe_pair(cp), cp.struct.split_k, e0, e1))
 
     # ---- fused pair of streaming steps ---------------------------------------------
-    def contract_chain2(self, c2, dtype, a, w1p, w2p, c, ep=None):
-        """C = (A . W1) . W2 in one pass (chain2.hip).  ``c2``: pairwise.Chain2Spec;
-        ``ep`` = (slots_a, slots_w1, slots_w2, slots_out) or None."""
+    def contract_chain2(self, c2, dtype, a, w1, w2, c, ep=None):
+        """C = (A . W1) . W2 in one pass (chain2r.hip / chain2.hip).  ``c2``: pairwise.Chain2Spec;
+        ``w1`` / ``w2``: the small tensors in their own layouts (``c2.w1_pack`` / ``w2_pack`` say how
+        to address them); ``ep`` = (slots_a, slots_w1, slots_w2, slots_out) or None."""
         key = ("chain2", c2, dtype_code(dtype))
         ent = self._pairs.get(key)
         if ent is None:
@@ -203,11 +204,31 @@ class HipDevice:
                 pl.flags |= 2  # QAMD_CHAIN2_K1_SINGLE
             if c2.no_n2out:
                 pl.flags |= 4  # QAMD_CHAIN2_NO_N2OUT
+            buf = C.create_string_buffer(128)
+            _lib.check(self.lib.qamd_chain2_describe(C.byref(pl), buf, 128), "qamd_chain2_describe")
+            name = buf.value.decode()
+            if name.startswith("chain2r"):
+                # the register kernel reads the small tensors in place: no packed copies, no permute launches
+                pl.flags |= 8  # QAMD_CHAIN2_W_STRIDED
+                s1, s2 = list(c2.w1_pack.strides), list(c2.w2_pack.strides)
+                if c2.k1_single:
+                    s1 = [s1[0], 0] + s1[1:]
+                if c2.no_n2out:
+                    s2 = s2[:2] + [0] + s2[2:]
+                for i in range(4):
+                    pl.w1_strides[i], pl.w2_strides[i] = s1[i], s2[i]
             k1 = self.torch.tensor(c2.off_k1, dtype=self.torch.int64, device=self.tdev)
             co = self.torch.tensor(c2.off_co, dtype=self.torch.int64, device=self.tdev)
-            ent = (pl, k1, co)
+            ent = (pl, k1, co, name)
             self._pairs[key] = ent
-        pl, k1, co = ent
+        pl, k1, co, name = ent
+        if pl.flags & 8:
+            w1p, w2p = w1, w2
+        else:
+            w1p = self.empty(prod(c2.w1_pack.shape), dtype)
+            w2p = self.empty(prod(c2.w2_pack.shape), dtype)
+            self.permute(w1p, w1, c2.w1_pack.shape, c2.w1_pack.strides, 0, dtype)
+            self.permute(w2p, w2, c2.w2_pack.shape, c2.w2_pack.strides, 0, dtype)
         ptr = lambda t: (t.data_ptr() if t is not None else None)
         sa = s1 = s2 = so = None
         if ep is not None:
@@ -226,9 +247,7 @@ class HipDevice:
         )
         if prof is not None:
             e1.record()
-            buf = C.create_string_buffer(128)
-            _lib.check(self.lib.qamd_chain2_describe(C.byref(pl), buf, 128), "qamd_chain2_describe")
-            prof.append((c2, np.dtype(dtype), buf.value.decode(), 1, e0, e1))
+            prof.append((c2, np.dtype(dtype), name, 1, e0, e1))
 
     # ---- layout / elementwise -----------------------------------------------
     def permute(self, dst, src, shape, strides, offset, dtype):

@@ -222,17 +222,13 @@ class TreeExecutor:
                 elif only_independent and not independent:
                     continue
                 else:
-                    from .ops import _apply_pre
-
-                    w1p = _apply_pre(live[w1], (c2.w1_pack,))
-                    w2p = _apply_pre(live[w2], (c2.w2_pack,))
                     x = Array.empty(c2.out_shape, self.dtype, dev)
                     ep = None
                     if exponent is not None:
                         ep = tuple(dev.slots_row(slots, s_) if s_ in has_scale else None for s_ in (a, w1, w2))
                         ep = ep + (dev.slots_row(slots, res),)
                         has_scale.add(res)
-                    dev.contract_chain2(c2, self.dtype, live[a]._buf, w1p._buf, w2p._buf, x._buf, ep)
+                    dev.contract_chain2(c2, self.dtype, live[a]._buf, live[w1]._buf, live[w2]._buf, x._buf, ep)
                     live[res] = x
                     if independent and cache is not None:
                         cache[res] = x

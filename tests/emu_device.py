@@ -66,10 +66,13 @@ class EmuDevice:
         assert len(np.unique(idx)) == idx.size, "output offsets collide"
         c[idx] = C
 
-    def contract_chain2(self, c2, dtype, a, w1p, w2p, c, ep=None):
-        """Semantics of qamd_contract_chain2 (see include/quimb_amd.h)."""
+    def contract_chain2(self, c2, dtype, a, w1, w2, c, ep=None):
+        """Semantics of qamd_contract_chain2 (see include/quimb_amd.h); the small tensors arrive in
+        their own layouts and are gathered as ``c2.w1_pack`` / ``w2_pack`` describe."""
         self.calls["chain2"] = self.calls.get("chain2", 0) + 1
         D = c2.D
+        w1p = w1[_offsets(list(zip(c2.w1_pack.shape, c2.w1_pack.strides)), 1)]
+        w2p = w2[_offsets(list(zip(c2.w2_pack.shape, c2.w2_pack.strides)), 1)]
         om_a = _offsets([(d, sa) for d, sa, _ in c2.m], 1)
         om_c = _offsets([(d, sc) for d, _, sc in c2.m], 1)
         ok1 = np.asarray(c2.off_k1, dtype=np.int64)
