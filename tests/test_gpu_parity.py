@@ -216,6 +216,50 @@ def test_peps_6x6_D6_fp32_vs_fp64_oracle(hip):
     assert got == pytest.approx(ref, rel=5e-6)
 
 
+def test_full_size_10x10_D6_properties(hip):
+    """BASELINE config #3 at FULL size (10x10, D=6, fp32: the boundary tensor has 6^11 elements = 1.45 GB, far
+    beyond what the CPU oracle finishes in a test run), checked through size-independent properties:
+    reproducibility, fused == unfused kernels, linearity in one site tensor, slice-sum identity."""
+    import os
+
+    from oracle import np_oracle as orc
+    import quimb_amd as qa
+
+    arrays, inputs = orc.tn2d_rand(10, 10, 6, seed=7, dtype="float32")
+    size = {ix: 6 for t in inputs for ix in t}
+    tree = qa.ContractionTree(inputs, (), size, path=qa.sweep_path_2d(10, 10))
+    ex = qa.TreeExecutor(tree, "float32")
+
+    def log_value(res):
+        m, e = res
+        m = m.to_numpy().item()
+        return np.sign(m), np.log10(abs(m)) + e
+
+    s0, l0 = log_value(ex(arrays, strip_exponent=True))
+    assert np.isfinite(l0) and s0 != 0
+    # reproducibility: same executor, same inputs -> bit-identical (no atomics in the data path)
+    assert log_value(ex(arrays, strip_exponent=True)) == (s0, l0)
+    # fused pairs (chain2r) against one launch per step (sweep kernels)
+    os.environ["QAMD_CHAIN2"] = "0"
+    try:
+        ex_unfused = qa.TreeExecutor(tree, "float32")
+    finally:
+        del os.environ["QAMD_CHAIN2"]
+    assert not any(e[0] == "chain2" for e in ex_unfused.plan) and any(e[0] == "chain2" for e in ex.plan)
+    s1, l1 = log_value(ex_unfused(arrays, strip_exponent=True))
+    assert s1 == s0 and abs(l1 - l0) < 1e-5          # 1e-5 in log10 = 2.3e-5 relative
+    # linearity: Z is linear in every site tensor
+    scaled = list(arrays)
+    scaled[37] = (-3.0 * arrays[37]).astype(np.float32)
+    s2, l2 = log_value(ex(scaled, strip_exponent=True))
+    assert s2 == -s0 and abs(l2 - (l0 + np.log10(3.0))) < 1e-5
+    # slicing one bond: the 6 slices sum to the unsliced value
+    sliced_tree = qa.find_slices(tree, target_slices=6)
+    assert sliced_tree.nslices == 6
+    s3, l3 = log_value(qa.TreeExecutor(sliced_tree, "float32")(arrays, strip_exponent=True))
+    assert s3 == s0 and abs(l3 - l0) < 1e-5
+
+
 def test_no_cpu_fallback(hip):
     """The product device is the HIP one and the shared library is loaded."""
     import quimb_amd.device as qd
