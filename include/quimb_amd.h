@@ -218,6 +218,15 @@ int qamd_strip_exponent(void* x, int64_t n, int32_t dtype, void* scratch_dev,
 /* out_dev[0] (double, device) = max|x|; out_dev must provide 16 bytes (8 of scratch) */
 int qamd_absmax(void* out_dev, const void* x, int64_t n, int32_t dtype, void* stream);
 
+/*
+ * dst[i] = f(src[i]);  op: 0 abs, 1 sqrt, 2 exp, 3 log, 4 log10.  Real dtypes; for C64 / C128 only
+ * op 0, with dst REAL (float / double magnitudes).  Backs do("abs") / do("log10") ... of the
+ * strip_exponent and norm fallbacks (quimb/tensor/array_ops.py:257-263, tensor_core.py:330-340).
+ */
+int qamd_unary(void* dst, const void* src, int64_t n, int32_t op, int32_t dtype, void* stream);
+/* out_dev[0] (same real dtype as x) = max (want_min = 0) or min (want_min = 1) over x[0..n) */
+int qamd_minmax(void* out_dev, const void* x, int64_t n, int32_t want_min, int32_t dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -12,10 +12,12 @@ bound on first use and there is no CPU fallback.
 
 from .array import Array, asarray, to_numpy
 from .ops import (  # noqa: F401  (autoray resolves these by name)
-    absmax, add, array, astype, concatenate, conj, conjugate, divide, dot, einsum, einsum_pair,
-    expand_dims, eye, fuse, imag, matmul, multiply, ndim, negative, norm_fro, ones, ravel, real,
-    reshape, shape, size, squeeze, subtract, sum, take, tensordot, trace, transpose, true_divide, zeros,
+    abs, absolute, absmax, add, amax, amin, array, astype, concatenate, conj, conjugate, diagonal, divide, dot,
+    einsum, einsum_pair, exp, expand_dims, eye, fuse, imag, log, log10, matmul, max, min, multiply, ndim, negative,
+    norm_fro, ones, ravel, real, reshape, shape, size, sqrt, squeeze, subtract, sum, take, tensordot, trace,
+    transpose, true_divide, zeros,
 )
+from . import linalg  # noqa: F401  (do("linalg.svd" / "linalg.qr" / "linalg.eigh" / "linalg.norm"))
 from .contract import (  # noqa: F401
     ContractExpression, Tensor, array_contract, array_contract_expression, array_contract_path,
     array_contract_tree, contract_backend, contract_strategy, get_contract_backend,

@@ -455,8 +455,8 @@ extern "C" int qamd_conj(void* dst, const void* src, int64_t n, int32_t dtype, v
   if (n <= 0) return 0;
   uint32_t grid = flat_grid(n);
   switch (dtype) {
-    case 0: if (dst != src) hipMemcpyAsync(dst, src, (size_t)n * 4, hipMemcpyDeviceToDevice, st); break;
-    case 1: if (dst != src) hipMemcpyAsync(dst, src, (size_t)n * 8, hipMemcpyDeviceToDevice, st); break;
+    case 0: if (dst != src) (void)hipMemcpyAsync(dst, src, (size_t)n * 4, hipMemcpyDeviceToDevice, st); break;
+    case 1: if (dst != src) (void)hipMemcpyAsync(dst, src, (size_t)n * 8, hipMemcpyDeviceToDevice, st); break;
     case 2: QAMD_LAUNCH(conj_kernel<c64>, dim3(grid), dim3(256), 0, st, (c64*)dst, (const c64*)src, n); break;
     case 3: QAMD_LAUNCH(conj_kernel<c128>, dim3(grid), dim3(256), 0, st, (c128*)dst, (const c128*)src, n); break;
     default: return -2;
@@ -491,12 +491,109 @@ extern "C" int qamd_cast(void* dst, int32_t dd, const void* src, int32_t sd, int
   QAMD_CHECK_LAUNCH();
 }
 
+// ---- elementwise maths the autoray boundary asks for (abs / sqrt / exp / log / log10) -------
+template <typename R>
+__device__ __forceinline__ R unary_apply(R v, int op) {
+  switch (op) {
+    case 0: return fabs(v);
+    case 1: return sqrt(v);
+    case 2: return exp(v);
+    case 3: return log(v);
+    default: return log10(v);
+  }
+}
+template <typename R>
+__global__ void unary_kernel(R* __restrict__ dst, const R* __restrict__ src, int64_t n, int op, int cplx_abs) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  if (cplx_abs) {
+    for (; i < n; i += stride) {
+      R re = src[2 * i], im = src[2 * i + 1];
+      dst[i] = sqrt(re * re + im * im);
+    }
+  } else {
+    for (; i < n; i += stride) dst[i] = unary_apply(src[i], op);
+  }
+}
+
+// max / min over a real array: wave reduction + one compare-and-swap per wave on the value's bits
+template <typename R> struct MmBits;
+template <> struct MmBits<float> {
+  typedef unsigned int u;
+  static __device__ __forceinline__ u to(float v) { return __float_as_uint(v); }
+  static __device__ __forceinline__ float from(u b) { return __uint_as_float(b); }
+};
+template <> struct MmBits<double> {
+  typedef unsigned long long u;
+  static __device__ __forceinline__ u to(double v) { return (u)__double_as_longlong(v); }
+  static __device__ __forceinline__ double from(u b) { return __longlong_as_double((long long)b); }
+};
+template <typename R>
+__global__ void minmax_init_kernel(R* out, int want_min) { out[0] = want_min ? R(INFINITY) : R(-INFINITY); }
+template <typename R>
+__global__ __launch_bounds__(256) void minmax_kernel(R* __restrict__ out, const R* __restrict__ x, int64_t n,
+                                                      int want_min) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  R m = want_min ? R(INFINITY) : R(-INFINITY);
+  for (; i < n; i += stride) {
+    R v = x[i];
+    m = want_min ? (v < m ? v : m) : (v > m ? v : m);
+  }
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) {
+    R o = __shfl_down(m, d, 64);
+    m = want_min ? (o < m ? o : m) : (o > m ? o : m);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    typedef typename MmBits<R>::u u;
+    u* po = reinterpret_cast<u*>(out);
+    u old = *po;
+    while (true) {
+      R cur = MmBits<R>::from(old);
+      if (want_min ? !(m < cur) : !(m > cur)) break;
+      u prev = atomicCAS(po, old, MmBits<R>::to(m));
+      if (prev == old) break;
+      old = prev;
+    }
+  }
+}
+
+extern "C" int qamd_unary(void* dst, const void* src, int64_t n, int32_t op, int32_t dtype, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype < 0 || dtype > 3 || op < 0 || op > 4) return -2;
+  if (dtype >= 2 && op != 0) return -2;   // complex: only abs (-> real magnitudes)
+  if (n <= 0) return 0;
+  const int cplx = dtype >= 2;
+  if (dtype == 0 || dtype == 2)
+    QAMD_LAUNCH(unary_kernel<float>, dim3(flat_grid(n)), dim3(256), 0, st, (float*)dst, (const float*)src, n, op, cplx);
+  else
+    QAMD_LAUNCH(unary_kernel<double>, dim3(flat_grid(n)), dim3(256), 0, st, (double*)dst, (const double*)src, n, op, cplx);
+  QAMD_CHECK_LAUNCH();
+}
+
+extern "C" int qamd_minmax(void* out_dev, const void* x, int64_t n, int32_t want_min, int32_t dtype, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype != 0 && dtype != 1) return -2;
+  if (n <= 0) return -1;
+  uint32_t grid = flat_grid(n);
+  if (grid > 1024) grid = 1024;
+  if (dtype == 0) {
+    QAMD_LAUNCH(minmax_init_kernel<float>, dim3(1), dim3(1), 0, st, (float*)out_dev, want_min);
+    QAMD_LAUNCH(minmax_kernel<float>, dim3(grid), dim3(256), 0, st, (float*)out_dev, (const float*)x, n, want_min);
+  } else {
+    QAMD_LAUNCH(minmax_init_kernel<double>, dim3(1), dim3(1), 0, st, (double*)out_dev, want_min);
+    QAMD_LAUNCH(minmax_kernel<double>, dim3(grid), dim3(256), 0, st, (double*)out_dev, (const double*)x, n, want_min);
+  }
+  QAMD_CHECK_LAUNCH();
+}
+
 extern "C" int qamd_absmax(void* out_dev, const void* x, int64_t n, int32_t dtype, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   if (dtype < 0 || dtype > 3) return -2;
   // the 8 bytes after out_dev[0] are used as scratch: out_dev must be >= 16 bytes
   void* scratch = (char*)out_dev + 8;
-  hipMemsetAsync(scratch, 0, 8, st);
+  (void)hipMemsetAsync(scratch, 0, 8, st);
   uint32_t grid = flat_grid(n);
   if (grid > 1024) grid = 1024;
   int cplx = dtype >= 2;
@@ -515,7 +612,7 @@ extern "C" int qamd_strip_exponent(void* x, int64_t n, int32_t dtype, void* scra
   hipStream_t st = (hipStream_t)stream;
   if (dtype < 0 || dtype > 3) return -2;
   if (n <= 0) return 0;
-  hipMemsetAsync(scratch_dev, 0, 8, st);
+  (void)hipMemsetAsync(scratch_dev, 0, 8, st);
   uint32_t grid = flat_grid(n);
   if (grid > 1024) grid = 1024;
   int cplx = dtype >= 2;

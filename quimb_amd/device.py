@@ -360,6 +360,25 @@ class HipDevice:
         return float(self._scratch.cpu()[2])
 
 
+    _UNARY = {"abs": 0, "sqrt": 1, "exp": 2, "log": 3, "log10": 4}
+
+    def unary(self, dst, src, n, op, dtype):
+        """dst[i] = op(src[i]); complex dtypes support only ``abs`` (dst real)."""
+        _lib.check(
+            self.lib.qamd_unary(dst.data_ptr(), src.data_ptr(), int(n), self._UNARY[op], dtype_code(dtype), self.stream()),
+            "qamd_unary",
+        )
+
+    def minmax(self, x, n, want_min, dtype):
+        """1-element device buffer holding max (or min) of a real array."""
+        out = self.empty(1, dtype)
+        _lib.check(
+            self.lib.qamd_minmax(out.data_ptr(), x.data_ptr(), int(n), 1 if want_min else 0, dtype_code(dtype), self.stream()),
+            "qamd_minmax",
+        )
+        return out
+
+
 _DEFAULT = None
 
 

@@ -9,6 +9,7 @@ quimb/tensor/tensor_core.py:3793 (``do("tensordot")``), :3152-3159
 tensor_core.py:2332 (``take``).
 """
 
+import builtins
 import numbers
 
 import numpy as np
@@ -213,7 +214,7 @@ def fuse(x, *axes_groups):
     if not any(groups):
         return x
     in_group = {a for g in groups for a in g}
-    position = min(in_group)
+    position = builtins.min(in_group)
     before = [ax for ax in range(position) if ax not in in_group]
     after = [ax for ax in range(position, x.ndim) if ax not in in_group]
     perm = before + [ax for g in groups for ax in g] + after
@@ -337,6 +338,85 @@ def trace(x):
     return _einsum_single(x, ("i", "i"), ())
 
 
+def _unary(x, op):
+    if not isinstance(x, Array):          # python / numpy scalars and arrays keep numpy semantics
+        return getattr(np, "abs" if op == "abs" else op)(x)
+    if x.dtype.kind == "c" and op != "abs":
+        raise TypeError(f"quimb_amd.{op}: complex arrays are not supported")
+    out = Array.empty(x.shape, _REAL_OF[x.dtype], x._dev)
+    if out.size:
+        x._dev.unary(out._buf, x._buf, x.size, op, x.dtype)
+    return out
+
+
+def abs(x):  # noqa: A001  (autoray resolves do("abs") by this name)
+    """Elementwise magnitude (real result for complex input) -- ``do("abs", x)`` of the
+    strip_exponent / norm fallbacks (quimb/tensor/tensor_core.py:330-340, array_ops.py:257-263)."""
+    return _unary(x, "abs")
+
+
+absolute = abs
+
+
+def sqrt(x):
+    return _unary(x, "sqrt")
+
+
+def exp(x):
+    return _unary(x, "exp")
+
+
+def log(x):
+    return _unary(x, "log")
+
+
+def log10(x):
+    return _unary(x, "log10")
+
+
+def _minmax(x, want_min, axis=None):
+    if not isinstance(x, Array):
+        return (np.min if want_min else np.max)(x, axis=axis)
+    if axis is not None:
+        raise NotImplementedError("quimb_amd.max / min reduce over the whole array only")
+    if x.dtype.kind == "c":
+        raise TypeError("quimb_amd.max / min: complex arrays are not ordered")
+    if x.size == 0:
+        raise ValueError("zero-size array has no maximum")
+    return Array(x._dev, x._dev.minmax(x._buf, x.size, want_min, x.dtype), (), x.dtype)
+
+
+def max(x, axis=None):  # noqa: A001
+    """Maximum over all elements as a 0-d device array (``do("max", do("abs", x))``)."""
+    return _minmax(x, False, axis)
+
+
+def min(x, axis=None):  # noqa: A001
+    return _minmax(x, True, axis)
+
+
+amax, amin = max, min
+
+
+def diagonal(x, offset=0, axis1=0, axis2=1):
+    """numpy.diagonal semantics: the diagonal becomes the LAST axis (one strided copy)."""
+    x = asarray(x)
+    nd = x.ndim
+    axis1, axis2 = axis1 % nd, axis2 % nd
+    if axis1 == axis2:
+        raise ValueError("axis1 and axis2 cannot be the same")
+    st = contig_strides(x.shape)
+    d1, d2 = x.shape[axis1], x.shape[axis2]
+    if offset >= 0:
+        n, off = builtins.max(builtins.min(d1, d2 - offset), 0), offset * st[axis2]
+    else:
+        n, off = builtins.max(builtins.min(d1 + offset, d2), 0), -offset * st[axis1]
+    keep = [a for a in range(nd) if a not in (axis1, axis2)]
+    shape = [x.shape[a] for a in keep] + [n]
+    strides = [st[a] for a in keep] + [st[axis1] + st[axis2]]
+    return x._strided_copy(shape, strides, off if n else 0)
+
+
 def absmax(x):
     """max |x| as a python float (one device reduction + 8-byte read-back)."""
     x = asarray(x)
@@ -349,7 +429,7 @@ def norm_fro(x):
     x = asarray(x)
     v = x.ravel()
     out, _ = einsum_pair(v.conj(), ("i",), v, ("i",), (), True)
-    return float(np.sqrt(abs(out.item())))
+    return float(np.sqrt(builtins.abs(out.item())))
 
 
 def zeros(shape, dtype="float64", **_):

@@ -140,8 +140,34 @@ def check_layout_ops(dtype, seed=2):
     assert_close(qa.trace(qa.asarray(x[0, :4, :4, 0, 0])).to_numpy(), np.trace(x[0, :4, :4, 0, 0]), dtype)
     assert abs(qa.absmax(X) - np.max(np.abs(x))) <= 1e-6 * np.max(np.abs(x))
     assert abs(qa.norm_fro(X) - np.linalg.norm(x.ravel())) <= 1e-5 * np.linalg.norm(x.ravel())
+    # the elementwise / reduction names of the autoray boundary (abs, max, log10, diagonal ...)
+    assert_close(qa.abs(X).to_numpy(), np.abs(x), dtype)
+    assert qa.abs(X).dtype == np.abs(x).dtype
+    if np.dtype(dtype).kind != "c":
+        assert qa.max(X).item() == x.max() and qa.min(X).item() == x.min()
+        assert qa.max(X).shape == ()
+        pos = qa.abs(X) + 0.25
+        for fn, ref in ((qa.sqrt, np.sqrt), (qa.log, np.log), (qa.log10, np.log10), (qa.exp, np.exp)):
+            assert_close(fn(pos).to_numpy(), ref(np.abs(x) + np.asarray(0.25, x.dtype)), dtype)
+        # the reference's strip_exponent idiom: log10(max(abs(x)))  (tensor_core.py:330-340)
+        want = np.log10(np.max(np.abs(x)))
+        assert abs(qa.log10(qa.max(qa.abs(X))).item() - want) <= 1e-6 * max(1.0, abs(want))
+    assert qa.log10(100.0) == 2.0 and qa.max([1, 5, 2]) == 5   # non-device inputs keep numpy semantics
+    for off, a1, a2 in [(0, 0, 1), (1, 1, 3), (-2, 3, 2), (0, 4, 0)]:
+        np.testing.assert_array_equal(qa.diagonal(X, off, a1, a2).to_numpy(), np.diagonal(x, off, a1, a2))
     np.testing.assert_array_equal(qa.einsum("abcde->eb", X).to_numpy().shape, (2, 4))
     assert_close(qa.einsum("abcde->eb", X).to_numpy(), np.einsum("abcde->eb", x), dtype)
+
+
+def check_complex_abs(seed=21):
+    """|z| of complex arrays comes back REAL (numpy semantics) -- the norm / strip fallbacks rely on it."""
+    rng = np.random.default_rng(seed)
+    for dtype in ("complex64", "complex128"):
+        z = rand(rng, (7, 5, 3), dtype)
+        got = qa.abs(qa.asarray(z))
+        assert got.dtype == np.abs(z).dtype
+        assert_close(got.to_numpy(), np.abs(z), got.dtype)
+        assert abs(qa.max(got).item() - np.abs(z).max()) <= 1e-6 * np.abs(z).max()
 
 
 def rand_reg_network(n, deg, D, rng, dtype, n_out=0):

@@ -175,3 +175,13 @@ class EmuDevice:
 
     def absmax(self, x, n, dtype):
         return float(np.max(np.abs(x[:n]))) if n else 0.0
+
+    def unary(self, dst, src, n, op, dtype):
+        fn = {"abs": np.abs, "sqrt": np.sqrt, "exp": np.exp, "log": np.log, "log10": np.log10}[op]
+        with np.errstate(all="ignore"):
+            dst[:n] = fn(src[:n])
+
+    def minmax(self, x, n, want_min, dtype):
+        out = self.empty(1, dtype)
+        out[0] = np.min(x[:n]) if want_min else np.max(x[:n])
+        return out

@@ -163,6 +163,10 @@ def test_tensor_network_semantics(hip):
     checks.check_tensor_network_semantics()
 
 
+def test_complex_abs(hip):
+    checks.check_complex_abs()
+
+
 def test_hyper_network(hip):
     checks.check_hyper_network("float64")
     checks.check_hyper_network("float32")

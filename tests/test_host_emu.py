@@ -33,6 +33,10 @@ def test_fast_tile_shapes(emu):
     checks.check_fast_tiles("float32")
 
 
+def test_complex_abs(emu):
+    checks.check_complex_abs()
+
+
 def test_hyper_network(emu):
     checks.check_hyper_network("float64")
 
