@@ -196,6 +196,13 @@ int qamd_binary(void* out, const void* a, const int64_t* a_strides, const void* 
 int qamd_scale(void* x, int64_t n, double re, double im, int32_t dtype, void* stream);
 /* y = y * fy + x * fx  with real factors (slice accumulation). */
 int qamd_axpby(void* y, const void* x, int64_t n, double fy, double fx, int32_t dtype, void* stream);
+/*
+ * Slice accumulation with device-resident exponents (no host round trip per slice):
+ *   y * 10^(*y_exp) + x * 10^(*x_exp)  ->  y * 10^max(*y_exp, *x_exp);  *y_exp <- the max.
+ * Exponents are doubles in device memory; -inf marks "nothing accumulated yet".
+ */
+int qamd_axpby_exp(void* y, const void* x, int64_t n, void* y_exp_dev, const void* x_exp_dev, int32_t dtype,
+                   void* stream);
 int qamd_conj(void* dst, const void* src, int64_t n, int32_t dtype, void* stream);
 int qamd_cast(void* dst, int32_t dst_dtype, const void* src, int32_t src_dtype, int64_t n, void* stream);
 int qamd_fill(void* dst, int64_t n, double re, double im, int32_t dtype, void* stream);

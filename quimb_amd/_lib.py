@@ -84,6 +84,7 @@ SYMBOLS = [
     ("qamd_binary", C.c_int, [_vp, _vp, _pi64, _vp, _pi64, _i32, _pi64, _i32, _i32, _vp]),
     ("qamd_scale", C.c_int, [_vp, _i64, _dbl, _dbl, _i32, _vp]),
     ("qamd_axpby", C.c_int, [_vp, _vp, _i64, _dbl, _dbl, _i32, _vp]),
+    ("qamd_axpby_exp", C.c_int, [_vp, _vp, _i64, _vp, _vp, _i32, _vp]),
     ("qamd_conj", C.c_int, [_vp, _vp, _i64, _i32, _vp]),
     ("qamd_cast", C.c_int, [_vp, _i32, _vp, _i32, _i64, _vp]),
     ("qamd_fill", C.c_int, [_vp, _i64, _dbl, _dbl, _i32, _vp]),

@@ -214,6 +214,22 @@ __global__ void axpby_kernel(R* __restrict__ y, const R* __restrict__ x, int64_t
   int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (; i < n; i += stride) y[i] = y[i] * fy + x[i] * fx;
 }
+// y * 10^ye + x * 10^xe  ->  y * 10^max(ye, xe), exponents on the device (slice accumulation
+// without a host round trip); the exponent itself is advanced by a second one-thread kernel
+template <typename R>
+__global__ void axpby_exp_kernel(R* __restrict__ y, const R* __restrict__ x, int64_t n,
+                                 const double* __restrict__ ye, const double* __restrict__ xe) {
+  const double a = ye[0], b = xe[0];
+  const double m = a > b ? a : b;
+  const R fy = (R)(isfinite(a) ? pow(10.0, a - m) : 0.0), fx = (R)(isfinite(b) ? pow(10.0, b - m) : 0.0);
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) y[i] = y[i] * fy + x[i] * fx;
+}
+__global__ void max_exp_kernel(double* ye, const double* xe) {
+  const double a = ye[0], b = xe[0];
+  ye[0] = a > b ? a : b;
+}
 template <typename C>
 __global__ void conj_kernel(C* __restrict__ dst, const C* __restrict__ src, int64_t n) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -447,6 +463,24 @@ extern "C" int qamd_axpby(void* y, const void* x, int64_t n, double fy, double f
     QAMD_LAUNCH(axpby_kernel<double>, dim3(grid), dim3(256), 0, st, (double*)y, (const double*)x, nr, fy, fx);
   else
     return -2;
+  QAMD_CHECK_LAUNCH();
+}
+
+extern "C" int qamd_axpby_exp(void* y, const void* x, int64_t n, void* y_exp_dev, const void* x_exp_dev, int32_t dtype,
+                              void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype < 0 || dtype > 3 || !y_exp_dev || !x_exp_dev) return -2;
+  int64_t nr = dtype >= 2 ? 2 * n : n;
+  if (nr > 0) {
+    uint32_t grid = flat_grid(nr);
+    if (dtype == 0 || dtype == 2)
+      QAMD_LAUNCH(axpby_exp_kernel<float>, dim3(grid), dim3(256), 0, st, (float*)y, (const float*)x, nr,
+                  (const double*)y_exp_dev, (const double*)x_exp_dev);
+    else
+      QAMD_LAUNCH(axpby_exp_kernel<double>, dim3(grid), dim3(256), 0, st, (double*)y, (const double*)x, nr,
+                  (const double*)y_exp_dev, (const double*)x_exp_dev);
+  }
+  QAMD_LAUNCH(max_exp_kernel, dim3(1), dim3(1), 0, st, (double*)y_exp_dev, (const double*)x_exp_dev);
   QAMD_CHECK_LAUNCH();
 }
 

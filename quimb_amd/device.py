@@ -288,6 +288,17 @@ class HipDevice:
             "qamd_axpby",
         )
 
+    def axpby_exp(self, y, x, n, y_exp, x_exp, dtype):
+        """y*10^y_exp + x*10^x_exp -> y*10^max(...) with both exponents on the device; y_exp is advanced."""
+        _lib.check(
+            self.lib.qamd_axpby_exp(y.data_ptr(), x.data_ptr(), int(n), y_exp.data_ptr(), x_exp.data_ptr(),
+                                    dtype_code(dtype), self.stream()),
+            "qamd_axpby_exp",
+        )
+
+    def new_exponent_neg_inf(self):
+        return self.torch.full((1,), float("-inf"), dtype=self.torch.float64, device=self.tdev)
+
     def conj(self, dst, src, n, dtype):
         _lib.check(self.lib.qamd_conj(dst.data_ptr(), src.data_ptr(), int(n), dtype_code(dtype), self.stream()), "qamd_conj")
 

@@ -310,19 +310,17 @@ class TreeExecutor:
         todo = range(nsl) if slices is None else list(slices)
         cache = {} if (hoist and not strip_exponent) else None
         acc, acc_e = None, None
+        acc_exp = None   # device-resident exponent of the running sum: the slice loop never syncs with the host
         for s in todo:
             vals = self._slice_values(s)
             ins = [self._slice_input(x, i, vals) for i, x in enumerate(xs)]
             if strip_exponent:
                 exponent = dev.new_exponent()
                 out = self._run_core(ins, exponent, None)
-                e = dev.read_exponent(exponent)
                 if acc is None:
-                    acc, acc_e = out.copy() if out is ins[0] else out, e
-                else:
-                    e_new = max(acc_e, e)
-                    dev.axpby(acc._buf, out._buf, acc.size, 10.0 ** (acc_e - e_new), 10.0 ** (e - e_new), acc.dtype)
-                    acc_e = e_new
+                    acc = Array.full(out.shape, 0.0, out.dtype, dev)
+                    acc_exp = dev.new_exponent_neg_inf()
+                dev.axpby_exp(acc._buf, out._buf, acc.size, acc_exp, exponent, acc.dtype)
             else:
                 out = self._run_core(ins, None, cache)
                 if acc is None:
@@ -332,6 +330,8 @@ class TreeExecutor:
         if acc is None:  # this rank owns no slices
             acc = Array.full([tree.size_dict[ix] for ix in tree.output], 0.0, self.dtype, dev)
             acc_e = float("-inf") if strip_exponent else None
+        elif strip_exponent:
+            acc_e = dev.read_exponent(acc_exp)   # the one read-back of the whole slice loop
         return (acc, acc_e) if strip_exponent else acc
 
 

@@ -124,6 +124,17 @@ class EmuDevice:
     def axpby(self, y, x, n, fy, fx, dtype):
         y[:n] = y[:n] * fy + x[:n] * fx
 
+    def axpby_exp(self, y, x, n, y_exp, x_exp, dtype):
+        a, b = float(y_exp[0]), float(x_exp[0])
+        m = max(a, b)
+        fy = 10.0 ** (a - m) if np.isfinite(a) else 0.0
+        fx = 10.0 ** (b - m) if np.isfinite(b) else 0.0
+        y[:n] = y[:n] * np.asarray(fy, y.real.dtype) + x[:n] * np.asarray(fx, x.real.dtype)
+        y_exp[0] = m
+
+    def new_exponent_neg_inf(self):
+        return np.full(1, -np.inf)
+
     def conj(self, dst, src, n, dtype):
         dst[:n] = np.conj(src[:n])
 
