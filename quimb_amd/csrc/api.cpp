@@ -93,6 +93,25 @@ static int stream_lds_bytes(int64_t K, int64_t N, int es) {
 
 static int64_t c_extent(const qamd_pair_plan* p);
 
+// "few rows x one long vector" (dotm.hip): M*N <= 32 with one of them 1, K one stride-1 group in
+// both operands.  Fills the row offsets; returns false if the shape does not qualify.
+static bool dot_rows(const qamd_pair_plan* p, const PairDims& d, DotArgs& a) {
+  if (p->nb != 0 || p->nk != 1 || p->sa_k[0] != 1 || p->sb_k[0] != 1) return false;
+  const bool rows_a = d.N == 1 && d.M <= 32, rows_b = d.M == 1 && d.N <= 32 && !rows_a;
+  if (!rows_a && !rows_b) return false;
+  const int ng = rows_a ? p->nm : p->nn;
+  const int64_t* dims = rows_a ? p->dim_m : p->dim_n;
+  const int64_t* str = rows_a ? p->sa_m : p->sb_n;
+  a.S = (int32_t)(rows_a ? d.M : d.N);
+  a.K = d.K;
+  for (int s = 0; s < a.S; ++s) {
+    int64_t idx = s, off = 0;
+    for (int g = ng - 1; g >= 0; --g) { off += (idx % dims[g]) * str[g]; idx /= dims[g]; }
+    a.row_off[s] = off;
+  }
+  return true;
+}
+
 extern "C" int qamd_pair_plan_finalize(qamd_pair_plan* p, int64_t align_a, int64_t align_b, int64_t align_c) {
   PairDims d;
   int rc = pair_dims(p, d);
@@ -168,8 +187,25 @@ extern "C" int qamd_pair_plan_finalize(qamd_pair_plan* p, int64_t align_a, int64
       kern = 1;
     }
     p->vec_c = vc;
+    // kernel 4: reduction-shaped (norms, projections onto a few vectors): streaming multi-dot
+    if (!kern && d.K >= 32768 && align_a % 16 == 0 && align_b % 16 == 0 && c_extent(p) == d.M * d.N) {
+      DotArgs da;
+      if (dot_rows(p, d, da)) {
+        const int ev = 16 / es;
+        bool ok = true;
+        for (int s = 0; s < da.S; ++s) ok = ok && (da.row_off[s] % ev == 0);
+        if (ok) kern = 4;
+      }
+    }
     if (p->kernel == -1) p->kernel = 0;  // caller forces the tiled kernel
     else p->kernel = kern;
+  }
+  if (p->kernel == 4) {
+    // one slab of partial sums per workgroup; every workgroup streams >= 2 x 256 16-byte vectors per row
+    const int64_t nvec = d.K / (16 / es);
+    p->split_k = (int32_t)std::max<int64_t>(1, std::min<int64_t>(1024, nvec / (256 * 2)));
+    p->tile_cfg = 1;
+    return QAMD_OK;
   }
 
   // ---- tile shape -----------------------------------------------------------
@@ -348,6 +384,17 @@ extern "C" int qamd_contract_pair_ex(const qamd_pair_plan* p, const void* A, con
   if (p->tile_cfg < 0 || p->tile_cfg >= kNumTileCfg || p->split_k < 1) return QAMD_EINVAL;
   if (!A || !B || !C || !ktab) return QAMD_EINVAL;
   if (p->kernel == 1 || p->kernel == 2) return launch_stream(p, d, A, B, C, ktab, ep, stream);
+  if (p->kernel == 4) {
+    DotArgs da;
+    memset(&da, 0, sizeof(da));
+    if (!dot_rows(p, d, da) || ((uintptr_t)A & 15) || ((uintptr_t)B & 15)) return QAMD_EINVAL;
+    da.grid = (uint32_t)p->split_k;
+    const int64_t csz = d.M * d.N;
+    if (!ws || ws_bytes < (int64_t)p->split_k * csz * kEsize[p->dtype]) return QAMD_EWORKSPACE;
+    const bool rows_a = d.N == 1 && d.M <= 32;
+    return qamd_dotm_launch(p->dtype, &da, rows_a ? A : B, rows_a ? B : A, ws, C, ep ? ep->scale_a : nullptr,
+                            ep ? ep->scale_b : nullptr, ep ? ep->absmax_out : nullptr, stream);
+  }
   const int bm = kTileBM[p->tile_cfg], bn = kTileBN[p->tile_cfg];
   const void* sa = ep ? ep->scale_a : nullptr;
   const void* sb = ep ? ep->scale_b : nullptr;
@@ -577,6 +624,10 @@ extern "C" int qamd_pair_describe(const qamd_pair_plan* p, char* buf, int32_t bu
   int rc = pair_dims(p, d);
   if (rc || !buf || buflen <= 0) return QAMD_EINVAL;
   const char* T = p->dtype == QAMD_F32 ? "float" : (p->dtype == QAMD_F64 ? "double" : "?");
+  if (p->kernel == 4) {
+    snprintf(buf, buflen, "dotm_kernel<%s, %d>", T, (int)std::max(d.M, d.N));
+    return QAMD_OK;
+  }
   if (p->kernel == 1 || p->kernel == 2) {
     StreamArgs s;
     fill_stream_args(p, d, s);

@@ -51,6 +51,14 @@ struct Chain2Args {
   uint32_t ablate;  // debug/ablation bits (QAMD_CHAIN2_ABLATE): 1 no stores, 2 no stage-1 scatter, 4 no loads, 8 no stage 2
 };
 
+// few rows x one long vector (dotm.hip)
+struct DotArgs {
+  int32_t S;            // rows (<= 32)
+  int64_t K;            // length of the contraction, stride 1 in both operands
+  int64_t row_off[32];  // element offset of every row
+  uint32_t grid;        // workgroups = slabs of partial sums
+};
+
 struct KtabArgs {
   int32_t nk;
   uint32_t K, Kpad;
@@ -66,6 +74,8 @@ int qamd_gett_launch(int dtype, int cfg, const GettArgs* a, int swap, const void
                      void* stream);
 int qamd_gettf_launch(int dtype, int bn, const GettArgs* a, int swap, const void* A, const void* B, void* C,
                       const void* ktab, const void* scale_a, const void* scale_b, void* absmax_out, void* stream);
+int qamd_dotm_launch(int dtype, const DotArgs* a, const void* R, const void* v, void* slab, void* C,
+                     const void* scale_a, const void* scale_b, void* absmax_out, void* stream);
 int qamd_stream_launch(int dtype, int V, const StreamArgs* a, const void* A, const void* B, void* C,
                        const void* ktab, const void* scale_a, const void* scale_b, void* absmax_out,
                        void* stream);

@@ -1,0 +1,119 @@
+"""Device-resident Lanczos for the lowest / highest eigenpair of a Hermitian operator.
+
+Caller side of the hot path: DMRG's local solve
+(``DMRG._eigs`` -> ``eigh(A, k=1, which=..., v0=..., ncv=..., tol=..., maxiter=...)``,
+quimb/tensor/tn1d/dmrg.py:626-645, answered in the reference by
+``quimb.linalg.base_linalg.eigensystem_partial`` -> scipy ARPACK, base_linalg.py:80) calls
+``A.matvec`` 10-30 times per site.  With ARPACK the Krylov vectors live on the host, so
+every matvec of a device operator pays two PCIe copies of the (chi*d*d*chi) vector; here
+the basis ``Q[m, n]``, the matvecs (``TNLinearOperator``: cached contraction expression
+on the GETT kernels) and the re-orthogonalisation GEMVs all stay in HBM, and only the
+(j+1) projection coefficients and one norm per iteration cross to the host, where the
+tiny tridiagonal problem is solved.
+
+Same call shape as the reference's ``eigh`` for the arguments DMRG passes; returns
+``(eigenvalues, eigenvectors)`` with eigenvectors as a device ``Array`` of shape (n, k).
+"""
+
+import numpy as np
+
+from . import ops
+from .array import Array, asarray
+
+
+def _matvec(A, x):
+    if hasattr(A, "matvec"):
+        return asarray(A.matvec(x))
+    return ops.matmul(A, x)
+
+
+def eigh_lanczos(A, k=1, which="SA", v0=None, ncv=None, tol=1e-10, maxiter=None, return_vecs=True):
+    """``k`` extremal eigenpairs of the Hermitian operator ``A`` (anything with ``.shape``, ``.dtype`` and
+    ``.matvec`` on device arrays -- a ``TNLinearOperator`` -- or a dense device matrix).
+
+    Lanczos with full re-orthogonalisation in a basis of ``ncv`` device vectors and explicit restart
+    from the current Ritz vector(s); converged when every wanted Ritz pair has residual
+    ``|beta_m s_m| <= tol * max(|theta|, 1)`` (``tol = 0`` means machine precision, as in scipy).
+    ``which``: "SA" (algebraically smallest) or "LA" (largest)."""
+    if which not in ("SA", "LA"):
+        raise ValueError("which must be 'SA' or 'LA'")
+    n = int(A.shape[0])
+    dtype = np.dtype(A.dtype)
+    rdt = np.zeros(0, dtype).real.dtype
+    eps = np.finfo(rdt).eps
+    tol = float(tol) if tol else 10 * eps
+    k = int(k)
+    if not 1 <= k < n:
+        raise ValueError("need 1 <= k < n")
+    m = int(ncv) if ncv else max(2 * k + 1, 20)
+    m = max(min(m, n), k + 1)
+    maxiter = int(maxiter) if maxiter else 10 * n
+    if v0 is None:
+        rng = np.random.default_rng(0)
+        v0 = rng.standard_normal(n).astype(rdt)
+        if dtype.kind == "c":
+            v0 = v0 + 1j * rng.standard_normal(n).astype(rdt)
+    q = asarray(v0).astype(dtype).reshape(n)
+    dev = q._dev
+    # basis rows beyond the current step are kept at zero, so that every projection runs on the SAME
+    # (m + 1, n) shape: one cached kernel plan for the whole solve instead of one per step
+    Q = Array.full((m + 1, n), 0.0, dtype, dev)
+    passes = 1 if rdt == np.float64 else 2   # classical Gram-Schmidt twice in single precision
+
+    def put(row, vec):      # Q[row] <- vec  (device-to-device, one strided copy)
+        dev.permute(Q._buf[row * n:], vec._buf, (n,), (1,), 0, dtype)
+
+    def norm(x):
+        return float(np.sqrt(abs(ops.tensordot(x.conj(), x, axes=([0], [0])).item())))
+
+    nmv = 0
+    nrm = norm(q)
+    if nrm == 0:
+        raise ValueError("v0 is zero")
+    put(0, q / nrm)
+    theta = S = None
+    while True:
+        alphas, betas = [], []
+        j_done = 0
+        for j in range(m):
+            qj = Array(dev, Q._buf[j * n:], (n,), dtype)
+            w = _matvec(A, qj)
+            nmv += 1
+            # full re-orthogonalisation against the whole basis: h = Q^H w ; w -= Q^T h
+            Qc = Q.conj()
+            hh = np.zeros(m + 1, dtype)
+            for _ in range(passes):
+                h = ops.tensordot(Qc, w, axes=([1], [0]))
+                w = w - ops.tensordot(h, Q, axes=([0], [0]))
+                hh = hh + h.to_numpy()
+            alphas.append(float(np.real(hh[j])))
+            beta = norm(w)
+            betas.append(beta)
+            j_done = j + 1
+            # Ritz values of the (j+1) x (j+1) tridiagonal matrix
+            T = np.diag(alphas) + np.diag(betas[:-1], 1) + np.diag(betas[:-1], -1)
+            evals, evecs = np.linalg.eigh(T)
+            order = np.argsort(evals) if which == "SA" else np.argsort(-evals)
+            kk = min(k, j_done)
+            theta, S = evals[order[:kk]], evecs[:, order[:kk]]
+            resid = np.abs(beta * S[-1, :])
+            if j_done >= k and np.all(resid <= tol * np.maximum(np.abs(theta), 1.0)):
+                break
+            if beta <= eps * max(abs(alphas[-1]), 1.0) or j + 1 == m:
+                break                                  # invariant subspace found, or basis full
+            put(j + 1, w / beta)
+        Sfull = np.zeros((m + 1, S.shape[1]), dtype)
+        Sfull[:j_done] = S
+        X = ops.tensordot(asarray(Sfull), Q, axes=([0], [0]))               # (k, n) Ritz vectors
+        converged = np.all(np.abs(betas[-1] * S[-1, :]) <= tol * np.maximum(np.abs(theta), 1.0)) or \
+            betas[-1] <= eps * max(abs(alphas[-1]), 1.0)
+        if converged or nmv >= maxiter or j_done == n:
+            break
+        # explicit restart from the (sum of the) wanted Ritz vectors
+        x0 = X[0] if k == 1 else ops.sum(X, axis=0)
+        x0 = x0 / norm(x0)
+        dev.fill(Q._buf, Q.size, 0.0, dtype)
+        put(0, x0)
+    if not return_vecs:
+        return theta.astype(rdt)
+    return theta.astype(rdt), ops.transpose(X, (1, 0))

@@ -106,3 +106,37 @@ for spec, dt_, name, sk, e0, e1 in dev.profile:
     shp = f"M={getattr(spec, 'M', '?')} N={getattr(spec, 'N', '?')} K={getattr(spec, 'K', '?')}"
     print(f"   {e0.elapsed_time(e1)*1e3:8.1f} us  {name}  split_k={sk}  {shp}")
 dev.profile = None
+# DMRG local solve: device Lanczos on a symmetrised chi=512 effective Hamiltonian (BASELINE config #5)
+import time as _time
+(L_, li), (W1_, w1i), (W2_, w2i), (R_, ri) = tensors
+L_ = (L_ + L_.transpose(2, 1, 0)) / 2; R_ = (R_ + R_.transpose(2, 1, 0)) / 2
+W1_ = (W1_ + W1_.transpose(0, 1, 3, 2)) / 2; W2_ = (W2_ + W2_.transpose(0, 1, 3, 2)) / 2
+As = qa.TNLinearOperator([(L_, li), (W1_, w1i), (W2_, w2i), (R_, ri)], left, right, optimize="random-greedy")
+v0 = rnd((512 * 2 * 2 * 512,), "float64")
+qa.eigh_lanczos(As, k=1, which="SA", v0=v0, ncv=4, tol=1e-3, maxiter=8)   # warm the plan caches
+__import__("torch").cuda.synchronize()
+_mv = As.matvec
+_cnt = [0]
+def _counting(x):
+    _cnt[0] += 1
+    return _mv(x)
+As.matvec = _counting
+for ncv, tol_ in ((4, 1e-3), (20, 1e-8)):
+    _cnt[0] = 0
+    t0 = _time.perf_counter()
+    w_, _v = qa.eigh_lanczos(As, k=1, which="SA", v0=v0, ncv=ncv, tol=tol_, maxiter=200)
+    __import__("torch").cuda.synchronize()
+    dt_ = _time.perf_counter() - t0
+    print(f"device Lanczos chi=512 fp64 (ncv={ncv}, tol={tol_:g}): {dt_*1e3:8.2f} ms  {_cnt[0]} matvecs  "
+          f"{dt_/_cnt[0]*1e3:.3f} ms/iteration  E0={w_[0]:.8f}", flush=True)
+As.matvec = _mv
+dev.profile = []
+qa.eigh_lanczos(As, k=1, which="SA", v0=v0, ncv=20, tol=1e-8, maxiter=3)
+__import__("torch").cuda.synchronize()
+agg = {}
+for spec, dt_, name, sk, e0, e1 in dev.profile:
+    key = (name, getattr(spec, "M", 0), getattr(spec, "N", 0), getattr(spec, "K", 0), sk)
+    a_ = agg.setdefault(key, [0, 0.0]); a_[0] += 1; a_[1] += e0.elapsed_time(e1)
+for key, (c_, t_) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+    print(f"   lanczos pair kernels: {t_/c_*1e3:8.1f} us x{c_:3d}  {key}")
+dev.profile = None

@@ -591,6 +591,63 @@ def check_linop(dtype, chi=12):
     assert_close(y.to_numpy(), dense @ x, dtype)
 
 
+def check_long_reductions(dtype, seed=14):
+    """Reduction-shaped contractions (M*N tiny, K long): norms and projections onto a few vectors --
+    the streaming multi-dot kernel on the device."""
+    rng = np.random.default_rng(seed)
+    K = 70000 + 3                      # not a multiple of the vector width: scalar tail
+    for rows in (1, 2, 5, 21, 32):
+        Q = rand(rng, (rows, K), dtype)
+        w = rand(rng, (K,), dtype)
+        want = Q.astype(np.float64) @ w.astype(np.float64)
+        scale = np.abs(Q.astype(np.float64)) @ np.abs(w.astype(np.float64))   # conditioning of the sums
+        got = qa.tensordot(qa.asarray(Q), qa.asarray(w), axes=([1], [0])).to_numpy()
+        assert np.all(np.abs(got - want) <= 20 * RTOL[np.dtype(dtype)] * scale / np.sqrt(K) + 1e-30), rows
+        got2 = qa.tensordot(qa.asarray(w), qa.asarray(Q), axes=([0], [1])).to_numpy()   # vector first
+        assert np.all(np.abs(got2 - want) <= 20 * RTOL[np.dtype(dtype)] * scale / np.sqrt(K) + 1e-30), rows
+    x = rand(rng, (1 << 17,), dtype)
+    nn = qa.tensordot(qa.asarray(x), qa.asarray(x), axes=([0], [0])).item()
+    assert abs(nn - float(x.astype(np.float64) @ x.astype(np.float64))) <= 1e-5 * nn
+
+
+def check_lanczos(dtype, chi=6):
+    """Device Lanczos (quimb_amd.eigh_lanczos) on a dense symmetric matrix and on a symmetric DMRG-style
+    effective Hamiltonian (TNLinearOperator) against numpy's dense eigh -- the call DMRG._eigs makes
+    (quimb/tensor/tn1d/dmrg.py:626-645)."""
+    rng = np.random.default_rng(5)
+    tol = 1e-10 if np.dtype(dtype) == np.float64 else 1e-5
+    # dense symmetric matrix
+    n = 120
+    M = rng.normal(size=(n, n))
+    M = ((M + M.T) / 2).astype(dtype)
+    ref = np.linalg.eigvalsh(M.astype(np.float64))
+    for which, want in (("SA", ref[0]), ("LA", ref[-1])):
+        w, v = qa.eigh_lanczos(qa.asarray(M), k=1, which=which, ncv=30, tol=tol)
+        assert abs(w[0] - want) <= 50 * tol * max(1.0, abs(want))
+        v = v.to_numpy()[:, 0].astype(np.float64)
+        assert abs(np.linalg.norm(v) - 1) < 1e-4
+        assert np.linalg.norm(M.astype(np.float64) @ v - w[0] * v) <= 2e3 * tol * max(1.0, abs(want))
+    w2 = qa.eigh_lanczos(qa.asarray(M), k=2, which="SA", ncv=40, tol=tol, return_vecs=False)
+    assert np.allclose(w2, ref[:2], atol=1e3 * tol * max(1.0, abs(ref[0])))
+    # symmetric 2-site effective Hamiltonian as a TNLinearOperator
+    tensors, left, right = dmrg_effective_ham(chi, dtype=dtype)
+    (L, li), (W1, w1i), (W2, w2i), (R, ri) = tensors
+    L = (L + L.transpose(2, 1, 0)) / 2
+    R = (R + R.transpose(2, 1, 0)) / 2
+    W1 = (W1 + W1.transpose(0, 1, 3, 2)) / 2
+    W2 = (W2 + W2.transpose(0, 1, 3, 2)) / 2
+    tensors = [(L, li), (W1, w1i), (W2, w2i), (R, ri)]
+    A = qa.TNLinearOperator(tensors, left, right)
+    n = chi * 2 * 2 * chi
+    dense = np.einsum("apA,pqsS,qrtT,brB->astbASTB", *[t[0].astype(np.float64) for t in tensors]).reshape(n, n)
+    assert np.allclose(dense, dense.T)
+    ref = np.linalg.eigvalsh(dense)
+    w, v = qa.eigh_lanczos(A, k=1, which="SA", tol=tol, ncv=24)
+    assert abs(w[0] - ref[0]) <= 100 * tol * max(1.0, abs(ref[0]))
+    v = v.to_numpy()[:, 0].astype(np.float64)
+    assert np.linalg.norm(dense @ v - w[0] * v) <= 5e3 * tol * max(1.0, abs(ref[0]))
+
+
 def check_tensor_network_semantics():
     """Restatement of the reference's TensorNetwork contraction tests
     (tests/test_tensor/test_tensor_core.py:1128-1169, :318-330)."""

@@ -163,6 +163,16 @@ def test_tensor_network_semantics(hip):
     checks.check_tensor_network_semantics()
 
 
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+def test_long_reductions(hip, dtype):
+    checks.check_long_reductions(dtype)
+
+
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+def test_lanczos(hip, dtype):
+    checks.check_lanczos(dtype)
+
+
 def test_complex_abs(hip):
     checks.check_complex_abs()
 

@@ -33,6 +33,16 @@ def test_fast_tile_shapes(emu):
     checks.check_fast_tiles("float32")
 
 
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+def test_long_reductions(emu, dtype):
+    checks.check_long_reductions(dtype)
+
+
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+def test_lanczos(emu, dtype):
+    checks.check_lanczos(dtype)
+
+
 def test_complex_abs(emu):
     checks.check_complex_abs()
 
