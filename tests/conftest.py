@@ -11,6 +11,12 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # a fresh checkout has no built library (it is git-ignored): build it once, as __graft_entry__.build() does
+    so = os.path.join(ROOT, "quimb_amd", "libquimb_amd.so")
+    if not os.path.exists(so) and os.path.exists("/opt/rocm/bin/hipcc"):
+        import subprocess
+
+        subprocess.run(["make", "-s", "-j8", "-C", os.path.join(ROOT, "quimb_amd", "csrc")], check=False)
 
 
 @pytest.fixture
