@@ -16,8 +16,11 @@ from .pairwise import prod
 
 
 class TNLinearOperator:
-    def __init__(self, tensors, left_inds, right_inds, ldims=None, rdims=None, optimize=None, dtype=None):
-        """``tensors``: sequence of (array, inds) -- or objects with ``.data`` / ``.inds``."""
+    def __init__(self, tensors, left_inds, right_inds, ldims=None, rdims=None, optimize=None, dtype=None,
+                 graph=False):
+        """``tensors``: sequence of (array, inds) -- or objects with ``.data`` / ``.inds``.
+        ``graph=True``: matvecs on device vectors replay ONE recorded hipGraph of the planned steps
+         instead of launching them one by one from Python."""
         arrs, inds = [], []
         for t in tensors:
             a, i = (t.data, t.inds) if hasattr(t, "inds") else t
@@ -42,6 +45,8 @@ class TNLinearOperator:
         self._optimize = optimize
         self._exprs = {}
         self.is_conj = False
+        self._use_graph = bool(graph)
+        self._graphed = None
 
     def _expr(self, ncols):
         ex = self._exprs.get(ncols)
@@ -65,7 +70,16 @@ class TNLinearOperator:
         xd = xd.reshape(self.rdims + ((ncols,) if ncols else ()))
         if self.is_conj:
             xd = xd.conj()
-        out = self._expr(ncols)(xd)
+        if self._use_graph and not ncols and not host and hasattr(xd._dev, "torch"):
+            if self._graphed is None:
+                from .executor import GraphedContraction
+
+                x0 = Array.full(self.rdims, 0.0, self.dtype, xd._dev)
+                self._graphed = GraphedContraction(self._expr(0).executor, list(self._arrays) + [x0])
+            self._graphed.update(len(self._arrays), xd)
+            out = self._graphed.replay().copy()      # the graph's output buffer is reused by the next replay
+        else:
+            out = self._expr(ncols)(xd)
         if isinstance(out, np.ndarray):
             out = asarray(out)
         if self.is_conj:

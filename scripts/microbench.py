@@ -130,6 +130,13 @@ for ncv, tol_ in ((4, 1e-3), (20, 1e-8)):
     print(f"device Lanczos chi=512 fp64 (ncv={ncv}, tol={tol_:g}): {dt_*1e3:8.2f} ms  {_cnt[0]} matvecs  "
           f"{dt_/_cnt[0]*1e3:.3f} ms/iteration  E0={w_[0]:.8f}", flush=True)
 As.matvec = _mv
+Ag = qa.TNLinearOperator([(L_, li), (W1_, w1i), (W2_, w2i), (R_, ri)], left, right, optimize="random-greedy", graph=True)
+qa.eigh_lanczos(Ag, k=1, which="SA", v0=v0, ncv=20, tol=1e-8, maxiter=4)
+__import__("torch").cuda.synchronize()
+t0 = _time.perf_counter()
+w_, _v = qa.eigh_lanczos(Ag, k=1, which="SA", v0=v0, ncv=20, tol=1e-8, maxiter=200)
+__import__("torch").cuda.synchronize()
+print(f"device Lanczos chi=512 fp64 (ncv=20, tol=1e-08, hipGraph matvec): {(_time.perf_counter()-t0)*1e3:8.2f} ms  E0={w_[0]:.8f}", flush=True)
 dev.profile = []
 qa.eigh_lanczos(As, k=1, which="SA", v0=v0, ncv=20, tol=1e-8, maxiter=3)
 __import__("torch").cuda.synchronize()

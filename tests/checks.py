@@ -589,6 +589,11 @@ def check_linop(dtype, chi=12):
     y = A @ xd
     assert isinstance(y, qa.Array)
     assert_close(y.to_numpy(), dense @ x, dtype)
+    # the same matvec replayed as one recorded hipGraph (plain path on the CPU interpreter)
+    Ag = qa.TNLinearOperator(tensors, left, right, graph=True)
+    for _ in range(3):
+        x2 = rand(rng, (n,), dtype)
+        assert_close((Ag @ qa.asarray(x2)).to_numpy(), dense @ x2, dtype)
 
 
 def check_long_reductions(dtype, seed=14):
