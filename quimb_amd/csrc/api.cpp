@@ -671,7 +671,7 @@ extern "C" int qamd_chain2_describe(const qamd_chain2_plan* p, char* buf, int32_
   if (variant && !chain2_uses_registers(p, nullptr)) return QAMD_EUNSUPPORTED;
   if (chain2_uses_registers(p, nullptr))
     snprintf(buf, buflen, "chain2r_kernel<%d, %d, %d>", p->D, (p->flags & QAMD_CHAIN2_K1_SINGLE) ? 1 : 2,
-             (p->flags & QAMD_CHAIN2_NO_N2OUT) ? 0 : 1);
+             (p->flags & QAMD_CHAIN2_NO_N2OUT) ? 0 : 1);   // (the super-chunk flag is a launch-time choice)
   else
     snprintf(buf, buflen, "chain2_kernel<%s, %d, %d>", p->dtype == QAMD_F32 ? "float" : "double", p->D, ch / 16);
   return QAMD_OK;
@@ -701,16 +701,28 @@ extern "C" int qamd_contract_chain2(const qamd_chain2_plan* p, const void* A, co
   a.chunks = (uint32_t)(M / ch);
   const uint32_t ic = (uint32_t)(inner / ch);
   const uint32_t target = std::max<uint32_t>(4, (a.chunks + 256 * 12 - 1) / (256 * 12));
-  uint32_t best = 0;
+  uint32_t best = 0, best_even = 0;
   for (uint32_t dlo = 1; (uint64_t)dlo * dlo <= ic; ++dlo) {
     if (ic % dlo) continue;
     uint32_t cand[2] = {dlo, ic / dlo};
-    for (uint32_t c : cand)
+    for (uint32_t c : cand) {
       if (c <= target && c > best) best = c;
+      if (c % 2 == 0 && c <= 2 * target && c > best_even) best_even = c;
+    }
   }
   if (best < 1) return QAMD_EUNSUPPORTED;
   a.chunks_per_block = best;
-  a.grid = a.chunks / best;
+  // super-chunks (pairs of adjacent chunks per wave, whole-line loads; even chunk count per workgroup):
+  // opt-in with QAMD_C2R_SC=1 -- measured equal to the default on MI355X (0.762 vs 0.764 ms per interior
+  // pair): the 9 % of re-fetched lines it saves is not what bounds the kernel
+  {
+    const char* e = getenv("QAMD_C2R_SC");
+    if (best_even >= 2 && e && e[0] == '1' && chain2_uses_registers(p, C)) {
+      a.chunks_per_block = best_even;
+      a.sc = 1;
+    }
+  }
+  a.grid = a.chunks / a.chunks_per_block;
   if (const char* e = getenv("QAMD_CHAIN2_ABLATE")) a.ablate = (uint32_t)atoi(e);
   const int k1_single = (p->flags & QAMD_CHAIN2_K1_SINGLE) ? 1 : 0, no_n2out = (p->flags & QAMD_CHAIN2_NO_N2OUT) ? 1 : 0;
   if (k1_single && no_n2out) return QAMD_EUNSUPPORTED;

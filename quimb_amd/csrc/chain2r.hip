@@ -77,7 +77,11 @@ __device__ __forceinline__ void rdecomp2(uint32_t idx, int n, const uint32_t* di
 
 // K1D: number of size-D indices in k1 (2 = (h, u) interior site, 1 = row start: no h yet);
 // NOD: 1 = n2 = (no, ni) interior site, 0 = row end: n2 = ni only (no new horizontal bond).
-template <int D, int K1D, int NOD>
+// SC ("super-chunks"): a wave works on PAIRS of adjacent chunks (32 consecutive m).  Every load
+// instruction then covers 2 rows x 128 contiguous bytes -- whole cache lines, half as many VMEM
+// instructions, no line shared with another wave -- and two lane swaps (v_permlane32_swap +
+// v_permlane16_swap) turn each pair of loaded registers into the MFMA B operands of the two chunks.
+template <int D, int K1D, int NOD, bool SC>
 __global__ __launch_bounds__(256, 2) void chain2r_kernel(const Chain2Args p, const float* __restrict__ A,
                                                          const float* __restrict__ W1p,
                                                          const float* __restrict__ W2p, float* __restrict__ C,
@@ -155,15 +159,18 @@ __global__ __launch_bounds__(256, 2) void chain2r_kernel(const Chain2Args p, con
     }
   const float alpha = 1.f / (rread_scale(scale_a) * rread_scale(scale_1) * rread_scale(scale_2));
 
-  const uint32_t blk_first = blockIdx.x * p.chunks_per_block;
-  uint32_t c_end = blk_first + p.chunks_per_block;
-  if (c_end > p.chunks) c_end = p.chunks;
+  // work units: chunks of 16 m, or (SC) super-chunks of 32 m; the 4 waves interleave units
+  constexpr uint32_t UW = SC ? 2 : 1;
+  const uint32_t units = p.chunks / UW, upb = p.chunks_per_block / UW;
+  const uint32_t blk_first = blockIdx.x * upb;
+  uint32_t c_end = blk_first + upb;
+  if (c_end > units) c_end = units;
   const uint32_t c_begin = blk_first + wave;
   if (c_begin >= c_end) return;
-  const uint32_t my_chunks = (c_end - c_begin + CSTRIDE - 1) / CSTRIDE;
+  const uint32_t my_chunks = (c_end - c_begin + CSTRIDE - 1) / CSTRIDE;   // units of this wave
 
   int64_t o2[2];
-  rdecomp2(c_begin * CH, p.nm, p.dim_m, p.sa_m, p.sc_m, o2);
+  rdecomp2(c_begin * (CH * UW), p.nm, p.dim_m, p.sa_m, p.sc_m, o2);
   uint64_t sbase;
   {
     uint64_t b = (uint64_t)(A + o2[0]);
@@ -181,6 +188,17 @@ __global__ __launch_bounds__(256, 2) void chain2r_kernel(const Chain2Args p, con
   for (int s = 0; s < KS1; ++s) {
     int k = 4 * s + kq;
     koff[s] = (uint32_t)(((k < K1 ? offK1[k] : offK1[0]) + j) * (int64_t)sizeof(float));
+  }
+  // SC: load h of k-step s covers rows 4s + 2h + (lane >> 5), columns m = lane & 31
+  uint32_t koff2[SC ? KS1 : 1][2];
+  if constexpr (SC) {
+#pragma unroll
+    for (int s = 0; s < KS1; ++s)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        int k = 4 * s + 2 * h + (lane >> 5);
+        koff2[s][h] = (uint32_t)(((k < K1 ? offK1[k] : offK1[0]) + (lane & 31)) * (int64_t)sizeof(float));
+      }
   }
   int64_t co[NO];
 #pragma unroll
@@ -208,7 +226,7 @@ __global__ __launch_bounds__(256, 2) void chain2r_kernel(const Chain2Args p, con
   // copy-out of the tile written by the previous chunk's stage 2: for every no, RUN contiguous
   // elements of C.  It runs inside the NEXT chunk (after its first stage-1 tile), so its stores
   // are never the newest VMEM operations a wait has to look past.
-  auto copy_out = [&]() {
+  auto copy_out = [&](int64_t cinc) {
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int no = 0; no < NO; ++no) {
@@ -224,7 +242,7 @@ __global__ __launch_bounds__(256, 2) void chain2r_kernel(const Chain2Args p, con
       }
     }
     __builtin_amdgcn_wave_barrier();
-    cbase += cstep;
+    cbase += cinc;     // C offset of the tile that stage 2 is about to write
   };
 
   // A registers, double buffered: the loads of chunk u+1 are issued before chunk u is touched
@@ -245,7 +263,36 @@ __global__ __launch_bounds__(256, 2) void chain2r_kernel(const Chain2Args p, con
   // chunk]: a wave can have at most 64 vector-memory instructions outstanding, so stores must not
   // be issued right behind a fresh batch of loads (54 + 18 > 64 would park the wave, MFMAs and
   // all, until HBM answers) -- the loads go out one stage-2 block after the stores instead.
-  auto chunk = [&](float (&cur)[D][KS1], float (&nxt)[D][KS1], uint64_t nbase, bool copy_prev) {
+  // SC: raw loads of a super-chunk (bufA <- rows 4s, 4s+1 ; bufB <- rows 4s+2, 4s+3, 32 columns each) ...
+  auto issue_pair = [&](uint64_t base) {
+    if (abl & 4) return;
+#pragma unroll
+    for (int v = 0; v < D; ++v)
+#pragma unroll
+      for (int s = 0; s < KS1; ++s) {
+        bufA[v][s] = rload(base + (uint64_t)v * svb, koff2[SC ? s : 0][0]);
+        bufB[v][s] = rload(base + (uint64_t)v * svb, koff2[SC ? s : 0][1]);
+      }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  // ... and the two lane swaps that make bufA the B operands of the even chunk, bufB of the odd one
+  auto swap_pair = [&]() {
+#pragma unroll
+    for (int v = 0; v < D; ++v)
+#pragma unroll
+      for (int s = 0; s < KS1; ++s) {
+        const auto a32 = __builtin_amdgcn_permlane32_swap(__float_as_uint(bufA[v][s]), __float_as_uint(bufB[v][s]),
+                                                          false, false);
+        const auto a16 = __builtin_amdgcn_permlane16_swap(a32[0], a32[1], false, false);
+        bufA[v][s] = __uint_as_float(a16[0]);
+        bufB[v][s] = __uint_as_float(a16[1]);
+      }
+  };
+
+  // mode 0: prefetch the next chunk into ``nxt`` in D batches; 1: no prefetch; 2: (SC) issue the next
+  // super-chunk's raw loads once this chunk's last stage-1 tile has consumed the registers
+  auto chunk = [&](float (&cur)[D][KS1], float (&nxt)[D][KS1], uint64_t nbase, bool copy_prev, int64_t cinc,
+                   int mode) {
 #ifdef QAMD_C2R_SYNC
     __builtin_amdgcn_s_barrier();   // keep the 4 waves (adjacent 64-B halves of the same lines) in step
 #endif
@@ -261,9 +308,10 @@ __global__ __launch_bounds__(256, 2) void chain2r_kernel(const Chain2Args p, con
         for (int v = 0; v < D; ++v)
           X[v] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf1[s][nt], cur[v][s], X[v], 0, 0, 0);
       QAMD_STAMP(nt == 0 ? 0 : (nt == 1 ? 4 : 6));      // stage 1 of tile nt
-      if (nt == 0 && copy_prev) copy_out();
+      if (nt == 0 && copy_prev) copy_out(cinc);
       if (nt == 0) QAMD_STAMP(1);                       // copy-out
-      if (NT == 1) issue(nxt, nbase);
+      if (NT == 1 && mode == 0) issue(nxt, nbase);
+      if (nt == NT - 1 && mode == 2) issue_pair(nbase);
       QAMD_STAMP(2);
       // ---- stage 2 for the x values of this tile: the stage-1 registers are the B operands ----
 #pragma unroll
@@ -272,7 +320,7 @@ __global__ __launch_bounds__(256, 2) void chain2r_kernel(const Chain2Args p, con
         if (x < D) {
           // the next chunk's loads go out in D batches of KS1, one in front of every stage-2 block
           // (a 54-load burst parks the wave at VMEM issue while the CU's memory pipe is busy)
-          if (NT > 1) issue_v(nxt, nbase, x);
+          if (NT > 1 && mode == 0) issue_v(nxt, nbase, x);
           r_acc_t acc[NT2];
 #pragma unroll
           for (int t = 0; t < NT2; ++t) acc[t] = r_acc_t{0, 0, 0, 0};
@@ -314,17 +362,30 @@ __global__ __launch_bounds__(256, 2) void chain2r_kernel(const Chain2Args p, con
     }
   };
 
-  constexpr uint64_t STEP = (uint64_t)(CSTRIDE * CH * sizeof(float));
-  issue(bufA, sbase);
-  uint32_t u = 0;
-  for (; u + 2 <= my_chunks; u += 2) {
-    sbase += STEP;
-    chunk(bufA, bufB, sbase, u > 0);                     // chunk u   (prefetches u+1)
-    sbase += (u + 2 < my_chunks) ? STEP : 0;             // (the last pair re-loads its own chunk: no branch)
-    chunk(bufB, bufA, sbase, true);                      // chunk u+1 (prefetches u+2)
+  if constexpr (SC) {
+    constexpr uint64_t STEP = (uint64_t)(CSTRIDE * 2 * CH * sizeof(float));
+    const int64_t cB = (int64_t)CH * N, cA = (int64_t)(CSTRIDE * 2 * CH - CH) * N;   // C steps: even -> odd chunk, odd -> next even
+    issue_pair(sbase);
+    for (uint32_t u = 0; u < my_chunks; ++u) {
+      swap_pair();
+      sbase += (u + 1 < my_chunks) ? STEP : 0;           // (the last super-chunk re-loads itself: no branch)
+      chunk(bufA, bufB, sbase, u > 0, cA, 1);            // even chunk; flushes the previous odd tile
+      chunk(bufB, bufA, sbase, true, cB, 2);             // odd chunk; flushes the even tile, then prefetches
+    }
+    copy_out(0);
+  } else {
+    constexpr uint64_t STEP = (uint64_t)(CSTRIDE * CH * sizeof(float));
+    issue(bufA, sbase);
+    uint32_t u = 0;
+    for (; u + 2 <= my_chunks; u += 2) {
+      sbase += STEP;
+      chunk(bufA, bufB, sbase, u > 0, cstep, 0);           // chunk u   (prefetches u+1)
+      sbase += (u + 2 < my_chunks) ? STEP : 0;             // (the last pair re-loads its own chunk: no branch)
+      chunk(bufB, bufA, sbase, true, cstep, 0);            // chunk u+1 (prefetches u+2)
+    }
+    if (u < my_chunks) chunk(bufA, bufB, sbase, u > 0, cstep, 0);   // odd tail (its prefetch re-loads itself)
+    copy_out(0);
   }
-  if (u < my_chunks) chunk(bufA, bufB, sbase, u > 0);    // odd tail (its prefetch re-loads itself)
-  copy_out();
 
 #ifdef QAMD_CHAIN2_TIMING
   if (absmax_out && lane == 0) {
@@ -345,16 +406,16 @@ __global__ __launch_bounds__(256, 2) void chain2r_kernel(const Chain2Args p, con
 
 using namespace qamd;
 
-template <int D, int K1D, int NOD>
+template <int D, int K1D, int NOD, bool SC>
 static int launch_chain2r_d(const Chain2Args& a, const void* A, const void* W1p, const void* W2p, void* C,
                             const void* offK1, const void* offCo, const void* sa, const void* s1, const void* s2,
                             void* amax, hipStream_t st) {
   size_t lds = (size_t)4 * (NOD ? D : 1) * 16 * D * D * sizeof(float);
   if (lds > 160 * 1024) return -2;
   if (lds > 64 * 1024)
-    (void)hipFuncSetAttribute((const void*)chain2r_kernel<D, K1D, NOD>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    (void)hipFuncSetAttribute((const void*)chain2r_kernel<D, K1D, NOD, SC>, hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)lds);
-  QAMD_LAUNCH((chain2r_kernel<D, K1D, NOD>), dim3(a.grid), dim3(256), lds, st, a, (const float*)A, (const float*)W1p,
+  QAMD_LAUNCH((chain2r_kernel<D, K1D, NOD, SC>), dim3(a.grid), dim3(256), lds, st, a, (const float*)A, (const float*)W1p,
               (const float*)W2p, (float*)C, (const int64_t*)offK1, (const int64_t*)offCo, (const float*)sa,
               (const float*)s1, (const float*)s2, (float*)amax);
   return hipGetLastError() == hipSuccess ? 0 : -4;
@@ -372,9 +433,14 @@ extern "C" int qamd_chain2r_launch(int D, int k1_single, int no_n2out, const Cha
   if (k1_single && no_n2out) return -2;
 #define QAMD_C2R(DD)                                                                                                 \
   case DD:                                                                                                           \
-    if (k1_single) return launch_chain2r_d<DD, 1, 1>(*a, A, W1p, W2p, C, offK1, offCo, scale_a, scale_1, scale_2, absmax_out, st); \
-    if (no_n2out) return launch_chain2r_d<DD, 2, 0>(*a, A, W1p, W2p, C, offK1, offCo, scale_a, scale_1, scale_2, absmax_out, st);  \
-    return launch_chain2r_d<DD, 2, 1>(*a, A, W1p, W2p, C, offK1, offCo, scale_a, scale_1, scale_2, absmax_out, st);
+    if (a->sc) {                                                                                                       \
+      if (k1_single) return launch_chain2r_d<DD, 1, 1, true>(*a, A, W1p, W2p, C, offK1, offCo, scale_a, scale_1, scale_2, absmax_out, st); \
+      if (no_n2out) return launch_chain2r_d<DD, 2, 0, true>(*a, A, W1p, W2p, C, offK1, offCo, scale_a, scale_1, scale_2, absmax_out, st);  \
+      return launch_chain2r_d<DD, 2, 1, true>(*a, A, W1p, W2p, C, offK1, offCo, scale_a, scale_1, scale_2, absmax_out, st);                \
+    }                                                                                                                  \
+    if (k1_single) return launch_chain2r_d<DD, 1, 1, false>(*a, A, W1p, W2p, C, offK1, offCo, scale_a, scale_1, scale_2, absmax_out, st); \
+    if (no_n2out) return launch_chain2r_d<DD, 2, 0, false>(*a, A, W1p, W2p, C, offK1, offCo, scale_a, scale_1, scale_2, absmax_out, st);  \
+    return launch_chain2r_d<DD, 2, 1, false>(*a, A, W1p, W2p, C, offK1, offCo, scale_a, scale_1, scale_2, absmax_out, st);
   switch (D) {
     QAMD_C2R(2) QAMD_C2R(3) QAMD_C2R(4) QAMD_C2R(5) QAMD_C2R(6)
   }

@@ -48,6 +48,7 @@ struct Chain2Args {
   uint32_t chunks, chunks_per_block, grid;
   int64_t w1s[4];   // W1 element strides of (k1 outer, k1 inner, x, y); a single-index k1 uses w1s[0] only
   int64_t w2s[4];   // W2 element strides of (y, v, n2_out, n2_in)
+  uint32_t sc;      // chain2r: waves work on pairs of adjacent chunks (chunks_per_block is even)
   uint32_t ablate;  // debug/ablation bits (QAMD_CHAIN2_ABLATE): 1 no stores, 2 no stage-1 scatter, 4 no loads, 8 no stage 2
 };
 

@@ -9,18 +9,24 @@ from quimb_amd.pairwise import plan_chain2
 from quimb_amd.ops import _apply_pre
 dev = qa.default_device()
 D, nm = 6, 8
-la = ("h", "u", "v") + tuple(f"m{i}" for i in range(nm))
-l1 = ("h", "y", "u", "x")
-lx = ("v", "y") + la[3:] + ("x",)
-l2 = ("y", "yy", "v", "xx")
-lc = (la[3], "yy") + la[4:] + ("x", "xx")
+variant = os.environ.get("QAMD_C2_VARIANT", "interior")   # interior | start (k1 = u only) | end (n2 = one index)
+ms = tuple(f"m{i}" for i in range(nm))
+if variant == "start":
+    la, l1 = ("u", "v") + ms, ("u", "y", "x")
+else:
+    la, l1 = ("h", "u", "v") + ms, ("h", "y", "u", "x")
+lx = ("v", "y") + ms + ("x",)
+if variant == "end":
+    l2, lc = ("y", "v", "xx"), ms + ("x", "xx")
+else:
+    l2, lc = ("y", "yy", "v", "xx"), (ms[0], "yy") + ms[1:] + ("x", "xx")
 size = {i: D for i in set(la) | set(l1) | set(l2)}
 c2 = plan_chain2(la, l1, lx, l2, lc, size, "float32")
 assert c2 is not None
 rnd = lambda n: torch.rand(n, device=dev.tdev) - 0.5
 A = qa.Array(dev, rnd(D ** len(la)), (D,) * len(la), "float32")
-W1 = qa.Array(dev, rnd(D**4), (D,) * 4, "float32")
-W2 = qa.Array(dev, rnd(D**4), (D,) * 4, "float32")
+W1 = qa.Array(dev, rnd(D ** len(l1)), (D,) * len(l1), "float32")
+W2 = qa.Array(dev, rnd(D ** len(l2)), (D,) * len(l2), "float32")
 w1p, w2p = W1, W2   # the device addresses the small tensors in place (or packs them itself)
 out = qa.Array.empty(c2.out_shape, "float32", dev)
 def run():
@@ -32,7 +38,7 @@ e0.record()
 for _ in range(10): run()
 e1.record(); torch.cuda.synchronize()
 t = e0.elapsed_time(e1) / 10 * 1e-3
-print(f"ablate={os.environ.get('QAMD_CHAIN2_ABLATE','0')} V1={os.environ.get('QAMD_CHAIN2_V1','')} {t*1e3:.3f} ms  {2*c2.mults/t/1e12:.1f} TF  {4*(c2.a_size+c2.c_size)/t/1e9:.0f} GB/s")
+print(f"{variant} ablate={os.environ.get('QAMD_CHAIN2_ABLATE','0')} V1={os.environ.get('QAMD_CHAIN2_V1','')} {t*1e3:.3f} ms  {2*c2.mults/t/1e12:.1f} TF  {4*(c2.a_size+c2.c_size)/t/1e9:.0f} GB/s")
 # single-launch timing (one event pair per launch) and host-side cost of a launch
 import time
 ts = []

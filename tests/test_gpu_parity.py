@@ -95,6 +95,13 @@ def test_fused_pairs(hip, Lx, Ly, D, dtype):
     finally:
         del os.environ["QAMD_CHAIN2"]
     assert any(e[0] == "chain2" for e in ex.plan)
+    if dtype == "float32":   # the opt-in super-chunk variant (whole-line loads + lane swaps) must agree as well
+        os.environ["QAMD_C2R_SC"] = "1"
+        try:
+            msc, esc = ex(arrays, strip_exponent=True)
+        finally:
+            del os.environ["QAMD_C2R_SC"]
+        assert msc.to_numpy().item() * 10.0**esc == pytest.approx(want, rel=5e-6)
     if dtype == "float32":   # row-start and row-end pairs are fused too (register kernel only)
         assert any(e[0] == "chain2" and e[5].k1_single for e in ex.plan)
         assert any(e[0] == "chain2" and e[5].no_n2out for e in ex.plan)
