@@ -41,6 +41,28 @@ torch.cuda.synchronize(); t0 = time.perf_counter()
 for _ in range(20): g2.replay()
 torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 20
 print(f"MPS, hipGraph replay: {dt*1e3:.3f} ms/contract")
+# BASELINE config #2: 53-qubit depth-10 brickwork circuit, one amplitude, complex64 -- 895 tiny steps, width 9:
+# dispatch-bound, so the numbers are eager (one Python launch per step) vs one hipGraph replay
+arrays, inputs, _ = checks.random_circuit_network(53, 10, np.random.default_rng(0), "complex64", dense=False)
+tree = qa.array_contract_tree(inputs, (), shapes=[a.shape for a in arrays], optimize="greedy")
+ref = orc.oracle_array_contract([a.astype(np.complex128) for a in arrays], inputs, (), path=tree.get_path())
+ex3 = qa.TreeExecutor(tree, "complex64"); xs3 = [qa.asarray(a) for a in arrays]
+for _ in range(3): r3 = ex3(xs3).item()
+torch.cuda.synchronize(); t0 = time.perf_counter()
+for _ in range(10): r3 = ex3(xs3).item()
+torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 10
+print(f"circuit 53q depth 10 (config #2): {len(tree.steps)} steps, width {tree.contraction_width():.0f}, eager {dt*1e3:.2f} ms/amplitude "
+      f"= {dt/len(tree.steps)*1e6:.1f} us/step, rel err vs fp64 oracle {abs(r3-ref)/abs(ref):.2e}")
+g3 = ex3.graph(xs3)
+for _ in range(3): g3.replay()
+torch.cuda.synchronize(); t0 = time.perf_counter()
+for _ in range(20): o3 = g3.replay()
+torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 20
+print(f"circuit 53q depth 10, hipGraph replay: {dt*1e3:.3f} ms/amplitude = {dt/len(tree.steps)*1e6:.2f} us/step, "
+      f"rel err {abs(o3.item()-ref)/abs(ref):.2e}")
+t0 = time.perf_counter()
+for _ in range(3): orc.oracle_array_contract(arrays, inputs, (), path=tree.get_path())
+print(f"numpy (oracle) on the host, same tree: {(time.perf_counter()-t0)/3*1e3:.2f} ms/amplitude")
 sys.exit(0)
 pr = cProfile.Profile(); pr.enable()
 for _ in range(5): run()

@@ -502,12 +502,12 @@ def check_golden(contract, tensor_contract=None, fuse=None, transpose=None, geti
         np.testing.assert_array_equal(np.asarray(getitem(t, (1, slice(None), 2))), L["sl"])
 
 
-def random_circuit_network(n, depth, rng, dtype="complex64"):
+def random_circuit_network(n, depth, rng, dtype="complex64", dense=True):
     """Brickwork random circuit as a tensor network for one amplitude <b|U|0..0>
     (cf. quimb Circuit.amplitude, quimb/tensor/circuit/exact.py:417-501): |0> vectors,
     random single-qubit unitaries, CZ-like two-qubit gates, <b| projectors.  Returns
     (arrays, inputs, exact_amplitude) with the amplitude from a dense state-vector
-    simulation."""
+    simulation (``dense=False``: no simulation, amplitude None -- for qubit counts a state vector cannot hold)."""
     def runitary(k):
         q, r = np.linalg.qr(rng.normal(size=(k, k)) + 1j * rng.normal(size=(k, k)))
         return q * (np.diag(r) / np.abs(np.diag(r)))
@@ -515,8 +515,10 @@ def random_circuit_network(n, depth, rng, dtype="complex64"):
     arrays, inputs = [], []
     cur = [f"q{i}_0" for i in range(n)]
     cnt = [0] * n
-    psi = np.zeros((2,) * n, dtype=np.complex128)
-    psi[(0,) * n] = 1.0
+    psi = None
+    if dense:
+        psi = np.zeros((2,) * n, dtype=np.complex128)
+        psi[(0,) * n] = 1.0
     for i in range(n):
         arrays.append(np.array([1.0, 0.0]))
         inputs.append((cur[i],))
@@ -528,7 +530,8 @@ def random_circuit_network(n, depth, rng, dtype="complex64"):
             arrays.append(U)
             inputs.append((new, cur[i]))
             cur[i] = new
-            psi = np.moveaxis(np.tensordot(U, psi, axes=([1], [i])), 0, i)
+            if dense:
+                psi = np.moveaxis(np.tensordot(U, psi, axes=([1], [i])), 0, i)
         for i in range(d % 2, n - 1, 2):
             G = runitary(4).reshape(2, 2, 2, 2)
             cnt[i] += 1
@@ -536,7 +539,8 @@ def random_circuit_network(n, depth, rng, dtype="complex64"):
             n1, n2 = f"q{i}_{cnt[i]}", f"q{i+1}_{cnt[i+1]}"
             arrays.append(G)
             inputs.append((n1, n2, cur[i], cur[i + 1]))
-            psi = np.moveaxis(np.tensordot(G, psi, axes=([2, 3], [i, i + 1])), [0, 1], [i, i + 1])
+            if dense:
+                psi = np.moveaxis(np.tensordot(G, psi, axes=([2, 3], [i, i + 1])), [0, 1], [i, i + 1])
             cur[i], cur[i + 1] = n1, n2
     bits = rng.integers(0, 2, size=n)
     for i in range(n):
@@ -544,7 +548,7 @@ def random_circuit_network(n, depth, rng, dtype="complex64"):
         v[bits[i]] = 1.0
         arrays.append(v)
         inputs.append((cur[i],))
-    amp = psi[tuple(bits)]
+    amp = psi[tuple(bits)] if dense else None
     return [a.astype(dtype) for a in arrays], inputs, amp
 
 
