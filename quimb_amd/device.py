@@ -371,6 +371,32 @@ class HipDevice:
         return float(self._scratch.cpu()[2])
 
 
+    def buffer_address(self, buf):
+        return buf.data_ptr()
+
+    def microtree_run(self, mt, table, keep, out):
+        """One launch for ``table.shape[0]`` instances of the compiled tree ``mt`` (microtree.hip).
+        ``table``: int64 [ninst, ninputs] device addresses; ``keep``: objects that own those buffers."""
+        torch = self.torch
+        key = ("microtree", id(mt))
+        steps_dev = self._pairs.get(key)
+        if steps_dev is None:
+            raw = np.frombuffer(mt.packed(), dtype=np.uint8).copy()
+            steps_dev = torch.from_numpy(raw).to(self.tdev)
+            self._pairs[key] = steps_dev
+        ninst = int(table.shape[0])
+        ptrs = torch.from_numpy(np.ascontiguousarray(table, dtype=np.int64)).to(self.tdev, non_blocking=False)
+        arena = self.empty(max(mt.arena_elems * ninst, 1), mt.dtype)
+        _lib.check(
+            self.lib.qamd_microtree_run(
+                dtype_code(mt.dtype), steps_dev.data_ptr(), len(mt.steps), ptrs.data_ptr(), mt.ninputs,
+                arena.data_ptr(), int(mt.arena_elems), out.data_ptr(), int(mt.out_elems), ninst, self.stream(),
+            ),
+            "qamd_microtree_run",
+        )
+        # the pointer table, the arena and every input must outlive the asynchronous launch
+        self._micro_keep = (ptrs, arena, keep)
+
     _UNARY = {"abs": 0, "sqrt": 1, "exp": 2, "log": 3, "log10": 4}
 
     def unary(self, dst, src, n, op, dtype):

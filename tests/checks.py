@@ -552,6 +552,44 @@ def random_circuit_network(n, depth, rng, dtype="complex64", dense=True):
     return [a.astype(dtype) for a in arrays], inputs, amp
 
 
+def check_microtree(dtype, seed=19):
+    """One-launch tree walk (MicroTree) against the dense simulation and against TreeExecutor: a circuit
+    amplitude, a batch of bitstrings sharing the gate tensors, and a small real network with open indices."""
+    rng = np.random.default_rng(seed)
+    n, depth = 8, 6
+    arrays, inputs, amp = random_circuit_network(n, depth, rng, dtype)
+    tree = qa.array_contract_tree(inputs, (), shapes=[a.shape for a in arrays], optimize="greedy")
+    mt = qa.MicroTree(tree, dtype)
+    got = mt(arrays).to_numpy().item()
+    assert abs(got - amp) <= 50 * RTOL[np.dtype(dtype)] * max(abs(amp), 2.0 ** (-n / 2))
+    # batch: every bitstring of the last 3 qubits, gate tensors shared as device arrays
+    dev_arrays = [qa.asarray(a) for a in arrays]
+    e0, e1 = qa.asarray(np.array([1, 0], dtype)), qa.asarray(np.array([0, 1], dtype))
+    insts, want = [], []
+    ex = qa.TreeExecutor(tree, dtype)
+    for bits in itertools.product((0, 1), repeat=3):
+        xs = list(dev_arrays)
+        for q, bt in zip(range(n - 3, n), bits):
+            xs[len(arrays) - n + q] = e1 if bt else e0
+        insts.append(xs)
+        want.append(ex(xs).to_numpy().item())
+    res = mt.run_batch(insts).to_numpy()
+    assert res.shape == (8,)
+    assert np.max(np.abs(res - np.asarray(want))) <= 50 * RTOL[np.dtype(dtype)] * max(np.max(np.abs(want)), 2.0 ** (-n / 2))
+    # the same batch through the bound form: shared tensors tabulated once, per-instance choices as index arrays
+    bits = np.array(list(itertools.product((0, 1), repeat=3)))
+    sel = {len(arrays) - n + q: ((e0, e1), bits[:, i]) for i, q in enumerate(range(n - 3, n))}
+    res2 = mt.bind(dev_arrays).batch(sel).to_numpy()
+    np.testing.assert_array_equal(res2, res)
+    # real dtype, open output indices
+    rdt = "float32" if np.dtype(dtype).itemsize == 8 else "float64"
+    arrs, ins, out = rand_reg_network(8, 3, 3, rng, rdt, n_out=2)
+    tr = qa.array_contract_tree(ins, out, shapes=[a.shape for a in arrs], optimize="greedy")
+    got = qa.MicroTree(tr, rdt)(arrs).to_numpy()
+    ref = orc.oracle_array_contract([a.astype(np.float64) for a in arrs], ins, out)
+    assert_close(got, ref, rdt)
+
+
 def check_circuit_amplitude(dtype, n=10, depth=6, seed=17):
     """BASELINE config #2 in miniature: a circuit amplitude, complex dtype, O(100) small
     tensors, greedy path -- dispatch-bound, exercises the complex GETT path."""

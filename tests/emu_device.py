@@ -187,6 +187,34 @@ class EmuDevice:
     def absmax(self, x, n, dtype):
         return float(np.max(np.abs(x[:n]))) if n else 0.0
 
+    def buffer_address(self, buf):
+        """Stand-in for a device address: a handle the interpreter can turn back into the buffer."""
+        self._handles = getattr(self, "_handles", {})
+        self._handles[id(buf)] = buf
+        return id(buf)
+
+    def microtree_run(self, mt, table, keep, out):
+        """Semantics of qamd_microtree_run: walk the plan step by step for every instance."""
+        for ii in range(table.shape[0]):
+            xs = [self._handles[int(h)] for h in table[ii]]
+            arena = np.zeros(max(mt.arena_elems, 1), dtype=mt.dtype)
+            for s in mt.steps:
+                sp = s["spec"]
+                A = arena[s["a"][1]:] if s["a"][0] else xs[s["a"][1]]
+                B = arena[s["b"][1]:] if s["b"][0] else xs[s["b"][1]]
+                ob_a, ob_b, ob_c = (_offsets(sp.b, c) for c in (1, 2, 3))
+                om_a, om_c = _offsets(sp.m, 1), _offsets(sp.m, 3)
+                on_b, on_c = _offsets(sp.n, 2), _offsets(sp.n, 3)
+                ok_a, ok_b = _offsets(sp.k, 1), _offsets(sp.k, 2)
+                a4 = A[ob_a[:, None, None] + om_a[None, :, None] + ok_a[None, None, :]]      # [b, m, k]
+                b4 = B[ob_b[:, None, None] + ok_b[None, :, None] + on_b[None, None, :]]      # [b, k, n]
+                c = np.einsum("bmk,bkn->bmn", a4, b4)
+                oc = ob_c[:, None, None] + om_c[None, :, None] + on_c[None, None, :]
+                if s["c_off"] < 0:
+                    out[ii * mt.out_elems + oc] = c
+                else:
+                    arena[s["c_off"] + oc] = c
+
     def unary(self, dst, src, n, op, dtype):
         fn = {"abs": np.abs, "sqrt": np.sqrt, "exp": np.exp, "log": np.log, "log10": np.log10}[op]
         with np.errstate(all="ignore"):

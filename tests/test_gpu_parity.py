@@ -180,6 +180,11 @@ def test_lanczos(hip, dtype):
     checks.check_lanczos(dtype)
 
 
+@pytest.mark.parametrize("dtype", ["complex64", "complex128"])
+def test_microtree(hip, dtype):
+    checks.check_microtree(dtype)
+
+
 def test_complex_abs(hip):
     checks.check_complex_abs()
 

@@ -43,6 +43,11 @@ def test_lanczos(emu, dtype):
     checks.check_lanczos(dtype)
 
 
+@pytest.mark.parametrize("dtype", ["complex64", "complex128"])
+def test_microtree(emu, dtype):
+    checks.check_microtree(dtype)
+
+
 def test_complex_abs(emu):
     checks.check_complex_abs()
 
