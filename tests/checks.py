@@ -590,6 +590,30 @@ def check_microtree(dtype, seed=19):
     assert_close(got, ref, rdt)
 
 
+def check_microtree_config2():
+    """BASELINE config #2 at full size: 53-qubit depth-10 brickwork circuit, one amplitude and a batch of
+    bitstrings, complex64, against the fp64 numpy oracle on the same tree (a state vector cannot hold 2^53)."""
+    rng = np.random.default_rng(0)
+    arrays, inputs, _ = random_circuit_network(53, 10, rng, "complex64", dense=False)
+    tree = qa.array_contract_tree(inputs, (), shapes=[a.shape for a in arrays], optimize="greedy")
+    assert len(tree.steps) == 895 and tree.contraction_width() <= 12
+    hi = [a.astype(np.complex128) for a in arrays]
+    ref = orc.oracle_array_contract(hi, inputs, (), path=tree.get_path())
+    bm = qa.MicroTree(tree, "complex64").bind(arrays)
+    got = bm().to_numpy().item()
+    assert abs(got - ref) <= 1e-4 * abs(ref)
+    e = [np.array([1, 0], np.complex64), np.array([0, 1], np.complex64)]
+    bits = np.random.default_rng(3).integers(0, 2, size=(5, 53))
+    n_in = len(arrays)
+    res = bm.batch({n_in - 53 + q: (e, bits[:, q]) for q in range(53)}).to_numpy()
+    for i in range(5):
+        hi_i = list(hi)
+        for q in range(53):
+            hi_i[n_in - 53 + q] = e[bits[i, q]].astype(np.complex128)
+        want = orc.oracle_array_contract(hi_i, inputs, (), path=tree.get_path())
+        assert abs(res[i] - want) <= 1e-4 * abs(want) + 1e-12
+
+
 def check_circuit_amplitude(dtype, n=10, depth=6, seed=17):
     """BASELINE config #2 in miniature: a circuit amplitude, complex dtype, O(100) small
     tensors, greedy path -- dispatch-bound, exercises the complex GETT path."""

@@ -185,6 +185,10 @@ def test_microtree(hip, dtype):
     checks.check_microtree(dtype)
 
 
+def test_microtree_config2_53_qubits(hip):
+    checks.check_microtree_config2()
+
+
 def test_complex_abs(hip):
     checks.check_complex_abs()
 

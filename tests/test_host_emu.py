@@ -48,6 +48,10 @@ def test_microtree(emu, dtype):
     checks.check_microtree(dtype)
 
 
+def test_microtree_config2_53_qubits(emu):
+    checks.check_microtree_config2()
+
+
 def test_complex_abs(emu):
     checks.check_complex_abs()
 
