@@ -189,6 +189,27 @@ def test_microtree_config2_53_qubits(hip):
     checks.check_microtree_config2()
 
 
+@pytest.mark.parametrize("dtype,shape", [("float64", (96, 64)), ("float32", (48, 80)), ("complex128", (40, 40)),
+                                         ("complex64", (72, 33))])
+def test_svd_via_eig(hip, dtype, shape):
+    """Gram-matrix SVD (the reference's split method "svd:eig", quimb/tensor/decomp.py:1168) vs numpy."""
+    import quimb_amd as qa
+
+    rng = np.random.default_rng(2)
+    x = checks.rand(rng, shape, dtype)
+    U, s, VH = qa.linalg.svd_via_eig(qa.asarray(x))
+    U, s, VH = U.to_numpy(), s.to_numpy(), VH.to_numpy()
+    k = min(shape)
+    assert U.shape == (shape[0], k) and s.shape == (k,) and VH.shape == (k, shape[1])
+    tol = 2e-4 if np.dtype(dtype).itemsize in (4, 8) and np.dtype(dtype).name in ("float32", "complex64") else 1e-9
+    s_ref = np.linalg.svd(x.astype(np.complex128), compute_uv=False)
+    assert np.max(np.abs(s - s_ref)) <= tol * s_ref[0]
+    assert np.max(np.abs((U * s) @ VH - x)) <= 10 * tol * s_ref[0]
+    assert np.max(np.abs(U.conj().T @ U - np.eye(k))) <= 100 * tol
+    Uk, sk, VHk = qa.linalg.svd_via_eig(qa.asarray(x), max_bond=5)
+    assert Uk.shape == (shape[0], 5) and sk.shape == (5,) and VHk.shape == (5, shape[1])
+
+
 def test_complex_abs(hip):
     checks.check_complex_abs()
 
