@@ -169,7 +169,10 @@ def array_contract_expression(
     key = None
     if cache and constants is None:
         try:
-            okey = optimize if isinstance(optimize, str) else id(optimize)
+            # the optimizer object itself is part of the key (it stays alive with the cache entry, so its
+            # identity cannot be recycled); unhashable ones (lists) raise TypeError below -> not cached
+            okey = optimize if isinstance(optimize, str) else ("obj", optimize)
+            hash(okey)
             key = (inputs, output, tuple(sorted(size_dict.items(), key=repr)), okey, np.dtype(dtype).name,
                    bool(strip_exponent), repr(slicing))
             hit = _EXPR_CACHE.get(key)

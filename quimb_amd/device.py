@@ -378,12 +378,10 @@ class HipDevice:
         """One launch for ``table.shape[0]`` instances of the compiled tree ``mt`` (microtree.hip).
         ``table``: int64 [ninst, ninputs] device addresses; ``keep``: objects that own those buffers."""
         torch = self.torch
-        key = ("microtree", id(mt))
-        steps_dev = self._pairs.get(key)
+        steps_dev = getattr(mt, "_steps_dev", None)     # the plan lives (and dies) with its MicroTree
         if steps_dev is None:
             raw = np.frombuffer(mt.packed(), dtype=np.uint8).copy()
-            steps_dev = torch.from_numpy(raw).to(self.tdev)
-            self._pairs[key] = steps_dev
+            steps_dev = mt._steps_dev = torch.from_numpy(raw).to(self.tdev)
         ninst = int(table.shape[0])
         ptrs = torch.from_numpy(np.ascontiguousarray(table, dtype=np.int64)).to(self.tdev, non_blocking=False)
         arena = self.empty(max(mt.arena_elems * ninst, 1), mt.dtype)
