@@ -38,6 +38,8 @@ namespace qamd {
 
 typedef __attribute__((ext_vector_type(4))) float r_acc_t;
 typedef float r_vec4 __attribute__((ext_vector_type(4), aligned(16)));
+struct r_true { static constexpr bool value = true; };
+struct r_false { static constexpr bool value = false; };
 typedef const __attribute__((address_space(1))) char* r_gptr_t;
 
 __device__ __forceinline__ float rload(uint64_t sbase, uint32_t voff) {
@@ -131,6 +133,9 @@ __global__ __launch_bounds__(256, 2) void chain2r_kernel(const Chain2Args p, con
       const float w = W1p[ok ? ko + x * p.w1s[2] + y * p.w1s[3] : 0];
       wf1[s][nt] = ok ? w : 0.f;
     }
+  // 1 / (max|A| max|W1| max|W2|) of the fused exponent stripping is folded into the W2 fragments: the
+  // stage-2 accumulators go to LDS as they are (no multiply between the MFMAs and the result writes)
+  const float alpha = 1.f / (rread_scale(scale_a) * rread_scale(scale_1) * rread_scale(scale_2));
   float wf2[SXF > 0 ? SXF : 1][D][NT2];
 #pragma unroll
   for (int sg = 0; sg < SXF; ++sg)
@@ -142,7 +147,7 @@ __global__ __launch_bounds__(256, 2) void chain2r_kernel(const Chain2Args p, con
         const int R = 4 * nt + r, no = R / SX, ni = 4 * (R % SX) + g, y = 4 * sg + kq;
         const bool ok = R < NSLOT2 && ni < D && y < D;
         const float w = W2p[ok ? y * p.w2s[0] + v * p.w2s[1] + no * p.w2s[2] + ni * p.w2s[3] : 0];
-        wf2[sg][v][nt] = ok ? w : 0.f;
+        wf2[sg][v][nt] = ok ? w * alpha : 0.f;
       }
   // merged steps: lane groups 0, 1 <-> (y = 4*(SX-1) + q, v = 2p); groups 2, 3 <-> (y = 4*(SX-1) + q - 2, v = 2p + 1)
   float wf2m[NPAIR > 0 ? NPAIR : 1][NT2];
@@ -155,9 +160,8 @@ __global__ __launch_bounds__(256, 2) void chain2r_kernel(const Chain2Args p, con
       const int y = 4 * (SX - 1) + (kq & 1), v = 2 * pr + (kq >> 1);
       const bool ok = R < NSLOT2 && ni < D && y < D;
       const float w = W2p[ok ? y * p.w2s[0] + v * p.w2s[1] + no * p.w2s[2] + ni * p.w2s[3] : 0];
-      wf2m[pr][nt] = ok ? w : 0.f;
+      wf2m[pr][nt] = ok ? w * alpha : 0.f;
     }
-  const float alpha = 1.f / (rread_scale(scale_a) * rread_scale(scale_1) * rread_scale(scale_2));
 
   // work units: chunks of 16 m, or (SC) super-chunks of 32 m; the 4 waves interleave units
   constexpr uint32_t UW = SC ? 2 : 1;
@@ -218,7 +222,7 @@ __global__ __launch_bounds__(256, 2) void chain2r_kernel(const Chain2Args p, con
 #ifdef QAMD_CHAIN2_TIMING   // experiment builds only: s_memtime stamps per phase, written to absmax_out
   uint64_t tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   uint64_t tlast = __builtin_amdgcn_s_memtime();
-#define QAMD_STAMP(i) do { uint64_t now_ = __builtin_amdgcn_s_memtime(); tacc[i] += now_ - tlast; tlast = now_; } while (0)
+#define QAMD_STAMP(i) do { __builtin_amdgcn_sched_barrier(0); uint64_t now_ = __builtin_amdgcn_s_memtime(); tacc[i] += now_ - tlast; tlast = now_; __builtin_amdgcn_sched_barrier(0); } while (0)
 #else
 #define QAMD_STAMP(i) do {} while (0)
 #endif
@@ -228,6 +232,8 @@ __global__ __launch_bounds__(256, 2) void chain2r_kernel(const Chain2Args p, con
   // are never the newest VMEM operations a wait has to look past.
   auto copy_out = [&](int64_t cinc) {
     __builtin_amdgcn_wave_barrier();
+    // (a version flattened over (no, element) with a single predicated tail was measured SLOWER: its per-lane
+    //  64-bit store addresses cost more than the five extra basic-block boundaries of this form)
 #pragma unroll
     for (int no = 0; no < NO; ++no) {
       float* cp = C + cbase + co[no];      // wave-uniform, 16-byte aligned (host contract)
@@ -289,10 +295,35 @@ __global__ __launch_bounds__(256, 2) void chain2r_kernel(const Chain2Args p, con
       }
   };
 
+  // stage-2 results: two accumulator sets (x even / odd) and the LDS write of one x
+  r_acc_t accs[2][NT2];
+  auto write_x = [&](const r_acc_t (&acc)[NT2], int x) {
+#pragma unroll
+    for (int t = 0; t < NT2; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int R = 4 * t + r, no = R / SX, s2 = R % SX;
+        if (R < NSLOT2 && (s2 < SX - 1 || D % 4 == 0)) Ol[no * RUN + x * D + 4 * s2] = acc[t][r];
+      }
+    // last ni sub-block: lane groups with ni >= D hold padding.  For x < D-1 they may write anyway: their
+    // target is (x+1, ni - D), which the NEXT x overwrites with real data -- no predicate, no basic-block
+    // boundary; only the last x of the chunk is predicated (its spill would land in the next m row).
+    if (D % 4 != 0 && (x < D - 1 || last_ok)) {
+#pragma unroll
+      for (int t = 0; t < NT2; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int R = 4 * t + r, no = R / SX, s2 = R % SX;
+          if (R < NSLOT2 && s2 == SX - 1) Ol[no * RUN + x * D + 4 * s2] = acc[t][r];
+        }
+    }
+  };
+
   // mode 0: prefetch the next chunk into ``nxt`` in D batches; 1: no prefetch; 2: (SC) issue the next
   // super-chunk's raw loads once this chunk's last stage-1 tile has consumed the registers
-  auto chunk = [&](float (&cur)[D][KS1], float (&nxt)[D][KS1], uint64_t nbase, bool copy_prev, int64_t cinc,
+  auto chunk = [&](float (&cur)[D][KS1], float (&nxt)[D][KS1], uint64_t nbase, auto copy_prev_tag, int64_t cinc,
                    int mode) {
+    constexpr bool copy_prev = decltype(copy_prev_tag)::value;   // compile time: no branch around the copy-out
 #ifdef QAMD_C2R_SYNC
     __builtin_amdgcn_s_barrier();   // keep the 4 waves (adjacent 64-B halves of the same lines) in step
 #endif
@@ -321,7 +352,9 @@ __global__ __launch_bounds__(256, 2) void chain2r_kernel(const Chain2Args p, con
           // the next chunk's loads go out in D batches of KS1, one in front of every stage-2 block
           // (a 54-load burst parks the wave at VMEM issue while the CU's memory pipe is busy)
           if (NT > 1 && mode == 0) issue_v(nxt, nbase, x);
-          r_acc_t acc[NT2];
+          // software pipeline over x: the MFMAs of x are issued first, then the result of x-1 (complete long
+          // ago: no MFMA -> LDS-write hazard wait) goes to LDS in the shadow of those MFMAs
+          r_acc_t (&acc)[NT2] = accs[x & 1];
 #pragma unroll
           for (int t = 0; t < NT2; ++t) acc[t] = r_acc_t{0, 0, 0, 0};
 #pragma unroll
@@ -340,26 +373,12 @@ __global__ __launch_bounds__(256, 2) void chain2r_kernel(const Chain2Args p, con
 #pragma unroll
             for (int t = 0; t < NT2; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf2m[pr][t], xm, acc[t], 0, 0, 0);
           }
-#pragma unroll
-          for (int t = 0; t < NT2; ++t)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const int R = 4 * t + r, no = R / SX, s2 = R % SX;
-              if (R < NSLOT2 && (s2 < SX - 1 || D % 4 == 0)) Ol[no * RUN + x * D + 4 * s2] = acc[t][r] * alpha;
-            }
-          if (D % 4 != 0 && last_ok) {
-#pragma unroll
-            for (int t = 0; t < NT2; ++t)
-#pragma unroll
-              for (int r = 0; r < 4; ++r) {
-                const int R = 4 * t + r, no = R / SX, s2 = R % SX;
-                if (R < NSLOT2 && s2 == SX - 1) Ol[no * RUN + x * D + 4 * s2] = acc[t][r] * alpha;
-              }
-          }
+          if (x > 0) write_x(accs[(x - 1) & 1], x - 1);
         }
       }
       QAMD_STAMP(nt == 0 ? 3 : (nt == 1 ? 5 : 7));      // stage 2 of tile nt
     }
+    write_x(accs[(D - 1) & 1], D - 1);                  // the last x of the chunk
   };
 
   if constexpr (SC) {
@@ -369,21 +388,32 @@ __global__ __launch_bounds__(256, 2) void chain2r_kernel(const Chain2Args p, con
     for (uint32_t u = 0; u < my_chunks; ++u) {
       swap_pair();
       sbase += (u + 1 < my_chunks) ? STEP : 0;           // (the last super-chunk re-loads itself: no branch)
-      chunk(bufA, bufB, sbase, u > 0, cA, 1);            // even chunk; flushes the previous odd tile
-      chunk(bufB, bufA, sbase, true, cB, 2);             // odd chunk; flushes the even tile, then prefetches
+      if (u == 0) chunk(bufA, bufB, sbase, r_false{}, cA, 1);   // even chunk; nothing to flush yet
+      else chunk(bufA, bufB, sbase, r_true{}, cA, 1);           // even chunk; flushes the previous odd tile
+      chunk(bufB, bufA, sbase, r_true{}, cB, 2);         // odd chunk; flushes the even tile, then prefetches
     }
     copy_out(0);
   } else {
     constexpr uint64_t STEP = (uint64_t)(CSTRIDE * CH * sizeof(float));
     issue(bufA, sbase);
     uint32_t u = 0;
+    if (my_chunks >= 2) {                                  // first pair peeled: its first chunk has nothing to flush
+      sbase += STEP;
+      chunk(bufA, bufB, sbase, r_false{}, cstep, 0);
+      sbase += (2 < my_chunks) ? STEP : 0;
+      chunk(bufB, bufA, sbase, r_true{}, cstep, 0);
+      u = 2;
+    }
     for (; u + 2 <= my_chunks; u += 2) {
       sbase += STEP;
-      chunk(bufA, bufB, sbase, u > 0, cstep, 0);           // chunk u   (prefetches u+1)
+      chunk(bufA, bufB, sbase, r_true{}, cstep, 0);        // chunk u   (prefetches u+1)
       sbase += (u + 2 < my_chunks) ? STEP : 0;             // (the last pair re-loads its own chunk: no branch)
-      chunk(bufB, bufA, sbase, true, cstep, 0);            // chunk u+1 (prefetches u+2)
+      chunk(bufB, bufA, sbase, r_true{}, cstep, 0);        // chunk u+1 (prefetches u+2)
     }
-    if (u < my_chunks) chunk(bufA, bufB, sbase, u > 0, cstep, 0);   // odd tail (its prefetch re-loads itself)
+    if (u < my_chunks) {                                   // odd tail (its prefetch re-loads itself)
+      if (u == 0) chunk(bufA, bufB, sbase, r_false{}, cstep, 0);
+      else chunk(bufA, bufB, sbase, r_true{}, cstep, 0);
+    }
     copy_out(0);
   }
 
