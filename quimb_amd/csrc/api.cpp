@@ -663,6 +663,36 @@ static bool chain2_uses_registers(const qamd_chain2_plan* p, const void* C) {
   return qamd_chain2r_supported(p->dtype, p->D) && qamd_chain2_chunk(p->dtype, p->D) == 16;
 }
 
+// chunks per workgroup of the fused-pair kernels: the largest divisor of the innermost m group's chunk count
+// that still leaves ~12 workgroups per CU; ``sc``: the opt-in super-chunk variant (QAMD_C2R_SC=1: pairs of
+// adjacent chunks per wave, whole-line loads -- measured equal to the default, 0.762 vs 0.764 ms per pair)
+static bool chain2_geometry(const qamd_chain2_plan* p, int ch, bool registers, uint32_t& chunks, uint32_t& cpb, bool& sc) {
+  int64_t M = 1;
+  for (int i = 0; i < p->nm; ++i) M *= p->dim_m[i];
+  const int64_t inner = p->dim_m[p->nm - 1];
+  chunks = (uint32_t)(M / ch);
+  const uint32_t ic = (uint32_t)(inner / ch);
+  const uint32_t target = std::max<uint32_t>(4, (chunks + 256 * 12 - 1) / (256 * 12));
+  uint32_t best = 0, best_even = 0;
+  for (uint32_t dlo = 1; (uint64_t)dlo * dlo <= ic; ++dlo) {
+    if (ic % dlo) continue;
+    uint32_t cand[2] = {dlo, ic / dlo};
+    for (uint32_t c : cand) {
+      if (c <= target && c > best) best = c;
+      if (c % 2 == 0 && c <= 2 * target && c > best_even) best_even = c;
+    }
+  }
+  if (best < 1) return false;
+  cpb = best;
+  sc = false;
+  const char* e = getenv("QAMD_C2R_SC");
+  if (best_even >= 2 && e && e[0] == '1' && registers) {
+    cpb = best_even;
+    sc = true;
+  }
+  return true;
+}
+
 extern "C" int qamd_chain2_describe(const qamd_chain2_plan* p, char* buf, int32_t buflen) {
   if (!p || !buf || buflen <= 0) return QAMD_EINVAL;
   const int ch = qamd_chain2_chunk(p->dtype, p->D);
@@ -670,8 +700,13 @@ extern "C" int qamd_chain2_describe(const qamd_chain2_plan* p, char* buf, int32_
   const bool variant = (p->flags & (QAMD_CHAIN2_K1_SINGLE | QAMD_CHAIN2_NO_N2OUT)) != 0;
   if (variant && !chain2_uses_registers(p, nullptr)) return QAMD_EUNSUPPORTED;
   if (chain2_uses_registers(p, nullptr))
-    snprintf(buf, buflen, "chain2r_kernel<%d, %d, %d>", p->D, (p->flags & QAMD_CHAIN2_K1_SINGLE) ? 1 : 2,
-             (p->flags & QAMD_CHAIN2_NO_N2OUT) ? 0 : 1);   // (the super-chunk flag is a launch-time choice)
+  {
+    uint32_t chunks = 0, cpb = 0;
+    bool sc = false;
+    if (p->nm < 1 || !chain2_geometry(p, ch, true, chunks, cpb, sc)) return QAMD_EUNSUPPORTED;
+    snprintf(buf, buflen, "chain2r_kernel<%d, %d, %d, %s>", p->D, (p->flags & QAMD_CHAIN2_K1_SINGLE) ? 1 : 2,
+             (p->flags & QAMD_CHAIN2_NO_N2OUT) ? 0 : 1, sc ? "true" : "false");
+  }
   else
     snprintf(buf, buflen, "chain2_kernel<%s, %d, %d>", p->dtype == QAMD_F32 ? "float" : "double", p->D, ch / 16);
   return QAMD_OK;
@@ -698,29 +733,10 @@ extern "C" int qamd_contract_chain2(const qamd_chain2_plan* p, const void* A, co
   a.nm = p->nm;
   for (int i = 0; i < p->nm; ++i) { a.dim_m[i] = (uint32_t)p->dim_m[i]; a.sa_m[i] = p->sa_m[i]; a.sc_m[i] = p->sc_m[i]; }
   a.sa_v = p->sa_v;
-  a.chunks = (uint32_t)(M / ch);
-  const uint32_t ic = (uint32_t)(inner / ch);
-  const uint32_t target = std::max<uint32_t>(4, (a.chunks + 256 * 12 - 1) / (256 * 12));
-  uint32_t best = 0, best_even = 0;
-  for (uint32_t dlo = 1; (uint64_t)dlo * dlo <= ic; ++dlo) {
-    if (ic % dlo) continue;
-    uint32_t cand[2] = {dlo, ic / dlo};
-    for (uint32_t c : cand) {
-      if (c <= target && c > best) best = c;
-      if (c % 2 == 0 && c <= 2 * target && c > best_even) best_even = c;
-    }
-  }
-  if (best < 1) return QAMD_EUNSUPPORTED;
-  a.chunks_per_block = best;
-  // super-chunks (pairs of adjacent chunks per wave, whole-line loads; even chunk count per workgroup):
-  // opt-in with QAMD_C2R_SC=1 -- measured equal to the default on MI355X (0.762 vs 0.764 ms per interior
-  // pair): the 9 % of re-fetched lines it saves is not what bounds the kernel
   {
-    const char* e = getenv("QAMD_C2R_SC");
-    if (best_even >= 2 && e && e[0] == '1' && chain2_uses_registers(p, C)) {
-      a.chunks_per_block = best_even;
-      a.sc = 1;
-    }
+    bool sc = false;
+    if (!chain2_geometry(p, ch, chain2_uses_registers(p, C), a.chunks, a.chunks_per_block, sc)) return QAMD_EUNSUPPORTED;
+    a.sc = sc ? 1 : 0;
   }
   a.grid = a.chunks / a.chunks_per_block;
   if (const char* e = getenv("QAMD_CHAIN2_ABLATE")) a.ablate = (uint32_t)atoi(e);
