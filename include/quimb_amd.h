@@ -237,28 +237,28 @@ int qamd_minmax(void* out_dev, const void* x, int64_t n, int32_t want_min, int32
 /*
  * A whole tree of SMALL contractions walked on the device (quimb's circuit amplitudes: hundreds of
  * pairwise steps on <= 2^10-element tensors, quimb/tensor/circuit/exact.py:417-501 -> the per-step
- * tensordot loop of ctg.array_contract, contraction.py:285).  steps_dev: nsteps plan entries in device
- * memory; inputs_dev: ninst x ninputs device pointers (instance i uses the i-th row; rows may share
- * tensors); arena_dev: ninst x arena_elems elements of scratch for the intermediates; the step with
+ * tensordot loop of ctg.array_contract, contraction.py:285).  steps_dev / etab_dev / ktab_dev: the lowered
+ * plan (below) in device memory; inputs_dev: ninst x ninputs device pointers (instance i uses the i-th row; rows may share
+ * tensors); arena_dev: ninst x arena_elems elements of scratch for the intermediates, or NULL to carve
+ * arena_elems elements out of each workgroup's LDS (dependent steps then hand over through LDS); the step with
  * c_off < 0 writes the result to out_dev (ninst x out_elems).  One 256-thread workgroup per instance.
  * Strides and offsets are in ELEMENTS of the dtype (complex: one element = (re, im)).
  */
-#define QAMD_MICRO_KMAX 4096
+#define QAMD_MICRO_LDS_ARENA_BYTES (112 * 1024)   /* arena_dev == NULL: the arena lives in LDS, at most this big */
+/* One pairwise step, fully lowered by the host: element e < total of the result is
+ *   C[etab[3*(eoff+e)+2]] = sum_{k<K} A[etab[3*(eoff+e)] + ktab[2*(koff+k)]] * B[etab[3*(eoff+e)+1] + ktab[2*(koff+k)+1]]
+ * (the mixed-radix tensor addressing of the GETT, tabulated: the tensors are tiny, the tables cheap, and the
+ * device does no index arithmetic on the dependent path). */
 typedef struct {
   int32_t a_kind, b_kind;      /* operand location: 0 = inputs[ref], 1 = arena + ref */
   int64_t a_ref, b_ref;
   int64_t c_off;               /* arena offset of the result, or -1: the output buffer */
-  int32_t nb, nm, nn, nk;      /* groups per bundle (<= 4 batch, <= QAMD_MAX_GROUPS others) */
-  uint32_t B, M, N, K;         /* bundle sizes; K <= QAMD_MICRO_KMAX */
-  uint32_t dim_b[4], dim_m[QAMD_MAX_GROUPS], dim_n[QAMD_MAX_GROUPS], dim_k[QAMD_MAX_GROUPS];
-  int32_t sa_b[4], sb_b[4], sc_b[4];
-  int32_t sa_m[QAMD_MAX_GROUPS], sc_m[QAMD_MAX_GROUPS];
-  int32_t sb_n[QAMD_MAX_GROUPS], sc_n[QAMD_MAX_GROUPS];
-  int32_t sa_k[QAMD_MAX_GROUPS], sb_k[QAMD_MAX_GROUPS];
+  uint32_t total, K;           /* result elements (B*M*N) and contraction length */
+  uint32_t eoff, koff;         /* first entry of this step in etab (triples) / ktab (pairs) */
 } qamd_micro_step;
-int qamd_microtree_run(int32_t dtype, const qamd_micro_step* steps_dev, int32_t nsteps, const void* const* inputs_dev,
-                       int32_t ninputs, void* arena_dev, int64_t arena_elems, void* out_dev, int64_t out_elems,
-                       int32_t ninst, void* stream);
+int qamd_microtree_run(int32_t dtype, const qamd_micro_step* steps_dev, int32_t nsteps, const int32_t* etab_dev,
+                       const int32_t* ktab_dev, const void* const* inputs_dev, int32_t ninputs, void* arena_dev,
+                       int64_t arena_elems, void* out_dev, int64_t out_elems, int32_t ninst, void* stream);
 
 #ifdef __cplusplus
 }

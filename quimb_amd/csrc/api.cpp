@@ -761,17 +761,18 @@ extern "C" int qamd_contract_chain2(const qamd_chain2_plan* p, const void* A, co
 // ---------------------------------------------------------------------------
 // device-resident tree of small contractions (microtree.hip)
 // ---------------------------------------------------------------------------
-extern "C" int qamd_microtree_launch(int dtype, const qamd_micro_step* steps_dev, int nsteps,
-                                     const void* const* inputs_dev, int ninputs, void* arena_dev,
+extern "C" int qamd_microtree_launch(int dtype, const qamd_micro_step* steps_dev, int nsteps, const int32_t* etab,
+                                     const int32_t* ktab, const void* const* inputs_dev, int ninputs, void* arena_dev,
                                      int64_t arena_elems, void* out_dev, int64_t out_elems, int ninst, void* stream);
 
-extern "C" int qamd_microtree_run(int32_t dtype, const qamd_micro_step* steps_dev, int32_t nsteps,
-                                  const void* const* inputs_dev, int32_t ninputs, void* arena_dev, int64_t arena_elems,
-                                  void* out_dev, int64_t out_elems, int32_t ninst, void* stream) {
-  if (!steps_dev || !inputs_dev || !out_dev || nsteps <= 0 || ninputs <= 0 || ninst <= 0) return QAMD_EINVAL;
+extern "C" int qamd_microtree_run(int32_t dtype, const qamd_micro_step* steps_dev, int32_t nsteps, const int32_t* etab_dev,
+                                  const int32_t* ktab_dev, const void* const* inputs_dev, int32_t ninputs, void* arena_dev,
+                                  int64_t arena_elems, void* out_dev, int64_t out_elems, int32_t ninst, void* stream) {
+  if (!steps_dev || !etab_dev || !ktab_dev || !inputs_dev || !out_dev || nsteps <= 0 || ninputs <= 0 || ninst <= 0)
+    return QAMD_EINVAL;
   if (dtype < 0 || dtype > 3) return QAMD_EUNSUPPORTED;
-  if (arena_elems > 0 && !arena_dev) return QAMD_EINVAL;
-  int rc = qamd_microtree_launch(dtype, steps_dev, nsteps, inputs_dev, ninputs, arena_dev, arena_elems, out_dev,
-                                 out_elems, ninst, stream);
+  if (!arena_dev && arena_elems * (int64_t)kEsize[dtype] > QAMD_MICRO_LDS_ARENA_BYTES) return QAMD_EINVAL;
+  int rc = qamd_microtree_launch(dtype, steps_dev, nsteps, etab_dev, ktab_dev, inputs_dev, ninputs, arena_dev, arena_elems,
+                                 out_dev, out_elems, ninst, stream);
   return rc == 0 ? QAMD_OK : (rc == -2 ? QAMD_EUNSUPPORTED : QAMD_ELAUNCH);
 }

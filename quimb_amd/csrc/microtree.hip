@@ -34,56 +34,73 @@ template <typename R> struct MElem<R, true> {
   }
 };
 
-__device__ __forceinline__ void mdecomp3(uint32_t idx, int n, const uint32_t* dims, const int32_t* s0,
-                                         const int32_t* s1, const int32_t* s2, int64_t& o0, int64_t& o1, int64_t& o2) {
-  for (int g = n - 1; g >= 0; --g) {
-    const uint32_t d = dims[g], q = idx / d, r = idx - q * d;
-    if (s0) o0 += (int64_t)r * s0[g];
-    if (s1) o1 += (int64_t)r * s1[g];
-    if (s2) o2 += (int64_t)r * s2[g];
-    idx = q;
-  }
-}
-
-template <typename R, bool CPLX>
+// LDSARENA: the intermediates live in LDS (the host's lifetime-aware allocation fits): a step then depends
+// on its predecessor through ~100 ns of LDS instead of a write-to-L2 / read-back round trip.
+//
+// The plan is fully lowered on the host (qamd_micro_step + etab + ktab): no index arithmetic on the device.
+// Software pipeline over steps: while step i computes, the header of step i+1 (wave-uniform -> scalar
+// loads), its first KREG k-offset pairs (scalar) and this thread's first address triple are already on
+// their way, so the dependent chain per step is  barrier -> operand reads -> FMAs -> result write.
+template <typename R, bool CPLX, bool LDSARENA>
 __global__ __launch_bounds__(256) void microtree_kernel(const qamd_micro_step* __restrict__ steps, int nsteps,
+                                                        const int32_t* __restrict__ etab,
+                                                        const int32_t* __restrict__ ktab,
                                                         const void* const* __restrict__ inputs, int ninputs,
                                                         void* __restrict__ arena, int64_t arena_elems,
                                                         void* __restrict__ out, int64_t out_elems) {
   typedef typename MElem<R, CPLX>::type E;
-  __shared__ int32_t koffA[QAMD_MICRO_KMAX], koffB[QAMD_MICRO_KMAX];
+  constexpr int KREG = 8;
+  extern __shared__ __attribute__((aligned(16))) char mt_lds[];
   const int tid = threadIdx.x;
   const void* const* my_in = inputs + (int64_t)blockIdx.x * ninputs;
-  E* my_arena = reinterpret_cast<E*>(arena) + (int64_t)blockIdx.x * arena_elems;
+  E* my_arena = LDSARENA ? reinterpret_cast<E*>(mt_lds) : reinterpret_cast<E*>(arena) + (int64_t)blockIdx.x * arena_elems;
   E* my_out = reinterpret_cast<E*>(out) + (int64_t)blockIdx.x * out_elems;
 
+  struct Pre {               // everything of a step that can be fetched before its operands exist
+    qamd_micro_step h;
+    int32_t ka[KREG], kb[KREG];
+    int32_t t0, t1, t2;      // this thread's first address triple
+  };
+  auto fetch = [&](int si, Pre& p) {
+    p.h = steps[si];                                  // wave-uniform address: scalar loads
+#pragma unroll
+    for (int k = 0; k < KREG; ++k) {
+      const bool ok = (uint32_t)k < p.h.K;
+      p.ka[k] = ok ? ktab[2 * (p.h.koff + k)] : 0;
+      p.kb[k] = ok ? ktab[2 * (p.h.koff + k) + 1] : 0;
+    }
+    const bool mine = (uint32_t)tid < p.h.total;
+    const int32_t* t = etab + 3 * (int64_t)(p.h.eoff + (mine ? tid : 0));
+    p.t0 = t[0]; p.t1 = t[1]; p.t2 = t[2];
+  };
+
+  Pre cur, nxt;
+  fetch(0, cur);
   for (int si = 0; si < nsteps; ++si) {
-    const qamd_micro_step& s = steps[si];
+    if (si + 1 < nsteps) fetch(si + 1, nxt);
+    const qamd_micro_step& s = cur.h;
     const E* A = s.a_kind ? my_arena + s.a_ref : reinterpret_cast<const E*>(my_in[s.a_ref]);
     const E* B = s.b_kind ? my_arena + s.b_ref : reinterpret_cast<const E*>(my_in[s.b_ref]);
     E* C = s.c_off >= 0 ? my_arena + s.c_off : my_out;
-    // k offsets of both operands, once per step
-    for (uint32_t k = tid; k < s.K; k += 256) {
-      int64_t oa = 0, ob = 0, dummy = 0;
-      mdecomp3(k, s.nk, s.dim_k, s.sa_k, s.sb_k, nullptr, oa, ob, dummy);
-      koffA[k] = (int32_t)oa;
-      koffB[k] = (int32_t)ob;
-    }
-    __syncthreads();
-    const uint32_t MN = s.M * s.N, total = s.B * MN;
-    for (uint32_t e = tid; e < total; e += 256) {
-      const uint32_t b = e / MN, r = e - b * MN, m = r / s.N, n = r - m * s.N;
-      int64_t oa = 0, ob = 0, oc = 0;
-      mdecomp3(b, s.nb, s.dim_b, s.sa_b, s.sb_b, s.sc_b, oa, ob, oc);
-      int64_t dummy = 0;
-      mdecomp3(m, s.nm, s.dim_m, s.sa_m, nullptr, s.sc_m, oa, dummy, oc);
-      mdecomp3(n, s.nn, s.dim_n, nullptr, s.sb_n, s.sc_n, dummy, ob, oc);
+    for (uint32_t e = tid; e < s.total; e += 256) {
+      int32_t oa = cur.t0, ob = cur.t1, oc = cur.t2;
+      if (e != (uint32_t)tid) {
+        const int32_t* t = etab + 3 * (int64_t)(s.eoff + e);
+        oa = t[0]; ob = t[1]; oc = t[2];
+      }
       E acc = MElem<R, CPLX>::zero();
-      for (uint32_t k = 0; k < s.K; ++k) MElem<R, CPLX>::fma(acc, A[oa + koffA[k]], B[ob + koffB[k]]);
+      // (prefetching the VALUES of input-kind operands one step ahead was measured slower: it lengthens the
+      //  serial load chain of the prefetch itself, which then bounds the step time)
+#pragma unroll
+      for (int k = 0; k < KREG; ++k)
+        if ((uint32_t)k < s.K) MElem<R, CPLX>::fma(acc, A[oa + cur.ka[k]], B[ob + cur.kb[k]]);
+      for (uint32_t k = KREG; k < s.K; ++k)
+        MElem<R, CPLX>::fma(acc, A[oa + ktab[2 * (s.koff + k)]], B[ob + ktab[2 * (s.koff + k) + 1]]);
       C[oc] = acc;
     }
-    __threadfence_block();
+    if (!LDSARENA) __threadfence_block();
     __syncthreads();
+    cur = nxt;
   }
 }
 
@@ -91,20 +108,37 @@ __global__ __launch_bounds__(256) void microtree_kernel(const qamd_micro_step* _
 
 using namespace qamd;
 
-extern "C" int qamd_microtree_launch(int dtype, const qamd_micro_step* steps_dev, int nsteps,
-                                     const void* const* inputs_dev, int ninputs, void* arena_dev,
+template <typename R, bool CP>
+static int launch_microtree(bool lds, size_t lds_bytes, const qamd_micro_step* steps_dev, int nsteps,
+                            const int32_t* etab, const int32_t* ktab, const void* const* inputs_dev, int ninputs, void* arena_dev, int64_t arena_elems,
+                            void* out_dev, int64_t out_elems, int ninst, hipStream_t st) {
+  if (lds) {
+    (void)hipFuncSetAttribute((const void*)microtree_kernel<R, CP, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)lds_bytes);
+    QAMD_LAUNCH((microtree_kernel<R, CP, true>), dim3(ninst), dim3(256), lds_bytes, st, steps_dev, nsteps, etab, ktab,
+                inputs_dev, ninputs, arena_dev, arena_elems, out_dev, out_elems);
+  } else {
+    QAMD_LAUNCH((microtree_kernel<R, CP, false>), dim3(ninst), dim3(256), 0, st, steps_dev, nsteps, etab, ktab,
+                inputs_dev, ninputs, arena_dev, arena_elems, out_dev, out_elems);
+  }
+  return hipGetLastError() == hipSuccess ? 0 : -4;
+}
+
+// arena_dev == NULL: the arena (arena_elems elements per instance) is carved out of LDS
+extern "C" int qamd_microtree_launch(int dtype, const qamd_micro_step* steps_dev, int nsteps, const int32_t* etab,
+                                     const int32_t* ktab, const void* const* inputs_dev, int ninputs, void* arena_dev,
                                      int64_t arena_elems, void* out_dev, int64_t out_elems, int ninst, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   if (nsteps <= 0 || ninst <= 0) return -1;
-#define QAMD_MT(R, CP) QAMD_LAUNCH((microtree_kernel<R, CP>), dim3(ninst), dim3(256), 0, st, steps_dev, nsteps, inputs_dev, \
-                                   ninputs, arena_dev, arena_elems, out_dev, out_elems)
+  static const size_t esz[4] = {4, 8, 8, 16};
+  if (dtype < 0 || dtype > 3) return -2;
+  const bool lds = arena_dev == nullptr && arena_elems > 0;
+  const size_t lds_bytes = lds ? (size_t)arena_elems * esz[dtype] : 0;
+  if (lds_bytes > QAMD_MICRO_LDS_ARENA_BYTES) return -2;
   switch (dtype) {
-    case 0: QAMD_MT(float, false); break;
-    case 1: QAMD_MT(double, false); break;
-    case 2: QAMD_MT(float, true); break;
-    case 3: QAMD_MT(double, true); break;
-    default: return -2;
+    case 0: return launch_microtree<float, false>(lds, lds_bytes, steps_dev, nsteps, etab, ktab, inputs_dev, ninputs, arena_dev, arena_elems, out_dev, out_elems, ninst, st);
+    case 1: return launch_microtree<double, false>(lds, lds_bytes, steps_dev, nsteps, etab, ktab, inputs_dev, ninputs, arena_dev, arena_elems, out_dev, out_elems, ninst, st);
+    case 2: return launch_microtree<float, true>(lds, lds_bytes, steps_dev, nsteps, etab, ktab, inputs_dev, ninputs, arena_dev, arena_elems, out_dev, out_elems, ninst, st);
+    default: return launch_microtree<double, true>(lds, lds_bytes, steps_dev, nsteps, etab, ktab, inputs_dev, ninputs, arena_dev, arena_elems, out_dev, out_elems, ninst, st);
   }
-#undef QAMD_MT
-  return hipGetLastError() == hipSuccess ? 0 : -4;
 }

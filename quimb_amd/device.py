@@ -378,17 +378,26 @@ class HipDevice:
         """One launch for ``table.shape[0]`` instances of the compiled tree ``mt`` (microtree.hip).
         ``table``: int64 [ninst, ninputs] device addresses; ``keep``: objects that own those buffers."""
         torch = self.torch
-        steps_dev = getattr(mt, "_steps_dev", None)     # the plan lives (and dies) with its MicroTree
-        if steps_dev is None:
-            raw = np.frombuffer(mt.packed(), dtype=np.uint8).copy()
-            steps_dev = mt._steps_dev = torch.from_numpy(raw).to(self.tdev)
+        plan = getattr(mt, "_plan_dev", None)           # the plan lives (and dies) with its MicroTree
+        if plan is None:
+            sb, etab, ktab = mt.packed()
+            plan = mt._plan_dev = (
+                torch.from_numpy(np.frombuffer(sb, dtype=np.uint8).copy()).to(self.tdev),
+                torch.from_numpy(etab).to(self.tdev),
+                torch.from_numpy(ktab).to(self.tdev),
+            )
+        steps_dev, etab_dev, ktab_dev = plan
         ninst = int(table.shape[0])
         ptrs = torch.from_numpy(np.ascontiguousarray(table, dtype=np.int64)).to(self.tdev, non_blocking=False)
-        arena = self.empty(max(mt.arena_elems * ninst, 1), mt.dtype)
+        mode = os.environ.get("QAMD_MICRO_ARENA", "auto")      # auto | lds | global
+        use_lds = mt.lds_ok and (mode == "lds" or (mode == "auto" and ninst <= 2 * 256))
+        arena = None if use_lds else self.empty(max(mt.arena_elems * ninst, 1), mt.dtype)
         _lib.check(
             self.lib.qamd_microtree_run(
-                dtype_code(mt.dtype), steps_dev.data_ptr(), len(mt.steps), ptrs.data_ptr(), mt.ninputs,
-                arena.data_ptr(), int(mt.arena_elems), out.data_ptr(), int(mt.out_elems), ninst, self.stream(),
+                dtype_code(mt.dtype), steps_dev.data_ptr(), len(mt.steps), etab_dev.data_ptr(), ktab_dev.data_ptr(),
+                ptrs.data_ptr(), mt.ninputs,
+                None if use_lds else arena.data_ptr(), int(mt.arena_elems), out.data_ptr(), int(mt.out_elems), ninst,
+                self.stream(),
             ),
             "qamd_microtree_run",
         )

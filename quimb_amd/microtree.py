@@ -25,20 +25,21 @@ KMAX = 4096
 
 
 class MicroStepStruct(C.Structure):
-    """Mirror of ``qamd_micro_step``."""
+    """Mirror of ``qamd_micro_step`` (the lowered plan entry)."""
 
     _fields_ = [
         ("a_kind", C.c_int32), ("b_kind", C.c_int32),
         ("a_ref", C.c_int64), ("b_ref", C.c_int64), ("c_off", C.c_int64),
-        ("nb", C.c_int32), ("nm", C.c_int32), ("nn", C.c_int32), ("nk", C.c_int32),
-        ("B", C.c_uint32), ("M", C.c_uint32), ("N", C.c_uint32), ("K", C.c_uint32),
-        ("dim_b", C.c_uint32 * 4), ("dim_m", C.c_uint32 * MAX_GROUPS), ("dim_n", C.c_uint32 * MAX_GROUPS),
-        ("dim_k", C.c_uint32 * MAX_GROUPS),
-        ("sa_b", C.c_int32 * 4), ("sb_b", C.c_int32 * 4), ("sc_b", C.c_int32 * 4),
-        ("sa_m", C.c_int32 * MAX_GROUPS), ("sc_m", C.c_int32 * MAX_GROUPS),
-        ("sb_n", C.c_int32 * MAX_GROUPS), ("sc_n", C.c_int32 * MAX_GROUPS),
-        ("sa_k", C.c_int32 * MAX_GROUPS), ("sb_k", C.c_int32 * MAX_GROUPS),
+        ("total", C.c_uint32), ("K", C.c_uint32), ("eoff", C.c_uint32), ("koff", C.c_uint32),
     ]
+
+
+def _bundle_offsets(groups, col):
+    """Element offsets of a bundle (mixed radix over its groups, last group fastest)."""
+    off = np.zeros(1, dtype=np.int64)
+    for g in groups:
+        off = (off[:, None] + (np.arange(g[0], dtype=np.int64) * g[col])[None, :]).reshape(-1)
+    return off
 
 
 class MicroTree:
@@ -60,10 +61,42 @@ class MicroTree:
         self.ninputs = len(tree.inputs)
         self.out_shape = tuple(tree.size_dict[ix] for ix in tree.output)
         self.out_elems = max(prod(self.out_shape), 1)
-        steps, arena = [], 0
-        loc = {}                                   # node id -> ("in", i) | ("arena", offset)
+        steps = []
+        loc = {}                                   # node id -> (0, input index) | (1, arena offset)
         for i in range(self.ninputs):
             loc[i] = (0, i)
+        # lifetime-aware arena: an intermediate's slot is recycled after its (single) consumer has run
+        # (first-fit over a coalescing free list); the peak footprint decides whether the arena fits in LDS
+        free, top = [], 0                          # free: sorted list of (offset, size)
+
+        def alloc(n):
+            nonlocal top
+            for i, (o, sz) in enumerate(free):
+                if sz >= n:
+                    if sz == n:
+                        free.pop(i)
+                    else:
+                        free[i] = (o + n, sz - n)
+                    return o
+            o, top = top, top + n
+            return o
+
+        def release(o, n):
+            nonlocal top
+            free.append((o, n))
+            free.sort()
+            merged = []
+            for off, sz in free:
+                if merged and merged[-1][0] + merged[-1][1] == off:
+                    merged[-1] = (merged[-1][0], merged[-1][1] + sz)
+                else:
+                    merged.append((off, sz))
+            if merged and merged[-1][0] + merged[-1][1] == top:
+                top = merged.pop()[0]
+            free[:] = merged
+
+        peak = 0
+        sizes = {}
         for entry in ex.plan:
             if entry[0] != "pair":
                 raise ValueError(f"MicroTree: unsupported plan entry {entry[0]!r}")
@@ -79,40 +112,55 @@ class MicroTree:
             if res == ex.root:
                 d["c_off"] = -1
             else:
-                d["c_off"] = arena
-                loc[res] = (1, arena)
-                arena += size
+                off = alloc(size)                  # allocated BEFORE the operands are released: never aliases them
+                d["c_off"] = off
+                loc[res] = (1, off)
+                sizes[res] = size
+                peak = max(peak, top)
+            for nid in (ka, kb):                   # every node of a tree is consumed exactly once
+                if nid in sizes:
+                    release(loc[nid][1], sizes.pop(nid))
             steps.append(d)
+        arena = peak
         if not steps:
             raise ValueError("MicroTree: nothing to contract")
         if steps[-1]["c_off"] != -1:
             raise ValueError("MicroTree: the root is not produced by the last step")
         self.steps = steps
         self.arena_elems = arena
+        #: the arena fits the LDS budget of one workgroup (QAMD_MICRO_LDS_ARENA_BYTES): dependent steps hand over
+        #: through LDS instead of L2 -- the latency mode; large batches may prefer the global arena (more
+        #: workgroups resident per CU)
+        self.lds_ok = 0 < arena * self.dtype.itemsize <= 112 * 1024
         self.flops = sum((8 if self.dtype.kind == "c" else 2) * s["spec"].mults for s in steps)
         self._packed = None
 
     # ---- plan serialisation ---------------------------------------------------------------
     def packed(self):
-        """The step table as bytes (array of ``qamd_micro_step``)."""
+        """The lowered plan: (steps bytes, etab int32 [3 * sum(total)], ktab int32 [2 * sum(K)]) -- every
+        result element's (A, B, C) offsets and every k's (A, B) offsets tabulated on the host."""
         if self._packed is None:
             arr = (MicroStepStruct * len(self.steps))()
+            etabs, ktabs, eoff, koff = [], [], 0, 0
             for t, s in zip(arr, self.steps):
                 sp = s["spec"]
+                ob_a, ob_b, ob_c = (_bundle_offsets(sp.b, c) for c in (1, 2, 3))
+                om_a, om_c = _bundle_offsets(sp.m, 1), _bundle_offsets(sp.m, 3)
+                on_b, on_c = _bundle_offsets(sp.n, 2), _bundle_offsets(sp.n, 3)
+                oa = (ob_a[:, None, None] + om_a[None, :, None] + 0 * on_c[None, None, :]).reshape(-1)
+                ob = (ob_b[:, None, None] + 0 * om_a[None, :, None] + on_b[None, None, :]).reshape(-1)
+                oc = (ob_c[:, None, None] + om_c[None, :, None] + on_c[None, None, :]).reshape(-1)
+                etabs.append(np.stack([oa, ob, oc], axis=1))
+                ktabs.append(np.stack([_bundle_offsets(sp.k, 1), _bundle_offsets(sp.k, 2)], axis=1))
                 t.a_kind, t.a_ref = s["a"]
                 t.b_kind, t.b_ref = s["b"]
                 t.c_off = s["c_off"]
-                t.nb, t.nm, t.nn, t.nk = len(sp.b), len(sp.m), len(sp.n), len(sp.k)
-                t.B, t.M, t.N, t.K = sp.B, sp.M, sp.N, sp.K
-                for i, (d, sa, sb, sc) in enumerate(sp.b):
-                    t.dim_b[i], t.sa_b[i], t.sb_b[i], t.sc_b[i] = d, sa, sb, sc
-                for i, (d, sa, _, sc) in enumerate(sp.m):
-                    t.dim_m[i], t.sa_m[i], t.sc_m[i] = d, sa, sc
-                for i, (d, _, sb, sc) in enumerate(sp.n):
-                    t.dim_n[i], t.sb_n[i], t.sc_n[i] = d, sb, sc
-                for i, (d, sa, sb, _) in enumerate(sp.k):
-                    t.dim_k[i], t.sa_k[i], t.sb_k[i] = d, sa, sb
-            self._packed = bytes(arr)
+                t.total, t.K, t.eoff, t.koff = len(oa), sp.K, eoff, koff
+                eoff += len(oa)
+                koff += sp.K
+            etab = np.ascontiguousarray(np.concatenate(etabs), dtype=np.int32).reshape(-1)
+            ktab = np.ascontiguousarray(np.concatenate(ktabs), dtype=np.int32).reshape(-1)
+            self._packed = (bytes(arr), etab, ktab)
         return self._packed
 
     # ---- execution --------------------------------------------------------------------------
