@@ -662,6 +662,49 @@ def check_linop(dtype, chi=12):
         assert_close((Ag @ qa.asarray(x2)).to_numpy(), dense @ x2, dtype)
 
 
+def check_random_pairs(dtype, ncases=120, seed=77):
+    """Randomised pairwise contractions (random index sets, extents, operand and output orders) against
+    numpy einsum in fp64 -- exercises the kernel-selection logic (tiled / fast-tile / streaming / multi-dot /
+    split-K, every vector-width and contiguity decision) on shapes nobody wrote down by hand."""
+    rng = np.random.default_rng(seed)
+    letters = "abcdefgh"
+    sizes_pool = [1, 2, 3, 4, 6, 8, 16, 32, 64, 128, 256]
+    done = 0
+    while done < ncases:
+        nidx = int(rng.integers(2, 7))
+        idx = list(letters[:nidx])
+        role = {}                      # 'k' contracted, 'm' only a, 'n' only b, 'b' batch
+        for ix in idx:
+            role[ix] = rng.choice(["k", "m", "n", "b"], p=[0.35, 0.3, 0.3, 0.05])
+        if not any(r == "k" for r in role.values()) and rng.random() < 0.8:
+            role[idx[0]] = "k"
+        dims = {ix: int(rng.choice(sizes_pool)) for ix in idx}
+        a_ix = [ix for ix in idx if role[ix] in "kmb"]
+        b_ix = [ix for ix in idx if role[ix] in "knb"]
+        o_ix = [ix for ix in idx if role[ix] in "mnb"]
+        if not a_ix or not b_ix:
+            continue
+        na = int(np.prod([dims[i] for i in a_ix])); nb = int(np.prod([dims[i] for i in b_ix]))
+        no = int(np.prod([dims[i] for i in o_ix])) if o_ix else 1
+        work = int(np.prod([dims[i] for i in idx]))
+        if max(na, nb, no) > 1 << 22 or work > 1 << 27:
+            continue
+        rng.shuffle(a_ix); rng.shuffle(b_ix); rng.shuffle(o_ix)
+        eq = "".join(a_ix) + "," + "".join(b_ix) + "->" + "".join(o_ix)
+        x = rand(rng, [dims[i] for i in a_ix], dtype)
+        y = rand(rng, [dims[i] for i in b_ix], dtype)
+        hi = np.complex128 if np.dtype(dtype).kind == "c" else np.float64
+        want = np.einsum(eq, x.astype(hi), y.astype(hi))
+        scale = np.einsum(eq, np.abs(x).astype(np.float64), np.abs(y).astype(np.float64))
+        got = qa.einsum(eq, qa.asarray(x), qa.asarray(y)).to_numpy()
+        # error budget relative to sum |a||b| (the inputs have a positive mean, so partial sums grow and the
+        # rounding error does not shrink with K): 0.1 * RTOL = 2e-6 in single, 1e-13 in double precision
+        tol = 0.1 * RTOL[np.dtype(dtype)] * np.maximum(scale, 1e-30) + 1e-30
+        assert got.shape == want.shape, eq
+        assert np.all(np.abs(got - want) <= tol), (eq, dims, float(np.max(np.abs(got - want) / tol)))
+        done += 1
+
+
 def check_long_reductions(dtype, seed=14):
     """Reduction-shaped contractions (M*N tiny, K long): norms and projections onto a few vectors --
     the streaming multi-dot kernel on the device."""

@@ -170,6 +170,11 @@ def test_tensor_network_semantics(hip):
     checks.check_tensor_network_semantics()
 
 
+@pytest.mark.parametrize("dtype", ["float64", "float32", "complex64"])
+def test_random_pairs(hip, dtype):
+    checks.check_random_pairs(dtype, ncases=150)
+
+
 @pytest.mark.parametrize("dtype", ["float64", "float32"])
 def test_long_reductions(hip, dtype):
     checks.check_long_reductions(dtype)

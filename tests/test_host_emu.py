@@ -33,6 +33,11 @@ def test_fast_tile_shapes(emu):
     checks.check_fast_tiles("float32")
 
 
+@pytest.mark.parametrize("dtype", ["float64", "float32", "complex64"])
+def test_random_pairs(emu, dtype):
+    checks.check_random_pairs(dtype, ncases=40)
+
+
 @pytest.mark.parametrize("dtype", ["float64", "float32"])
 def test_long_reductions(emu, dtype):
     checks.check_long_reductions(dtype)
