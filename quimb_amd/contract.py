@@ -14,6 +14,7 @@ Where the reference forwards to cotengra, this module drives ``TreeExecutor``.
 """
 
 import contextlib
+import os
 import threading
 from collections import Counter
 
@@ -23,6 +24,11 @@ from .array import Array, asarray
 from .executor import TreeExecutor
 from .pathfind import find_path, find_slices
 from .tree import ContractionTree
+
+
+#: a tree goes to the one-launch walker when it has at least this many steps and no intermediate above this size
+_MICRO_MIN_STEPS = 24
+_MICRO_MAX_ELEMS = 1 << 12
 
 
 class _OptionStack:
@@ -135,6 +141,17 @@ class ContractExpression:
         self.strip_exponent = strip_exponent
         self.constants = dict(constants or {})
         self._const_dev = {k: asarray(v).astype(dtype) for k, v in self.constants.items()}
+        # trees of many small tensors (circuit amplitudes) are dispatch-bound step by step: let the device walk
+        # them in one launch (MicroTree) -- same plan, same arithmetic order per step; QAMD_MICROTREE=0 opts out
+        self._micro = None
+        if (not strip_exponent and tree.nslices == 1 and len(tree.steps) >= _MICRO_MIN_STEPS
+                and os.environ.get("QAMD_MICROTREE", "1") != "0"):
+            try:
+                from .microtree import MicroTree
+
+                self._micro = MicroTree(tree, dtype, max_elems=_MICRO_MAX_ELEMS)
+            except ValueError:
+                self._micro = None
 
     def __call__(self, *arrays, backend=None, slices=None):
         _check_backend(backend)
@@ -143,6 +160,9 @@ class ContractExpression:
             n = len(self.tree.inputs)
             arrays = [self._const_dev[i] if i in self._const_dev else next(it) for i in range(n)]
         host_in = not any(isinstance(a, Array) for a in arrays if not any(a is c for c in self._const_dev.values()))
+        if self._micro is not None and slices is None:
+            out = self._micro(arrays)
+            return out.to_numpy() if host_in else out
         out = self.executor(arrays, strip_exponent=self.strip_exponent, slices=slices)
         if self.strip_exponent:
             out, e = out

@@ -625,6 +625,21 @@ def check_circuit_amplitude(dtype, n=10, depth=6, seed=17):
     ts = [qa.Tensor(a, t) for a, t in zip(arrays, inputs)]
     z = qa.tensor_contract(*ts, optimize="random-greedy")
     assert abs(z - amp) <= tol * max(abs(amp), 2.0 ** (-n / 2))
+    # the drop-in path routes such trees (many steps, tiny tensors) to the one-launch walker on its own ...
+    expr = qa.array_contract_expression(inputs, (), shapes=[a.shape for a in arrays], optimize="greedy", dtype=dtype,
+                                        cache=False)
+    assert expr._micro is not None
+    assert abs(np.asarray(expr(*arrays)).item() - amp) <= tol * max(abs(amp), 2.0 ** (-n / 2))
+    # ... and the step-by-step executor stays available and agrees
+    import os
+    os.environ["QAMD_MICROTREE"] = "0"
+    try:
+        expr0 = qa.array_contract_expression(inputs, (), shapes=[a.shape for a in arrays], optimize="greedy",
+                                             dtype=dtype, cache=False)
+    finally:
+        del os.environ["QAMD_MICROTREE"]
+    assert expr0._micro is None
+    assert abs(np.asarray(expr0(*arrays)).item() - amp) <= tol * max(abs(amp), 2.0 ** (-n / 2))
 
 
 def dmrg_effective_ham(chi, d=2, w=5, seed=23, dtype="float64"):
