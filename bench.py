@@ -196,7 +196,7 @@ def main():
             roof["share_of_step_time"] = tsum / dt
             roof["algorithmic_bytes_per_launch"] = bytes_launch
             roof["flops_per_launch"] = flops_launch
-        cpu = None if args.no_cpu else cpu_baseline(args.D, args.Ly, args.seed)
+        cpu = None if (args.no_cpu or world > 1) else cpu_baseline(args.D, args.Ly, args.seed)   # N=1 only
         out = {
             "metric": "contracted-FLOP/s on PEPS amplitude",
             "value": value,
