@@ -16,6 +16,8 @@ This is the MI355X replacement for the per-step python loop inside
   sliced index are evaluated once and reused by every slice.
 """
 
+import os
+
 import numpy as np
 
 from .array import Array, asarray, _coerce_dtype
@@ -281,6 +283,52 @@ class TreeExecutor:
         are static device buffers -- refresh them in place with ``g.update(i, array)``."""
         return GraphedContraction(self, arrays, strip_exponent)
 
+    def _run_slices_graphed(self, xs, todo):
+        """strip_exponent slice loop as hipGraph replays (HIP device only)."""
+        dev = xs[0]._dev
+        torch = dev.torch
+        sliced = [i for i in range(len(xs)) if self.input_sliced_axes[i]]
+        key = ("slice_graph", tuple(x.shape for x in xs))
+        ent = getattr(self, "_slice_graphs", {}).get(key)
+        if ent is None:
+            vals0 = self._slice_values(todo[0])
+            static = [self._slice_input(x, i, vals0) for i, x in enumerate(xs)]
+            static = [s.copy() if s is x else s for s, x in zip(static, xs)]  # private buffers for the graph
+            side = torch.cuda.Stream(device=dev.tdev)
+            side.wait_stream(torch.cuda.current_stream(dev.tdev))
+            with torch.cuda.stream(side):                                      # warm-up: plans, tables, allocator
+                for _ in range(2):
+                    self._run_core(static, dev.new_exponent(), None)
+            torch.cuda.current_stream(dev.tdev).wait_stream(side)
+            torch.cuda.synchronize(dev.tdev)
+            out_shape = tuple(self.tree.size_dict[ix] for ix in self.tree.output)
+            acc = Array.full(out_shape, 0.0, self.dtype, dev)
+            g_exp = dev.new_exponent()
+            acc_exp = dev.new_exponent_neg_inf()
+            torch.cuda.synchronize(dev.tdev)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                g_exp.zero_()
+                out = self._run_core(static, g_exp, None)
+                dev.axpby_exp(acc._buf, out._buf, acc.size, acc_exp, g_exp, acc.dtype)
+            ent = dict(static=static, g=g, acc=acc, acc_exp=acc_exp, keep=(out, g_exp))
+            if not hasattr(self, "_slice_graphs"):
+                self._slice_graphs = {}
+            self._slice_graphs[key] = ent
+        static, acc, acc_exp = ent["static"], ent["acc"], ent["acc_exp"]
+        dev.fill(acc._buf, acc.size, 0.0, acc.dtype)
+        acc_exp.fill_(float("-inf"))
+        for i in range(len(xs)):                                               # unsliced inputs: refresh once
+            if i not in sliced:
+                static[i]._buf[: xs[i].size].copy_(xs[i]._buf[: xs[i].size])
+        for s in todo:
+            vals = self._slice_values(s)
+            for i in sliced:
+                shape, strides, offset = _slice_view(self, xs[i], i, vals)
+                dev.permute(static[i]._buf, xs[i]._buf, shape, strides, offset, self.dtype)
+            ent["g"].replay()
+        return acc.copy(), dev.read_exponent(acc_exp)
+
     def __call__(self, arrays, strip_exponent=False, slices=None, hoist=True):
         """Contract.  ``slices``: iterable of slice numbers to evaluate (default
         all); the partial sum over exactly those slices is returned, which is what
@@ -311,6 +359,11 @@ class TreeExecutor:
         cache = {} if (hoist and not strip_exponent) else None
         acc, acc_e = None, None
         acc_exp = None   # device-resident exponent of the running sum: the slice loop never syncs with the host
+        if strip_exponent and len(todo) >= 4 and hasattr(dev, "torch") and os.environ.get("QAMD_SLICE_GRAPH", "1") != "0":
+            # every slice runs the SAME launch sequence on differently sliced inputs: record it once as a
+            # hipGraph over static input buffers and replay it per slice (a few tiny slicing copies + one
+            # graph launch instead of ~80 Python-driven launches)
+            return self._run_slices_graphed(xs, todo)
         for s in todo:
             vals = self._slice_values(s)
             ins = [self._slice_input(x, i, vals) for i, x in enumerate(xs)]
@@ -333,6 +386,18 @@ class TreeExecutor:
         elif strip_exponent:
             acc_e = dev.read_exponent(acc_exp)   # the one read-back of the whole slice loop
         return (acc, acc_e) if strip_exponent else acc
+
+
+def _slice_view(ex, x, i, vals):
+    """(shape, strides, offset) of input ``i`` sliced at ``vals`` -- the view ``_slice_input`` copies."""
+    from .pairwise import contig_strides
+
+    st = contig_strides(x.shape)
+    fixed = {ax: vals[ix] for ax, ix in ex.input_sliced_axes[i]}
+    shape = [d for ax, d in enumerate(x.shape) if ax not in fixed]
+    strides = [s for ax, s in enumerate(st) if ax not in fixed]
+    offset = sum(v * st[ax] for ax, v in fixed.items())
+    return shape, strides, offset
 
 
 class GraphedContraction:

@@ -268,8 +268,19 @@ def check_sliced(dtype, seed=6):
     o = orc.oracle_array_contract([a.astype(hi) for a in arrays], inputs, (), path=tree.get_path(),
                                   sliced_inds=st.sliced_inds)
     assert_close(o, want, "float64")
-    # sliced + strip_exponent
+    # sliced + strip_exponent (on the HIP device: the slice loop replays one recorded hipGraph per slice) ...
     m, e = ex(arrays, strip_exponent=True)
+    assert_close(m.to_numpy() * 10**e, want, dtype)
+    m, e = ex(arrays, strip_exponent=True)                     # ... a second call reuses the recorded graph
+    assert_close(m.to_numpy() * 10**e, want, dtype)
+    m, e = ex(arrays, strip_exponent=True, slices=range(1, st.nslices, 2))
+    assert_close(m.to_numpy() * 10**e, p1, dtype, scale=abs(float(want)))
+    import os
+    os.environ["QAMD_SLICE_GRAPH"] = "0"                        # ... and the plain launch-by-launch loop agrees
+    try:
+        m, e = ex(arrays, strip_exponent=True)
+    finally:
+        del os.environ["QAMD_SLICE_GRAPH"]
     assert_close(m.to_numpy() * 10**e, want, dtype)
 
 
