@@ -363,7 +363,15 @@ class TreeExecutor:
             # every slice runs the SAME launch sequence on differently sliced inputs: record it once as a
             # hipGraph over static input buffers and replay it per slice (a few tiny slicing copies + one
             # graph launch instead of ~80 Python-driven launches)
-            return self._run_slices_graphed(xs, todo)
+            if not getattr(self, "_slice_graph_broken", False):
+                try:
+                    return self._run_slices_graphed(xs, todo)
+                except RuntimeError as err:      # capture refused (driver / allocator state): plain loop from now on
+                    import warnings
+
+                    self._slice_graph_broken = True
+                    warnings.warn(f"quimb_amd: hipGraph capture of the slice loop failed ({err}); "
+                                  "falling back to launch-by-launch slices")
         for s in todo:
             vals = self._slice_values(s)
             ins = [self._slice_input(x, i, vals) for i, x in enumerate(xs)]
