@@ -153,6 +153,17 @@ def check_layout_ops(dtype, seed=2):
         want = np.log10(np.max(np.abs(x)))
         assert abs(qa.log10(qa.max(qa.abs(X))).item() - want) <= 1e-6 * max(1.0, abs(want))
     assert qa.log10(100.0) == 2.0 and qa.max([1, 5, 2]) == 5   # non-device inputs keep numpy semantics
+    # dtype / construction / elementwise names of the same table
+    assert qa.astype(X, "float64").dtype == np.float64 and qa.astype(X, "float32").dtype == np.float32
+    np.testing.assert_array_equal(qa.to_numpy(qa.asarray(x)), x)
+    np.testing.assert_array_equal(qa.zeros((3, 2), dtype=dtype).to_numpy(), np.zeros((3, 2), dtype))
+    np.testing.assert_array_equal(qa.ones((4,), dtype=dtype).to_numpy(), np.ones((4,), dtype))
+    np.testing.assert_array_equal(qa.eye(5, dtype=dtype).to_numpy(), np.eye(5, dtype=dtype))
+    assert_close(qa.multiply(X, X).to_numpy(), x * x, dtype)
+    assert_close(qa.real(X).to_numpy(), x.real, dtype)
+    assert_close(qa.imag(X).to_numpy(), x.imag, dtype)
+    assert_close(qa.conj(X).to_numpy(), x.conj(), dtype)
+    assert qa.shape(X) == x.shape and qa.ndim(X) == x.ndim and qa.size(X) == x.size
     for off, a1, a2 in [(0, 0, 1), (1, 1, 3), (-2, 3, 2), (0, 4, 0)]:
         np.testing.assert_array_equal(qa.diagonal(X, off, a1, a2).to_numpy(), np.diagonal(x, off, a1, a2))
     np.testing.assert_array_equal(qa.einsum("abcde->eb", X).to_numpy().shape, (2, 4))
