@@ -190,7 +190,8 @@ class HipDevice:
         """C = (A . W1) . W2 in one pass (chain2r.hip / chain2.hip).  ``c2``: pairwise.Chain2Spec;
         ``w1`` / ``w2``: the small tensors in their own layouts (``c2.w1_pack`` / ``w2_pack`` say how
         to address them); ``ep`` = (slots_a, slots_w1, slots_w2, slots_out) or None."""
-        key = ("chain2", c2, dtype_code(dtype))
+        # the kernel choice (and with it the W addressing mode) follows these switches at call time
+        key = ("chain2", c2, dtype_code(dtype), os.environ.get("QAMD_CHAIN2R"), os.environ.get("QAMD_C2R_SC"))
         ent = self._pairs.get(key)
         if ent is None:
             pl = _lib.Chain2PlanStruct()

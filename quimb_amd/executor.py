@@ -40,6 +40,8 @@ class TreeExecutor:
     pinned by tests/test_tensor/test_contract.py:155-172 in the reference)."""
 
     def __init__(self, tree: ContractionTree, dtype="float32"):
+        if os.environ.get("QAMD_REGROUP", "1") != "0":
+            tree = tree.regrouped()          # (A.W1).W2 -> A.(W1.W2) where cheaper (sliced bonds); same result
         self.tree = tree
         self.dtype = _coerce_dtype(dtype)
         size = tree.size_dict

@@ -151,6 +151,39 @@ class ContractionTree:
     def with_slices(self, sliced_inds):
         return ContractionTree(self.inputs, self.output, self.size_dict, ssa_path=self.ssa_path, sliced_inds=sliced_inds)
 
+    def regrouped(self, max_small=1 << 16, gain=0.75):
+        """Re-associate ``(A . W1) . W2`` into ``A . (W1 . W2)`` wherever that lowers the cost.
+
+        Site-by-site absorption orders (``sweep_path_2d``, or any path found on the unsliced network) stay
+        optimal while every site tensor has all its legs; once a bond next to two neighbouring sites is
+        sliced away, contracting the two small tensors first makes ONE pass over the big operand instead
+        of two -- fewer multiplications and a third of the HBM traffic.  Only consecutive steps are
+        rewritten, and only where the two steps' multiplications drop below ``gain`` x their old count (the
+        caller's tree is otherwise executed as given); the small product is capped at ``max_small`` elements, and the result is the same
+        tensor (contraction is associative); ids, inputs and output are unchanged."""
+        n = len(self.inputs)
+        best = self
+        si = 0
+        while si + 1 < len(best.ssa_path):
+            ssa = best.ssa_path
+            c1, c2 = ssa[si], ssa[si + 1]
+            r1 = n + si
+            if len(c1) == 2 and len(c2) == 2 and r1 in c2 and c2[0] != c2[1]:
+                w2 = c2[0] if c2[1] == r1 else c2[1]
+                if w2 < r1:
+                    for a, w1 in (c1, c1[::-1]):
+                        trial = list(ssa)
+                        trial[si], trial[si + 1] = (w1, w2), (a, r1)
+                        t = ContractionTree(self.inputs, self.output, self.size_dict, ssa_path=trial,
+                                            sliced_inds=self.sliced_inds)
+                        small = prod(self.size_dict[ix] for ix in t.steps[si][3])
+                        old_cost = best.steps[si][4] + best.steps[si + 1][4]
+                        if small <= max_small and t.steps[si][4] + t.steps[si + 1][4] < gain * old_cost:
+                            best = t
+                            break
+            si += 1
+        return best
+
     def death_times(self):
         """For every ssa id: {ind: step at which that index is contracted away}
         (indices surviving to the output never die)."""

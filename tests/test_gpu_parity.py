@@ -90,11 +90,16 @@ def test_fused_pairs(hip, Lx, Ly, D, dtype):
                                        strip_exponent=True)
     want = wm.item() * 10.0**we
     os.environ["QAMD_CHAIN2"] = "1"
+    os.environ["QAMD_REGROUP"] = "0"     # the tree exactly as given: every row has a start and an end pair
     try:
         ex = qa.TreeExecutor(tree, dtype)
     finally:
         del os.environ["QAMD_CHAIN2"]
+        del os.environ["QAMD_REGROUP"]
     assert any(e[0] == "chain2" for e in ex.plan)
+    exr = qa.TreeExecutor(tree, dtype)   # default: small operands regrouped where that is a clear win
+    assert exr.flops() <= ex.flops()
+    assert exr(arrays).to_numpy().item() == pytest.approx(want, rel=5e-6 if dtype == "float32" else 1e-11)
     if dtype == "float32":   # the opt-in super-chunk variant (whole-line loads + lane swaps) must agree as well
         os.environ["QAMD_C2R_SC"] = "1"
         try:
