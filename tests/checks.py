@@ -3,6 +3,7 @@ on whatever default device the calling test installed -- the HIP device in the
 ``-m gpu`` tests, the numpy plan interpreter in the CPU tests) with the oracle
 / numpy on the same seeded inputs.  Tolerances are written here once."""
 
+import math
 import itertools
 
 import numpy as np
@@ -848,3 +849,61 @@ def check_tensor_network_semantics():
     assert tne ^ all == pytest.approx(whole * 100.0, rel=1e-10)
     m, e = tne.contract(all, strip_exponent=True)
     assert m * 10**e == pytest.approx(whole * 100.0, rel=1e-10)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# boundary contraction (TensorNetwork2D.contract_boundary, quimb/tensor/tn2d/core.py:2502)
+# ---------------------------------------------------------------------------------------------------------
+def boundary_golden():
+    """tests/golden/boundary.npz: values of the REAL quimb's ``contract_boundary(max_bond=chi)`` (made by
+    tests/golden/make_golden.py) -> {name: (arrays, Lx, Ly, exact, chis, values, (mantissa, exponent))}."""
+    import json
+
+    g = np.load(_os.path.join(GOLDEN, "boundary.npz"))
+    out = {}
+    for name in json.loads(str(g["names"])):
+        Lx, Ly = (int(v) for v in g[name + "_shape"])
+        arrs = [g[f"{name}_a{k}"] for k in range(Lx * Ly)]
+        out[name] = (arrs, Lx, Ly, float(g[name + "_exact"]), [int(c) for c in g[name + "_chis"]],
+                     [float(v) for v in g[name + "_vals"]], tuple(float(v) for v in g[name + "_stripped"]))
+    return out
+
+
+def check_boundary_golden(fn, rtol):
+    """``fn(arrays, Lx, Ly, max_bond=..., strip_exponent=...)`` against the real quimb's values: same truncation
+    decisions, so agreement is at rounding level -- far below the truncation error itself."""
+    for name, (arrs, Lx, Ly, exact, chis, vals, (m, e)) in boundary_golden().items():
+        for chi, want in zip(chis, vals):
+            got = fn(arrs, Lx, Ly, max_bond=chi)
+            assert got == pytest.approx(want, rel=rtol), (name, chi)
+        gm, ge = fn(arrs, Lx, Ly, max_bond=chis[-1], strip_exponent=True)
+        assert abs(gm) == pytest.approx(1.0, rel=1e-12) and gm * m > 0
+        assert ge == pytest.approx(e, abs=max(rtol, 1e-12) * 10)
+        # no truncation at all reproduces the exact contraction
+        if Lx * Ly <= 36:
+            assert fn(arrs, Lx, Ly, max_bond=None, cutoff=0.0) == pytest.approx(exact, rel=max(rtol, 1e-11))
+
+
+def check_boundary(dtype="float64"):
+    """The product path against the golden values, the reference's own accuracy bar
+    (tests/test_tensor/test_tn2d/test_core.py:241-274: 8x8 D=2 uniform(-0.1, 1), chi=4, rel=1e-3 vs exact) and
+    its fixed-number known-answer test (16x16 Ising partition function at beta=0.44 = 8.459419593253275e100,
+    chi=8, rel=3.9e-9 two-sided / 2.2e-7 one-sided, test_core.py:309-335)."""
+    import quimb_amd as qa
+
+    f64 = np.dtype(dtype) == np.float64
+    fn = lambda arrs, Lx, Ly, **kw: qa.contract_boundary_2d(arrs, Lx, Ly, dtype=dtype, **kw)
+    check_boundary_golden(fn, 1e-9 if f64 else 3e-4)
+    arrs, Lx, Ly, exact, chis, vals, _ = boundary_golden()["u8x8D2"]
+    assert fn(arrs, Lx, Ly, max_bond=4) == pytest.approx(exact, rel=1e-3)
+    # fixed-number KAT; fp32 cannot hold 1e100, so it goes through the stripped exponent
+    arrays, _ = orc.tn2d_classical_ising(16, 16, 0.44)
+    want = math.log10(8.459419593253275e100)
+    m, e = fn(arrays, 16, 16, max_bond=8, strip_exponent=True)
+    assert m > 0 and e == pytest.approx(want, abs=(3.9e-9 if f64 else 5e-4) / math.log(10) * 1.01 + 1e-13), (m, e, want)
+    m1, e1 = fn(arrays, 16, 16, max_bond=8, strip_exponent=True, sequence=("xmin",))
+    assert m1 > 0 and e1 == pytest.approx(want, abs=(2.2e-7 if f64 else 5e-4) / math.log(10) * 1.01), (m1, e1, want)
+    with pytest.raises(ValueError):
+        fn(arrays[:-1], 16, 16)
+    with pytest.raises(ValueError):
+        fn(arrays, 16, 16, sequence=("ymin",))

@@ -224,3 +224,21 @@ class EmuDevice:
         out = self.empty(1, dtype)
         out[0] = np.min(x[:n]) if want_min else np.max(x[:n])
         return out
+
+    # decompositions (quimb_amd.linalg asks the device first): numpy LAPACK on the emulated buffers
+    def _wrap_np(self, x):
+        from quimb_amd.array import Array
+
+        return Array.from_numpy(np.ascontiguousarray(x), dev=self)
+
+    def linalg_svd(self, x, full_matrices=False):
+        u, s, vh = np.linalg.svd(x.to_numpy(), full_matrices=full_matrices)
+        return self._wrap_np(u), self._wrap_np(s), self._wrap_np(vh)
+
+    def linalg_qr(self, x, mode="reduced"):
+        q, r = np.linalg.qr(x.to_numpy(), mode=mode)
+        return self._wrap_np(q), self._wrap_np(r)
+
+    def linalg_eigh(self, x):
+        w, v = np.linalg.eigh(x.to_numpy())
+        return self._wrap_np(w), self._wrap_np(v)

@@ -6,7 +6,7 @@ __version__ = "0.0-shim"
 
 
 def _decorator(*args, **kwargs):
-    if len(args) == 1 and callable(args[0]) and not kwargs:
+    if len(args) == 1 and callable(args[0]):      # also njit(fn, cache=True), quimb/core.py:50
         return args[0]
     def wrap(fn):
         return fn

@@ -120,6 +120,43 @@ def main():
     cut = [ix for ix in tn.inner_inds()][:2]
     parts = [stn.contract(all, optimize="greedy") for stn in tn.cut_iter(*cut)]
     save_network("tn2d_cut_3x3_D3", tn, dict(value=np.asarray(full), cut=json.dumps(list(cut)), parts=np.asarray(parts)))
+    # 9. boundary contraction (TensorNetwork2D.contract_boundary, tn2d/core.py:2502; the accuracy test
+    #    tests/test_tensor/test_tn2d/test_core.py:241-274 uses the same uniform(-0.1, 1) fill)
+    def site_arrays(tn, Lx, Ly):
+        """Row-major site data re-ordered to l, r, u (row i+1), d (row i-1) by bond NAME (no layout assumed)."""
+        out = []
+        for i in range(Lx):
+            for j in range(Ly):
+                t = tn[tn.site_tag(i, j)]
+                order = []
+                for (ii, jj) in ((i, j - 1), (i, j + 1), (i + 1, j), (i - 1, j)):
+                    if 0 <= ii < Lx and 0 <= jj < Ly:
+                        (b,) = qtn.bonds(t, tn[tn.site_tag(ii, jj)])
+                        order.append(b)
+                out.append(np.asarray(t.transpose(*order).data))
+        return out
+
+    cases = {}
+    for name, Lx, Ly, D, chis in (("u8x8D2", 8, 8, 2, (2, 4)), ("u6x6D3", 6, 6, 3, (3, 6)),
+                                   ("u4x7D3", 4, 7, 3, (4,)), ("u7x4D3", 7, 4, 3, (4,))):
+        frng = np.random.default_rng(hash(name) % 1000 if False else len(name) * 100 + Lx * 10 + Ly)
+        tn = qtn.TN2D_from_fill_fn(lambda shape: frng.uniform(-0.1, 1.0, size=shape), Lx, Ly, D)
+        cases[name] = (tn, Lx, Ly, chis)
+    cases["ising8x8"] = (qtn.TN2D_classical_ising_partition_function(8, 8, 0.44), 8, 8, (2, 4))
+    out = {"names": json.dumps(sorted(cases))}
+    for name, (tn, Lx, Ly, chis) in cases.items():
+        arrs = site_arrays(tn, Lx, Ly)
+        for k, a in enumerate(arrs):
+            out[f"{name}_a{k}"] = a
+        out[f"{name}_shape"] = np.array([Lx, Ly])
+        out[f"{name}_exact"] = np.asarray(tn.contract(all, optimize="greedy"))
+        out[f"{name}_chis"] = np.array(chis)
+        out[f"{name}_vals"] = np.array([tn.contract_boundary(max_bond=chi) for chi in chis])
+        m, e = tn.contract_boundary(max_bond=chis[-1], strip_exponent=True)
+        out[f"{name}_stripped"] = np.array([m, e])
+        print(name, out[f"{name}_exact"], out[f"{name}_vals"], out[f"{name}_stripped"])
+    np.savez_compressed(os.path.join(HERE, "boundary.npz"), **out)
+    print("wrote boundary")
     print("quimb version:", qu.__version__)
 
 

@@ -46,3 +46,27 @@ def test_host_logic_matches_golden(emu):
 @pytest.mark.gpu
 def test_hip_matches_golden(hip):
     checks.check_golden(**_product_fns(), rtol=1e-10)
+
+
+def test_boundary_oracle_matches_real_quimb():
+    """The restated boundary contraction reproduces the real quimb's ``contract_boundary`` values (made by
+    tests/golden/make_golden.py through the stand-ins) to rounding level, square and rectangular lattices,
+    plain and stripped."""
+
+    def fn(arrs, Lx, Ly, strip_exponent=False, **kw):
+        m, e = orc.oracle_contract_boundary_2d(arrs, Lx, Ly, **kw)
+        if strip_exponent:
+            return m / abs(m), e + np.log10(abs(m))
+        return m * 10.0**e
+
+    checks.check_boundary_golden(fn, 1e-12)
+
+
+def test_boundary_host_logic_matches_real_quimb(emu):
+    checks.check_boundary("float64")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+def test_boundary_hip_matches_real_quimb(hip, dtype):
+    checks.check_boundary(dtype)
