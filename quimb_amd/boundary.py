@@ -80,12 +80,13 @@ class _Line:
             t[j] = q.reshape((l, x, k))
             t[j + 1] = ops.tensordot(rr, t[j + 1], axes=([1], [0]))
 
-    def compress(self, max_bond, cutoff):
+    def compress(self, max_bond, cutoff, method="svd"):
         """SVD sweep right -> left, truncating every bond; U*s is absorbed towards the left."""
         t = self.t
+        svd = linalg.svd if method == "svd" else linalg.svd_via_eig
         for j in range(len(t) - 1, 0, -1):
             l, x, r = t[j].shape
-            u, s, vh = linalg.svd(t[j].reshape((l, x * r)))
+            u, s, vh = svd(t[j].reshape((l, x * r)))
             sh = s.to_numpy()
             k = _n_keep(sh, max_bond, cutoff)
             t[j] = vh[:k, :].reshape((k, x, r))
@@ -104,19 +105,24 @@ class _Line:
 
 
 def contract_boundary_2d(arrays, Lx, Ly, max_bond=None, cutoff=1e-10, canonize=True, sequence=None,
-                         strip_exponent=False, dtype=None):
+                         strip_exponent=False, dtype=None, method="svd"):
     """Value of an open ``Lx`` x ``Ly`` network given as the row-major list of site arrays in the
     reference's l, r, u, d leg order (``TN2D_from_fill_fn``, quimb/tensor/tensor_builder.py:1345-1369;
     ``u`` points to row i+1).
 
     ``max_bond=None`` with ``cutoff=0`` is exact.  ``sequence`` (subset of ("xmin", "xmax"), default both)
-    names the sides that move inwards, alternately, until the two lines are adjacent.  Returns the scalar,
+    names the sides that move inwards, alternately, until the two lines are adjacent.  ``method``: "svd"
+    (rocSOLVER ``gesvd``) or "eig" (``linalg.svd_via_eig``: Gram matrix on the GETT kernels + ``syevd`` -- the
+    reference's ``method="svd:eig"`` split; singular values below ~sqrt(eps) x the largest lose accuracy, which
+    is harmless for values that are truncated anyway).  Returns the scalar,
     or ``(mantissa, exponent)`` with ``mantissa * 10**exponent`` the value when ``strip_exponent``."""
     if len(arrays) != Lx * Ly:
         raise ValueError(f"expected {Lx * Ly} site arrays, got {len(arrays)}")
     if Lx < 2 or Ly < 1:
         raise ValueError("need at least two rows")
     sequence = tuple(sequence) if sequence is not None else ("xmin", "xmax")
+    if method not in ("svd", "eig"):
+        raise ValueError("method must be 'svd' or 'eig'")
     if not sequence or any(s not in ("xmin", "xmax") for s in sequence):
         raise ValueError("sequence must name 'xmin' and / or 'xmax' (rows are the sweep direction here)")
     xs = [asarray(a) if dtype is None else asarray(a).astype(dtype) for a in arrays]
@@ -150,7 +156,7 @@ def contract_boundary_2d(arrays, Lx, Ly, max_bond=None, cutoff=1e-10, canonize=T
         if truncate:
             if canonize:
                 line.canonize()
-            line.compress(max_bond, cutoff)
+            line.compress(max_bond, cutoff, method)
         line.equalize()
     # the two lines are adjacent: contract the ladder exactly, left to right
     env = None
