@@ -29,6 +29,7 @@ from .linop import TNLinearOperator
 from .eigsolve import eigh_lanczos
 from .microtree import MicroTree
 from .boundary import contract_boundary_2d
+from .dmrg import DMRG2, mpo_ham_heis
 from .network import TensorNetwork
 from .pathfind import find_path, find_slices, greedy_path, random_greedy, sweep_path_2d
 from .tree import ContractionTree

@@ -27,14 +27,17 @@ def _matvec(A, x):
     return ops.matmul(A, x)
 
 
-def eigh_lanczos(A, k=1, which="SA", v0=None, ncv=None, tol=1e-10, maxiter=None, return_vecs=True):
+def eigh_lanczos(A, k=1, which="SA", v0=None, ncv=None, tol=1e-10, maxiter=None, return_vecs=True, miniter=0):
     """``k`` extremal eigenpairs of the Hermitian operator ``A`` (anything with ``.shape``, ``.dtype`` and
     ``.matvec`` on device arrays -- a ``TNLinearOperator`` -- or a dense device matrix).
 
     Lanczos with full re-orthogonalisation in a basis of ``ncv`` device vectors and explicit restart
     from the current Ritz vector(s); converged when every wanted Ritz pair has residual
     ``|beta_m s_m| <= tol * max(|theta|, 1)`` (``tol = 0`` means machine precision, as in scipy).
-    ``which``: "SA" (algebraically smallest) or "LA" (largest)."""
+    ``which``: "SA" (algebraically smallest) or "LA" (largest).  ``miniter``: Lanczos steps taken before the
+    residual test may stop the first cycle -- an implicitly restarted solver (ARPACK, the reference's default)
+    always completes one ``ncv``-step cycle, so a loose ``tol`` still improves a good starting vector; DMRG
+    passes ``miniter=ncv`` for the same effect."""
     if which not in ("SA", "LA"):
         raise ValueError("which must be 'SA' or 'LA'")
     n = int(A.shape[0])
@@ -97,7 +100,7 @@ def eigh_lanczos(A, k=1, which="SA", v0=None, ncv=None, tol=1e-10, maxiter=None,
             kk = min(k, j_done)
             theta, S = evals[order[:kk]], evecs[:, order[:kk]]
             resid = np.abs(beta * S[-1, :])
-            if j_done >= k and np.all(resid <= tol * np.maximum(np.abs(theta), 1.0)):
+            if j_done >= max(k, min(int(miniter), m)) and np.all(resid <= tol * np.maximum(np.abs(theta), 1.0)):
                 break
             if beta <= eps * max(abs(alphas[-1]), 1.0) or j + 1 == m:
                 break                                  # invariant subspace found, or basis full

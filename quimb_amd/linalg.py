@@ -19,7 +19,9 @@ def _as_torch(x):
 
 
 def _wrap(x, t):
-    t = t.contiguous()
+    # torch hands back lazily conjugated views (``Vh`` of a complex svd carries the conj bit): the kernels read
+    # raw memory, so materialise them
+    t = t.resolve_conj().resolve_neg().contiguous()
     return Array(x._dev, t.reshape(-1), tuple(t.shape), x.dtype if t.dtype == x._buf.dtype else _np_dtype(t))
 
 
@@ -58,7 +60,7 @@ def svd(x, full_matrices=False):
     t, scale = _unit_scale(t)
     u, s, vh = torch.linalg.svd(t, full_matrices=full_matrices)
     s = s * scale
-    return _wrap(x, u), Array(x._dev, s.contiguous().reshape(-1), tuple(s.shape), _np_dtype(s)), _wrap(x, vh)
+    return _wrap(x, u), Array(x._dev, s.resolve_conj().contiguous().reshape(-1), tuple(s.shape), _np_dtype(s)), _wrap(x, vh)
 
 
 def svd_via_eig(x, max_bond=-1):

@@ -157,6 +157,29 @@ def main():
         print(name, out[f"{name}_exact"], out[f"{name}_vals"], out[f"{name}_stripped"])
     np.savez_compressed(os.path.join(HERE, "boundary.npz"), **out)
     print("wrote boundary")
+    # 10. DMRG2 (tn1d/dmrg.py): the reference's MPO tensors, its per-sweep energies for a fixed schedule and
+    #     the dense ground energy (tests/test_tensor/test_tn1d/test_dmrg.py:240-311)
+    out = {}
+    for name, L, kw in (("heis10", 10, {}), ("heis6_bz", 6, {"bz": 0.3})):
+        H = qtn.MPO_ham_heis(L, **kw)
+        for k in range(L):
+            out[f"{name}_w{k}"] = np.asarray(H[k].data)      # first (r,k,b) / bulk (l,r,k,b) / last (l,k,b)
+        out[f"{name}_dense"] = np.asarray(H.to_dense())
+        dm = qtn.DMRG2(H, bond_dims=[8, 16, 32], cutoffs=1e-10)
+        out[f"{name}_converged"] = dm.solve(tol=1e-9, max_sweeps=8)
+        out[f"{name}_energies"] = np.array(dm.energies)
+        out[f"{name}_e0"] = np.linalg.eigvalsh(out[f"{name}_dense"])[0]
+        out[f"{name}_max_bond"] = dm.state.max_bond()
+        print(name, out[f"{name}_energies"], out[f"{name}_e0"], out[f"{name}_max_bond"])
+    builder = qtn.SpinHam1D(1 / 2)
+    builder[0, 1] += 1.0, "Z", "Z"
+    H = builder.build_mpo(2)
+    out["zz2_w0"], out["zz2_w1"] = np.asarray(H[0].data), np.asarray(H[1].data)
+    dm = qtn.DMRG2(H)
+    dm.solve()
+    out["zz2_energy"] = dm.energy
+    np.savez_compressed(os.path.join(HERE, "dmrg.npz"), **out)
+    print("wrote dmrg", out["zz2_energy"])
     print("quimb version:", qu.__version__)
 
 

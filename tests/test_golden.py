@@ -70,3 +70,14 @@ def test_boundary_host_logic_matches_real_quimb(emu):
 @pytest.mark.parametrize("dtype", ["float64", "float32"])
 def test_boundary_hip_matches_real_quimb(hip, dtype):
     checks.check_boundary(dtype)
+
+
+def test_dmrg2_host_logic_matches_real_quimb(emu):
+    """Same MPO tensors, same schedule as a run of the real quimb's DMRG2: same converged energy and bond."""
+    checks.check_dmrg("float64")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+def test_dmrg2_hip_matches_real_quimb(hip, dtype):
+    checks.check_dmrg(dtype)

@@ -220,6 +220,37 @@ def test_svd_via_eig(hip, dtype, shape):
     assert Uk.shape == (shape[0], 5) and sk.shape == (5,) and VHk.shape == (5, shape[1])
 
 
+@pytest.mark.parametrize("dtype", ["float32", "float64", "complex64", "complex128"])
+def test_linalg_results_feed_the_kernels(hip, dtype):
+    """Decomposition factors come back through torch / rocSOLVER and go straight into this library's kernels,
+    which read RAW device memory: lazily conjugated views (``Vh`` of a complex svd) must be materialised, and
+    entries around 1e12 -- where rocSOLVER's fp32 ``gesvd`` returns wrong singular values -- must still give
+    the right answer.  Reconstruction is done by the GETT kernels, not by torch."""
+    import quimb_amd as qa
+
+    rng = np.random.default_rng(5)
+    low = np.dtype(dtype).name in ("float32", "complex64")
+    tol = 2e-5 if low else 1e-12
+    for scale in (1.0, 3e12):
+        x = checks.rand(rng, (24, 40), dtype) * np.dtype(dtype).type(scale)
+        X = qa.asarray(x)
+        u, s, vh = qa.linalg.svd(X)
+        s_ref = np.linalg.svd(x.astype(np.complex128), compute_uv=False)
+        assert np.max(np.abs(s.to_numpy() - s_ref)) <= tol * s_ref[0]
+        us = qa.multiply(u, qa.asarray(s.to_numpy().astype(dtype))[None, :])
+        rec = qa.tensordot(us, vh[:24, :], axes=([1], [0])).to_numpy()
+        assert np.max(np.abs(rec - x)) <= 20 * tol * s_ref[0]
+        q, r = qa.linalg.qr(X)
+        rec = qa.tensordot(q, r, axes=([1], [0])).to_numpy()
+        assert np.max(np.abs(rec - x)) <= 20 * tol * s_ref[0]
+        h = x[:, :24] + x[:, :24].conj().T
+        w, v = qa.linalg.eigh(qa.asarray(h))
+        w_ref = np.linalg.eigvalsh(h.astype(np.complex128))
+        assert np.max(np.abs(w.to_numpy() - w_ref)) <= 5 * tol * np.abs(w_ref).max()
+        hv = qa.tensordot(qa.asarray(h), v, axes=([1], [0])).to_numpy()
+        assert np.max(np.abs(hv - v.to_numpy() * w.to_numpy())) <= 50 * tol * np.abs(w_ref).max()
+
+
 def test_complex_abs(hip):
     checks.check_complex_abs()
 
