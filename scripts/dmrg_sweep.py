@@ -2,7 +2,7 @@
 """BASELINE config #5 end to end: ``DMRG2(MPO_ham_heis(L), bond_dims=chi)`` sweeps on the device
 (quimb_amd.dmrg.DMRG2; reference quimb/tensor/tn1d/dmrg.py).  Prints wall time per sweep and the energy.
 
-    python scripts/dmrg_sweep.py [L] [chi] [sweeps] [split]
+    python scripts/dmrg_sweep.py [L] [chi] [sweeps] [split] [sweep sequence, e.g. RL]
 """
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -15,14 +15,50 @@ L = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 chi = int(sys.argv[2]) if len(sys.argv) > 2 else 512
 nsweeps = int(sys.argv[3]) if len(sys.argv) > 3 else 2
 split = sys.argv[4] if len(sys.argv) > 4 else "eig"
+seq = sys.argv[5] if len(sys.argv) > 5 else "R"            # the reference's default sweeps rightwards every time
+import quimb_amd.dmrg as qdm
+
+# where a sweep's wall time goes (device sync around every phase: slightly pessimistic)
+phase = {}
+
+
+def timed(name, fn):
+    def w(*a, **k):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        out = fn(*a, **k)
+        torch.cuda.synchronize()
+        phase[name] = phase.get(name, 0.0) + time.perf_counter() - t0
+        return out
+    return w
+
+
+if os.environ.get("QAMD_DMRG_PHASES", "1") != "0":
+    qdm.eigh_lanczos = timed("local eigensolve (Lanczos + matvecs)", qdm.eigh_lanczos)
+
+    class _L:
+        svd = staticmethod(timed("split (gesvd)", qa.linalg.svd))
+        svd_via_eig = staticmethod(timed("split (Gram eigh)", qa.linalg.svd_via_eig))
+        qr = staticmethod(timed("canonize (QR)", qa.linalg.qr))
+    qdm.linalg = _L
+    qdm.DMRG2._grow_left = timed("environment update", qdm.DMRG2._grow_left)
+    qdm.DMRG2._grow_right = timed("environment update", qdm.DMRG2._grow_right)
+    qdm.TNLinearOperator = timed("operator setup", qdm.TNLinearOperator)
+
 dm = DMRG2(mpo_ham_heis(L), bond_dims=[chi], cutoffs=1e-10, split=split)
 print(f"DMRG2 Heisenberg L={L} fp64, max bond {chi}, split={split}; start bond {dm.max_bond()}")
 prev = "0"
 for k in range(nsweeps):
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    e = dm.sweep("R", canonize=True, max_bond=chi, cutoff=1e-10)
+    direction = seq[k % len(seq)]
+    e = dm.sweep(direction, canonize=not (direction + prev in {"LR", "RL"}), max_bond=chi, cutoff=1e-10)
+    prev = direction
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    print(f"  sweep {k + 1}: {dt:7.2f} s   energy {e:.10f}   E/L {e / L:.8f}   max bond {dm.max_bond()}", flush=True)
+    print(f"  sweep {k + 1} ({direction}): {dt:7.2f} s   energy {e:.10f}   E/L {e / L:.8f}   max bond {dm.max_bond()}", flush=True)
+    if phase:
+        print("      " + "; ".join(f"{n} {v:.2f} s" for n, v in sorted(phase.items(), key=lambda kv: -kv[1]))
+              + f"; other {dt - sum(phase.values()):.2f} s", flush=True)
+        phase.clear()
 print("  (Bethe ansatz, L -> inf: E/L = 1/4 - ln 2 = %.8f)" % (0.25 - np.log(2)))
