@@ -23,7 +23,11 @@ else:
 size = {i: D for i in set(la) | set(l1) | set(l2)}
 c2 = plan_chain2(la, l1, lx, l2, lc, size, "float32")
 assert c2 is not None
-rnd = lambda n: torch.rand(n, device=dev.tdev) - 0.5
+# QAMD_C2_DATA: "sym" uniform(-0.5, 0.5) | "pos" uniform(0.1, 1.1) | "const" all ones -- the launch time depends on
+# the data through power (DVFS), not through the instruction stream
+mode = os.environ.get("QAMD_C2_DATA", "sym")
+rnd = {"sym": lambda n: torch.rand(n, device=dev.tdev) - 0.5, "pos": lambda n: torch.rand(n, device=dev.tdev) + 0.1,
+       "const": lambda n: torch.ones(n, device=dev.tdev)}[mode]
 A = qa.Array(dev, rnd(D ** len(la)), (D,) * len(la), "float32")
 W1 = qa.Array(dev, rnd(D ** len(l1)), (D,) * len(l1), "float32")
 W2 = qa.Array(dev, rnd(D ** len(l2)), (D,) * len(l2), "float32")
@@ -38,7 +42,7 @@ e0.record()
 for _ in range(10): run()
 e1.record(); torch.cuda.synchronize()
 t = e0.elapsed_time(e1) / 10 * 1e-3
-print(f"{variant} ablate={os.environ.get('QAMD_CHAIN2_ABLATE','0')} V1={os.environ.get('QAMD_CHAIN2_V1','')} {t*1e3:.3f} ms  {2*c2.mults/t/1e12:.1f} TF  {4*(c2.a_size+c2.c_size)/t/1e9:.0f} GB/s")
+print(f"{variant} data={mode} ablate={os.environ.get('QAMD_CHAIN2_ABLATE','0')} V1={os.environ.get('QAMD_CHAIN2_V1','')} {t*1e3:.3f} ms  {2*c2.mults/t/1e12:.1f} TF  {4*(c2.a_size+c2.c_size)/t/1e9:.0f} GB/s")
 # single-launch timing (one event pair per launch) and host-side cost of a launch
 import time
 ts = []
