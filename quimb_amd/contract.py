@@ -23,7 +23,7 @@ import numpy as np
 from .array import Array, asarray
 from .executor import TreeExecutor
 from .pathfind import find_path, find_slices
-from .tree import ContractionTree
+from .tree import ContractionTree  # noqa: F401  (re-exported: quimb_amd.contract.ContractionTree)
 
 
 #: a tree goes to the one-launch walker when it has at least this many steps and no intermediate above this size

@@ -18,7 +18,6 @@ This is the MI355X replacement for the per-step python loop inside
 
 import os
 
-import numpy as np
 
 from .array import Array, asarray, _coerce_dtype
 from .ops import _einsum_single, run_pair_step

@@ -15,7 +15,7 @@ written the way quimb's are.  Everything else quimb's TensorNetwork does
 
 import itertools
 
-from .array import Array, asarray
+from .array import asarray
 from .contract import Tensor, tensor_contract
 
 

@@ -16,7 +16,6 @@ import numpy as np
 
 from .array import Array, asarray, _coerce_dtype, _REAL_OF
 from .pairwise import (
-    BinarySpec,
     GettSpec,
     PermuteSpec,
     ReduceSpec,

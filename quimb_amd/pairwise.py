@@ -15,7 +15,7 @@ Plans are pure data and cached, mirroring the reference's ``lru_cache`` on
 """
 
 import functools
-from dataclasses import dataclass, field
+from dataclasses import dataclass
 
 MAX_GROUPS = 8
 

@@ -6,7 +6,6 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import quimb_amd as qa
 from quimb_amd.pairwise import plan_chain2
-from quimb_amd.ops import _apply_pre
 dev = qa.default_device()
 D, nm = 6, 8
 variant = os.environ.get("QAMD_C2_VARIANT", "interior")   # interior | start (k1 = u only) | end (n2 = one index)

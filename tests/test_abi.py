@@ -5,7 +5,6 @@ import ctypes as C
 import os
 import re
 
-import pytest
 
 from quimb_amd import _lib
 from quimb_amd.device import fill_plan_struct
