@@ -308,7 +308,9 @@ class TreeExecutor:
             acc_exp = dev.new_exponent_neg_inf()
             torch.cuda.synchronize(dev.tdev)
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            # thread-local capture: other threads of the process (RCCL's watchdog polling its events in a
+            # multi-GPU job) must not invalidate the capture
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
                 g_exp.zero_()
                 out = self._run_core(static, g_exp, None)
                 dev.axpby_exp(acc._buf, out._buf, acc.size, acc_exp, g_exp, acc.dtype)
@@ -434,7 +436,7 @@ class GraphedContraction:
         torch.cuda.synchronize(dev.tdev)
         self._graph = torch.cuda.CUDAGraph()
         self._exponent = dev.new_exponent() if strip_exponent else None
-        with torch.cuda.graph(self._graph):
+        with torch.cuda.graph(self._graph, capture_error_mode="thread_local"):
             if strip_exponent:
                 self._exponent.zero_()
             self.output = executor._run_core(self.inputs, self._exponent, None)
