@@ -118,8 +118,8 @@ def contract_boundary_2d(arrays, Lx, Ly, max_bond=None, cutoff=1e-10, canonize=T
     or ``(mantissa, exponent)`` with ``mantissa * 10**exponent`` the value when ``strip_exponent``."""
     if len(arrays) != Lx * Ly:
         raise ValueError(f"expected {Lx * Ly} site arrays, got {len(arrays)}")
-    if Lx < 2 or Ly < 1:
-        raise ValueError("need at least two rows")
+    if Lx < 1 or Ly < 1 or Lx * Ly < 2:
+        raise ValueError("need at least two sites")
     sequence = tuple(sequence) if sequence is not None else ("xmin", "xmax")
     if method not in ("svd", "eig"):
         raise ValueError("method must be 'svd' or 'eig'")

@@ -903,6 +903,11 @@ def check_boundary(dtype="float64"):
     assert m > 0 and e == pytest.approx(want, abs=(3.9e-9 if f64 else 5e-4) / math.log(10) * 1.01 + 1e-13), (m, e, want)
     m1, e1 = fn(arrays, 16, 16, max_bond=8, strip_exponent=True, sequence=("xmin",))
     assert m1 > 0 and e1 == pytest.approx(want, abs=(2.2e-7 if f64 else 5e-4) / math.log(10) * 1.01), (m1, e1, want)
+    # degenerate shapes: two lines only (no absorption), single rows / columns, a 2x2 plaquette
+    for (lx, ly, d) in ((2, 5, 3), (5, 2, 3), (2, 2, 2), (3, 1, 2), (1, 4, 2), (2, 1, 3)):
+        small, sin = orc.tn2d_rand(lx, ly, d, seed=3, dtype="float64", normalize=False)
+        ref = float(orc.oracle_array_contract(small, sin, ()))
+        assert fn(small, lx, ly, max_bond=4) == pytest.approx(ref, rel=1e-11 if f64 else 1e-4)
     with pytest.raises(ValueError):
         fn(arrays[:-1], 16, 16)
     with pytest.raises(ValueError):
