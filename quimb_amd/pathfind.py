@@ -10,10 +10,13 @@ part of this build, so the executor ships its own finders:
 * ``sweep_path_2d``    -- row-by-row, site-by-site boundary sweep of an Lx x Ly grid
 * ``find_slices``      -- greedy choice of sliced indices (what cotengra's
                           SliceFinder does) so that the slices can be sharded
+* ``set_tree_cache``   -- on-disk cache of found trees keyed by ``geometry_hash``
 """
 
 import heapq
+import json
 import math
+import os
 import random
 
 from .pairwise import prod
@@ -142,6 +145,40 @@ def sweep_path_2d(Lx, Ly):
     return ssa_to_linear(sweep_ssa_2d(Lx, Ly), Lx * Ly)
 
 
+def geometry_hash(inputs, output, size_dict, extra=""):
+    """Hash of a network's geometry that does not depend on the index NAMES: indices are renumbered by first
+    appearance, exactly what ``TensorNetwork.geometry_hash`` keys its path caches on
+    (quimb/tensor/tensor_core.py:5219-5293).  Two networks with the same hash accept the same ssa path."""
+    import hashlib
+
+    number = {}
+    canon = [[number.setdefault(ix, len(number)) for ix in t] for t in inputs]
+    out = [number[ix] for ix in output]
+    sizes = [int(size_dict[ix]) for ix in number]          # insertion order == numbering order
+    blob = repr((canon, out, sizes, extra)).encode()
+    return hashlib.sha1(blob).hexdigest()
+
+
+_TREE_CACHE_DIR = [None]
+
+
+def set_tree_cache(directory):
+    """Persist the trees found by the string-named strategies ("greedy", "random-greedy", "auto", "auto-hq")
+    under ``directory``, keyed by ``geometry_hash`` + strategy -- the role cotengra's
+    ``ReusableHyperOptimizer(directory=...)`` plays for quimb.  ``None`` switches it
+    off; the environment variable ``QAMD_TREE_CACHE`` sets the initial directory."""
+    _TREE_CACHE_DIR[0] = os.fspath(directory) if directory else None
+
+
+def _cache_file(inputs, output, size_dict, optimize):
+    d = _TREE_CACHE_DIR[0]
+    if d is None:
+        d = os.environ.get("QAMD_TREE_CACHE") or None
+    if not d:
+        return None
+    return os.path.join(d, f"tree-{geometry_hash(inputs, output, size_dict, optimize)}.json")
+
+
 def find_path(inputs, output, size_dict, optimize="greedy"):
     """Resolve quimb's ``optimize=`` argument to a ``ContractionTree``."""
     if isinstance(optimize, ContractionTree):
@@ -149,12 +186,28 @@ def find_path(inputs, output, size_dict, optimize="greedy"):
     if hasattr(optimize, "get_path") and hasattr(optimize, "size_dict"):
         return ContractionTree.from_any(optimize, inputs, output, size_dict)
     if isinstance(optimize, str):
+        if optimize not in ("greedy", "auto", "auto-hq", "random-greedy"):
+            raise ValueError(f"unknown contraction strategy {optimize!r}")
+        path_file = _cache_file(inputs, output, size_dict, optimize)
+        if path_file and os.path.exists(path_file):
+            try:
+                with open(path_file) as f:
+                    ssa = [tuple(c) for c in json.load(f)["ssa_path"]]
+                return ContractionTree(inputs, output, size_dict, ssa_path=ssa)
+            except (OSError, ValueError, KeyError, IndexError):
+                pass                                        # unreadable / stale entry: search again
         if optimize in ("greedy", "auto"):
-            ssa = greedy_ssa(inputs, output, size_dict)
-            return ContractionTree(inputs, output, size_dict, ssa_path=ssa)
-        if optimize in ("auto-hq", "random-greedy"):
-            return random_greedy(inputs, output, size_dict, repeats=64 if optimize == "auto-hq" else 32)
-        raise ValueError(f"unknown contraction strategy {optimize!r}")
+            tree = ContractionTree(inputs, output, size_dict, ssa_path=greedy_ssa(inputs, output, size_dict))
+        else:
+            tree = random_greedy(inputs, output, size_dict, repeats=64 if optimize == "auto-hq" else 32)
+        if path_file:
+            os.makedirs(os.path.dirname(path_file), exist_ok=True)
+            tmp = f"{path_file}.{os.getpid()}.tmp"
+            with open(tmp, "w") as f:
+                json.dump({"ssa_path": [list(c) for c in tree.ssa_path], "cost": tree.contraction_cost(),
+                           "strategy": optimize}, f)
+            os.replace(tmp, path_file)                      # atomic: concurrent ranks may race on the same key
+        return tree
     if callable(optimize):
         path = optimize(inputs, output, size_dict)
         return ContractionTree(inputs, output, size_dict, path=path)

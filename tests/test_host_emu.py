@@ -202,3 +202,43 @@ def test_regrouped_tree_is_cheaper_and_equal():
         for tr in (st, rg):
             tot[id(tr)] += float(orc.oracle_array_contract(xs, ins, (), path=tr.get_path()))
     assert abs(tot[id(st)] - tot[id(rg)]) <= 1e-10 * abs(tot[id(st)])
+
+
+def test_tree_cache_on_disk(tmp_path):
+    """Trees found by the named strategies persist under ``set_tree_cache(dir)`` keyed by a geometry hash that
+    ignores index names (the analogue of quimb's ``geometry_hash`` / cotengra's reusable optimizers)."""
+    import os
+
+    import quimb_amd as qa
+    from quimb_amd import pathfind
+
+    inputs = [("a", "b"), ("b", "c", "d"), ("d", "e"), ("c", "e", "f"), ("f", "a")]
+    size = dict(a=3, b=4, c=2, d=5, e=3, f=2)
+    renamed = [tuple(ix + "_x" for ix in t) for t in inputs]
+    size_r = {k + "_x": v for k, v in size.items()}
+    assert qa.geometry_hash(inputs, (), size) == qa.geometry_hash(renamed, (), size_r)
+    assert qa.geometry_hash(inputs, (), size) != qa.geometry_hash(inputs, (), dict(size, a=4))
+    assert qa.geometry_hash(inputs, (), size) != qa.geometry_hash(inputs[::-1], (), size)
+    qa.set_tree_cache(tmp_path)
+    try:
+        t1 = qa.find_path(inputs, (), size, "random-greedy")
+        files = os.listdir(tmp_path)
+        assert len(files) == 1 and files[0].startswith("tree-")
+        calls = []
+        real = pathfind.random_greedy
+        pathfind.random_greedy = lambda *a, **k: calls.append(1) or real(*a, **k)
+        try:
+            t2 = qa.find_path(renamed, (), size_r, "random-greedy")       # same geometry: no search
+        finally:
+            pathfind.random_greedy = real
+        assert not calls and t2.ssa_path == t1.ssa_path and t2.inputs == tuple(renamed)
+        qa.find_path(inputs, (), size, "greedy")                          # another strategy: its own entry
+        assert len(os.listdir(tmp_path)) == 2
+        # a corrupt entry is ignored and rewritten
+        with open(os.path.join(tmp_path, files[0]), "w") as f:
+            f.write("{not json")
+        t3 = qa.find_path(inputs, (), size, "random-greedy")
+        assert t3.contraction_cost() == t1.contraction_cost()
+    finally:
+        qa.set_tree_cache(None)
+    assert qa.find_path(inputs, (), size, "greedy").contraction_cost() > 0
