@@ -25,6 +25,7 @@ import numpy as np
 from . import linalg, ops
 from .array import asarray
 from .contract import array_contract
+from .split import svals_to_keep
 
 
 def _pad4(x, i, j, Lx, Ly):
@@ -33,19 +34,6 @@ def _pad4(x, i, j, Lx, Ly):
     it = iter(x.shape)
     shape = tuple(next(it) if h else 1 for h in have)
     return x.reshape(shape)
-
-
-def _n_keep(s, max_bond, cutoff):
-    """Number of singular values to keep: relative cutoff ``s_i > cutoff * s_0`` -- ``tensor_split``'s default
-    ``cutoff_mode="rel"`` (quimb/tensor/tensor_core.py:400, quimb/tensor/decomp.py:759-760) -- then the
-    ``max_bond`` cap (decomp.py:990-1001); never fewer than one."""
-    s = np.abs(np.asarray(s, dtype=np.float64))
-    n = len(s)
-    if cutoff > 0.0 and n:
-        n = max(int(np.count_nonzero(s > cutoff * s[0])), 1)
-    if max_bond is not None and max_bond > 0:
-        n = min(n, int(max_bond))
-    return n
 
 
 class _Line:
@@ -88,7 +76,8 @@ class _Line:
             l, x, r = t[j].shape
             u, s, vh = svd(t[j].reshape((l, x * r)))
             sh = s.to_numpy()
-            k = _n_keep(sh, max_bond, cutoff)
+            # tensor_split's default relative cutoff (tensor_core.py:400), then the max_bond cap
+            k = svals_to_keep(sh, cutoff, "rel", max_bond)
             t[j] = vh[:k, :].reshape((k, x, r))
             us = ops.multiply(u[:, :k], asarray(sh[:k].astype(u.dtype))[None, :])
             t[j - 1] = ops.tensordot(t[j - 1], us, axes=([2], [0]))

@@ -68,18 +68,20 @@ __global__ __launch_bounds__(256) void permute_kernel(T* __restrict__ dst, const
       idx = q;
     }
   }
+  // out-of-tile marker: NOT -1 -- source offsets are legitimately negative for reversed (negative-stride) views
+  constexpr int64_t kNone = INT64_MIN;
   for (int i = tid; i < p.TX + p.TY; i += 256) {
     if (i < p.TX) {
       uint32_t x = tx * p.TX + i;
       bool ok = x < p.X;
-      xs[i] = ok ? decomp1(x, p.nx, p.dim_x, p.ss_x) : -1;
-      xd[i] = ok ? decomp1(x, p.nx, p.dim_x, p.sd_x) : -1;
+      xs[i] = ok ? decomp1(x, p.nx, p.dim_x, p.ss_x) : kNone;
+      xd[i] = ok ? decomp1(x, p.nx, p.dim_x, p.sd_x) : kNone;
     } else {
       int j = i - p.TX;
       uint32_t y = ty * p.TY + j;
       bool ok = y < p.Y;
-      ys[j] = ok ? decomp1(y, p.ny, p.dim_y, p.ss_y) : -1;
-      yd[j] = ok ? decomp1(y, p.ny, p.dim_y, p.sd_y) : -1;
+      ys[j] = ok ? decomp1(y, p.ny, p.dim_y, p.ss_y) : kNone;
+      yd[j] = ok ? decomp1(y, p.ny, p.dim_y, p.sd_y) : kNone;
     }
   }
   __syncthreads();
@@ -89,20 +91,20 @@ __global__ __launch_bounds__(256) void permute_kernel(T* __restrict__ dst, const
     for (int e = tid; e < total; e += 256) {
       int x = e % p.TX, y = e / p.TX;
       int64_t a = xs[x], b = ys[y];
-      if (a >= 0 && b >= 0) dst[zd + xd[x] + yd[y]] = src[zs + a + b];
+      if (a != kNone && b != kNone) dst[zd + xd[x] + yd[y]] = src[zs + a + b];
     }
     return;
   }
   for (int e = tid; e < total; e += 256) {
     int x = e % p.TX, y = e / p.TX;
     int64_t a = xs[x], b = ys[y];
-    if (a >= 0 && b >= 0) tile[y * pitch + x] = src[zs + a + b];
+    if (a != kNone && b != kNone) tile[y * pitch + x] = src[zs + a + b];
   }
   __syncthreads();
   for (int e = tid; e < total; e += 256) {
     int y = e % p.TY, x = e / p.TY;
     int64_t a = xd[x], b = yd[y];
-    if (a >= 0 && b >= 0) dst[zd + a + b] = tile[y * pitch + x];
+    if (a != kNone && b != kNone) dst[zd + a + b] = tile[y * pitch + x];
   }
 }
 

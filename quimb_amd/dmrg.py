@@ -25,6 +25,7 @@ from .array import Array, asarray
 from .contract import array_contract
 from .eigsolve import eigh_lanczos
 from .linop import TNLinearOperator
+from .split import svals_to_keep
 
 
 def mpo_ham_heis(L, j=1.0, bz=0.0, dtype="float64"):
@@ -56,21 +57,6 @@ def mpo_ham_heis(L, j=1.0, bz=0.0, dtype="float64"):
     W[4, 4] = eye
     out = [W[4].copy()] + [W.copy() for _ in range(L - 2)] + [W[:, 0].copy()]
     return [a.astype(dtype) for a in out]
-
-
-def _sum2_keep(s, max_bond, cutoff):
-    """``cutoff_mode="sum2"``: drop the largest tail whose squared weight stays <= cutoff (absolute), keep at
-    least one, then cap at ``max_bond`` (quimb/tensor/decomp.py:912-936, :990-1001)."""
-    s2 = np.asarray(s, dtype=np.float64) ** 2
-    n = len(s2)
-    if cutoff > 0.0:
-        acc = 0.0
-        while n > 1 and acc + s2[n - 1] <= cutoff:
-            acc += s2[n - 1]
-            n -= 1
-    if max_bond is not None and max_bond > 0:
-        n = min(n, int(max_bond))
-    return n
 
 
 class DMRG2:
@@ -204,7 +190,7 @@ class DMRG2:
         m = gs.reshape((dims[0] * dims[1], dims[2] * dims[3]))
         u, s, vh = (linalg.svd if self.split == "svd" else linalg.svd_via_eig)(m)
         sh = s.to_numpy()
-        k = _sum2_keep(sh, max_bond, cutoff)
+        k = svals_to_keep(sh, cutoff, "sum2", max_bond)          # bond_compress_cutoff_mode, dmrg.py:85
         sk = asarray(sh[:k].astype(u.dtype))
         if direction == "right":       # A[i] left-canonical, s.V^H moves on
             A[i] = u[:, :k].reshape((dims[0], dims[1], k))

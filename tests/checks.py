@@ -120,6 +120,14 @@ def check_layout_ops(dtype, seed=2):
     np.testing.assert_array_equal(X[:, 2].to_numpy(), x[:, 2])
     np.testing.assert_array_equal(X[..., 1].to_numpy(), x[..., 1])
     np.testing.assert_array_equal(X[1:3, :, ::2, -1].to_numpy(), x[1:3, :, ::2, -1])
+    # reversed views: negative source strides (and negative offsets inside the copy kernel's tiles)
+    np.testing.assert_array_equal(X[::-1].to_numpy(), x[::-1])
+    np.testing.assert_array_equal(X[..., ::-1].to_numpy(), x[..., ::-1])
+    np.testing.assert_array_equal(X[:, ::-1, 1, ::-2].to_numpy(), x[:, ::-1, 1, ::-2])
+    np.testing.assert_array_equal(X[::-1, :, ::-1][:, :2].to_numpy(), x[::-1, :, ::-1][:, :2])
+    m2 = rand(np.random.default_rng(3), (3, 4), dtype)
+    np.testing.assert_array_equal(qa.asarray(m2)[:, ::-1].to_numpy(), m2[:, ::-1])
+    np.testing.assert_array_equal(qa.asarray(m2)[::-1, 1:3].to_numpy(), m2[::-1, 1:3])
     np.testing.assert_array_equal(qa.take(X, 3, axis=2).to_numpy(), np.take(x, 3, axis=2))
     np.testing.assert_array_equal(qa.take(X, [0, 2], axis=1).to_numpy(), np.take(x, [0, 2], axis=1))
     np.testing.assert_array_equal(X.reshape(12, -1).to_numpy(), x.reshape(12, -1))
@@ -996,3 +1004,63 @@ def check_dmrg(dtype="float64"):
         dmc.solve(max_sweeps=3)
         assert dmc.energy == pytest.approx(w[0], rel=1e-4)
         assert {np.dtype(t.dtype).kind for t in dmc.state} == {"c"}
+
+
+# ---------------------------------------------------------------------------------------------------------
+# truncated splits (tensor_split / array_split policy; golden values from the real quimb)
+# ---------------------------------------------------------------------------------------------------------
+def check_split(dtype="float64"):
+    import json
+
+    from quimb_amd.split import array_split, svals_to_keep, tensor_split
+
+    g = np.load(_os.path.join(GOLDEN, "split.npz"))
+    f64 = np.dtype(dtype) == np.float64
+    tol = 1e-10 if f64 else 1e-4      # rocSOLVER's fp32 gesvd: singular values good to ~1e-5..1e-4 of the largest
+    x = g["x"]
+    T = qa.Tensor(qa.asarray(x.reshape(4, 6, 5, 6).astype(dtype)), ["a", "b", "c", "d"], tags=("T",))
+    smax = np.linalg.svd(x, compute_uv=False)[0]
+    vals = tensor_split(T, ["a", "b"], get="values", method="svd").to_numpy()
+    assert np.max(np.abs(vals - g["values"])) <= tol * smax
+    for ci, kw in enumerate(json.loads(str(g["cases"]))):
+        if not f64 and (kw.get("method") == "eig" or 0.0 < kw.get("cutoff", 1e-10) < 1e-6):
+            continue        # fp32 cannot resolve this spectrum's tail (Gram route: squared condition number;
+                            # cutoffs below its rounding level keep the noise of the 12 exactly-zero values)
+        parts = tensor_split(T, ["a", "b"], get="arrays", **kw)
+        if kw.get("absorb", "both") is None:
+            l, s, r = (p.to_numpy() for p in parts)
+            prod_ = np.einsum("abk,k,kcd->abcd", l, s, r)
+            assert np.max(np.abs(s - g[f"s{ci}"])) <= tol * smax, kw
+        else:
+            l, r = (p.to_numpy() for p in parts)
+            prod_ = np.einsum("abk,kcd->abcd", l, r)
+        assert l.shape[-1] == int(g[f"k{ci}"]) == r.shape[0], (kw, l.shape)
+        assert l.shape[:2] == (4, 6) and r.shape[1:] == (5, 6)
+        assert np.max(np.abs(prod_ - g[f"p{ci}"])) <= 20 * tol * smax, kw
+        # isometry of the side that keeps no singular values
+        ab = kw.get("absorb", "both")
+        if ab == "right" or kw.get("method") == "qr":
+            lm = l.reshape(24, -1)
+            assert np.max(np.abs(lm.conj().T @ lm - np.eye(lm.shape[1]))) <= 100 * tol
+        if ab == "left":
+            rm = r.reshape(r.shape[0], -1)
+            assert np.max(np.abs(rm @ rm.conj().T - np.eye(rm.shape[0]))) <= 100 * tol
+    # Tensor results: new bond last on the left factor, first on the right one; tags carried over
+    tl, tr = tensor_split(T, ["a", "b"], cutoff=1e-3, bond_ind="k")
+    assert tl.inds == ("a", "b", "k") and tr.inds == ("k", "c", "d") and tl.tags == ("T",)
+    tl, ts, tr = tensor_split(T, ["c", "a"], absorb=None, cutoff=1e-3, bond_ind="k")
+    assert tl.inds == ("c", "a", "k") and ts.inds == ("k",) and tr.inds == ("k", "b", "d")
+    back = np.einsum("cak,k,kbd->abcd", tl.data.to_numpy(), ts.data.to_numpy(), tr.data.to_numpy())
+    assert np.max(np.abs(back - x.reshape(4, 6, 5, 6))) <= 2e-3 * smax
+    # the counting rule on its own (decomp.py:901-937)
+    s = np.array([1.0, 0.5, 0.1, 0.01, 0.001])
+    assert svals_to_keep(s, 0.05, "abs") == 3 and svals_to_keep(s, 0.2, "rel") == 2
+    assert svals_to_keep(s, 1.2e-4, "sum2") == 3 and svals_to_keep(s, 1e-4 / (s**2).sum(), "rsum2") == 4
+    assert svals_to_keep(s, 0.012, "sum1") == 3 and svals_to_keep(s, 10.0, "abs") == 1
+    assert svals_to_keep(s, 0.0, "rel", max_bond=2) == 2 and svals_to_keep(s, 0.0, "rel") == 5
+    with pytest.raises(ValueError):
+        array_split(qa.asarray(x.astype(dtype)), method="qr", absorb=None)
+    with pytest.raises(ValueError):
+        array_split(qa.asarray(x.astype(dtype)), absorb="sideways")
+    with pytest.raises(ValueError):
+        tensor_split(T, ["a", "b"], right_inds=["c"])

@@ -180,6 +180,44 @@ def main():
     out["zz2_energy"] = dm.energy
     np.savez_compressed(os.path.join(HERE, "dmrg.npz"), **out)
     print("wrote dmrg", out["zz2_energy"])
+    # 11. tensor_split / array_split policy (tensor_core.py:390, decomp.py:35): kept rank, singular values and
+    #     the (gauge-independent) product of the factors for a grid of cutoff modes / absorbs / methods
+    srng = np.random.default_rng(77)
+    spec = np.exp(-0.9 * np.arange(12))
+    ul, _ = np.linalg.qr(srng.normal(size=(24, 12)))
+    vr, _ = np.linalg.qr(srng.normal(size=(30, 12)))
+    x = (ul * spec) @ vr.T
+    t = qtn.Tensor(x.reshape(4, 6, 5, 6), inds=["a", "b", "c", "d"])
+    out = {"x": x}
+    cases = []
+    for ci, kw in enumerate([
+        dict(cutoff=1e-10), dict(cutoff=1e-3), dict(cutoff=1e-3, cutoff_mode="abs"),
+        dict(cutoff=1e-3, cutoff_mode="sum2"), dict(cutoff=1e-3, cutoff_mode="rsum2"),
+        dict(cutoff=1e-2, cutoff_mode="sum1"), dict(cutoff=1e-2, cutoff_mode="rsum1"),
+        dict(cutoff=0.0, max_bond=5), dict(cutoff=1e-3, max_bond=3), dict(cutoff=1e-3, cutoff_mode="rsum2", renorm=True),
+        dict(cutoff=0.0, max_bond=4, renorm=2), dict(cutoff=1e-4, method="eig"), dict(cutoff=0.0, method="qr", absorb="right"),
+        dict(cutoff=0.0, method="lq", absorb="left"), dict(cutoff=1e-3, absorb="left"), dict(cutoff=1e-3, absorb="right"),
+        dict(cutoff=1e-3, absorb=None),
+    ]):
+        import warnings as _w
+        with _w.catch_warnings():
+            _w.simplefilter("ignore")
+            parts = t.split(["a", "b"], get="arrays", **kw)
+        if len(parts) == 3:
+            l, sv, r = parts
+            prod_ = np.einsum("abk,k,kcd->abcd", l, sv, r)
+            out[f"s{ci}"] = sv
+        else:
+            l, r = parts
+            prod_ = np.einsum("abk,kcd->abcd", l, r)
+        out[f"p{ci}"] = prod_
+        out[f"k{ci}"] = l.shape[-1]
+        cases.append(kw)
+        print("split", kw, "rank", out[f"k{ci}"])
+    out["values"] = np.asarray(t.split(["a", "b"], get="values", method="svd"))   # the whole spectrum, untruncated
+    out["cases"] = json.dumps(cases)
+    np.savez_compressed(os.path.join(HERE, "split.npz"), **out)
+    print("wrote split")
     print("quimb version:", qu.__version__)
 
 

@@ -81,3 +81,15 @@ def test_dmrg2_host_logic_matches_real_quimb(emu):
 @pytest.mark.parametrize("dtype", ["float64", "float32"])
 def test_dmrg2_hip_matches_real_quimb(hip, dtype):
     checks.check_dmrg(dtype)
+
+
+def test_split_policy_matches_real_quimb(emu):
+    """Kept rank, singular values and factor products of ``tensor_split`` for every cutoff mode / absorb / method
+    of the golden grid (tests/golden/split.npz, made by the real quimb)."""
+    checks.check_split("float64")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+def test_split_hip_matches_real_quimb(hip, dtype):
+    checks.check_split(dtype)
