@@ -31,6 +31,7 @@ from .microtree import MicroTree
 from .boundary import contract_boundary_2d
 from .dmrg import DMRG2, mpo_ham_heis
 from .split import array_split, tensor_split
+from .circuit import Circuit, CircuitMPS
 from .network import TensorNetwork
 from .pathfind import find_path, find_slices, geometry_hash, greedy_path, random_greedy, set_tree_cache, sweep_path_2d
 from .tree import ContractionTree

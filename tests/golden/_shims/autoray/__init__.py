@@ -10,7 +10,7 @@ import numpy as np
 from . import lazy  # noqa: F401
 
 _REGISTRY = {}
-_BACKEND_ALIASES = {"builtins": "numpy"}
+_BACKEND_ALIASES = {"builtins": "numpy", "quimb": "numpy"}      # qarray is an ndarray subclass
 
 
 def infer_backend(x):
@@ -37,7 +37,10 @@ def _np_fn(name):
     return obj
 
 
-_CUSTOM = {}
+# autoray names numpy does not have (autoray translates them for the numpy backend)
+_CUSTOM = {
+    "complex": lambda re, im: np.asarray(re) + 1j * np.asarray(im),
+}
 
 
 def get_lib_fn(backend, name):

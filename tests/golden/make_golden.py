@@ -218,6 +218,55 @@ def main():
     out["cases"] = json.dumps(cases)
     np.savez_compressed(os.path.join(HERE, "split.npz"), **out)
     print("wrote split")
+    # 12. circuits (circuit/exact.py:417 Circuit.amplitude / to_dense; circuit/mps.py CircuitMPS): gate lists as
+    #     plain data, dense states and amplitudes of the real quimb
+    def plain(gates):
+        rows = []
+        for g in gates:
+            if hasattr(g, "label"):
+                rows.append([g.label, [float(p) for p in g.params], [int(q) for q in g.qubits]])
+            else:
+                name, *rest = g
+                npar = len(rest) - (2 if name.upper() in ("CZ", "CNOT", "CX", "CY", "ISWAP", "SWAP", "FSIM", "RZZ") else 1)
+                rows.append([name.upper(), [float(p) for p in rest[:npar]], [int(q) for q in rest[npar:]]])
+        return rows
+
+    crng = np.random.default_rng(3)
+    N = 5
+    gates = []
+    for d in range(3):
+        for q in range(N):
+            gates.append(("U3", *crng.uniform(0, 2 * np.pi, 3), q))
+        for q in range(d % 2, N - 1, 2):
+            gates.append(("CZ", q, q + 1))
+    gates += [("H", 0), ("CNOT", 0, 3), ("RZ", 0.3, 2), ("ISWAP", 1, 4), ("T", 2), ("S", 1), ("RX", 0.7, 4),
+              ("RY", 1.1, 0), ("SWAP", 2, 3), ("X", 1), ("Y", 2), ("Z", 3), ("FSIM", 0.4, 0.9, 0, 1), ("CY", 4, 2),
+              ("RZZ", 0.45, 1, 3)]
+    circ = qtn.Circuit(N)
+    circ.apply_gates(gates)
+    out = {"exact_gates": json.dumps(plain(gates)), "exact_N": N,
+           "exact_dense": np.asarray(circ.to_dense()).reshape(-1)}
+    bits = ["01101", "00000", "11111", "10010"]
+    out["exact_bits"] = json.dumps(bits)
+    out["exact_amps"] = np.array([circ.amplitude(b, simplify_sequence="") for b in bits])
+    from quimb.tensor import circuit_gen
+    for name, n, depth, chi in (("mps_exact", 8, 4, None), ("mps_chi4", 8, 6, 4), ("mps_chi8_nonlocal", 7, 3, 8)):
+        gl = list(circuit_gen.gates_1D_brickwork(n, depth, seed=11))
+        if name.endswith("nonlocal"):
+            gl += [("CZ", 0, 4), ("CNOT", 5, 1), ("ISWAP", 6, 2), ("H", 3)]
+        cm = qtn.CircuitMPS(n, max_bond=chi)
+        cm.apply_gates(gl)
+        out[f"{name}_gates"] = json.dumps(plain(cm.gates))
+        out[f"{name}_N"] = n
+        out[f"{name}_chi"] = -1 if chi is None else chi
+        out[f"{name}_dense"] = np.asarray(cm.psi.to_dense()).reshape(-1)
+        mbits = ["01" * (n // 2) + "0" * (n % 2), "0" * n, "1" * n]
+        out[f"{name}_bits"] = json.dumps(mbits)
+        out[f"{name}_amps"] = np.array([cm.amplitude(b) for b in mbits])
+        out[f"{name}_max_bond"] = cm.psi.max_bond()
+        print(name, out[f"{name}_amps"], out[f"{name}_max_bond"], np.linalg.norm(out[f"{name}_dense"]))
+    np.savez_compressed(os.path.join(HERE, "circuit.npz"), **out)
+    print("wrote circuit", out["exact_amps"])
     print("quimb version:", qu.__version__)
 
 

@@ -93,3 +93,15 @@ def test_split_policy_matches_real_quimb(emu):
 @pytest.mark.parametrize("dtype", ["float64", "float32"])
 def test_split_hip_matches_real_quimb(hip, dtype):
     checks.check_split(dtype)
+
+
+def test_circuits_host_logic_match_real_quimb(emu):
+    """``Circuit`` (dense state, amplitudes, batched amplitudes) and ``CircuitMPS`` (exact, truncated to chi = 4,
+    non-local gates through swaps) reproduce the real quimb's states on the same gate lists."""
+    checks.check_circuits("complex128")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", ["complex128", "complex64"])
+def test_circuits_hip_match_real_quimb(hip, dtype):
+    checks.check_circuits(dtype)
