@@ -6,7 +6,9 @@ written the way quimb's are.  Everything else quimb's TensorNetwork does
 
 * ``contract(tags=all, ...)``          tensor_core.py:9581-9716 (all tags and not inplace ->
                                         ``tensor_contract(*tensors, exponent=self.exponent)``)
-* ``contract_tags(tags, which=)``      :9426-9577 (partition, contract, re-insert)
+* ``contract_tags(tags, which=)``      :9426-9577 (partition, contract, re-insert; ``strip_exponent`` /
+                                        ``equalize_norms`` bookkeeping in ``tn.exponent``)
+* ``equalize_norms`` / ``strip_exponent``  :10801-10880
 * ``contract_cumulative(tags_seq)``    :9720-9800 (``>>``)
 * ``isel`` / ``cut_iter``              :9215-9244 / :9291-9328
 * ``apply_to_arrays`` / ``to_device``  :5304
@@ -14,9 +16,18 @@ written the way quimb's are.  Everything else quimb's TensorNetwork does
 """
 
 import itertools
+import math
 
+from . import ops
 from .array import asarray
 from .contract import Tensor, tensor_contract
+
+
+def _scalar(t):
+    """0-d Tensor -> python scalar, real if the imaginary part vanishes (``maybe_realify_scalar``)."""
+    from .contract import _realify_scalar
+
+    return _realify_scalar(asarray(t.data).to_numpy().item())
 
 
 def _tags_of(tags):
@@ -130,55 +141,120 @@ class TensorNetwork:
             yield self.isel(dict(zip(inds, vals)))
 
     # ---- contraction ------------------------------------------------------------------
-    def contract_tags(self, tags, which="any", inplace=False, **opts):
-        picked, rest = self._select(tags, which)
+    def contract_tags(self, tags, which="any", output_inds=None, optimize=None, backend=None,
+                      strip_exponent=False, equalize_norms="auto", preserve_tensor=False, inplace=False, **opts):
+        """Contract the tensors matching ``tags`` (``all`` / ``...``: every tensor) and put the result back
+        (tensor_core.py:9426-9577).  ``equalize_norms`` strips the scale inside the contraction and accumulates
+        it in ``tn.exponent`` ("auto": follow ``strip_exponent``); ``strip_exponent`` returns
+        ``(result, exponent)`` when everything was contracted, ``result * 10**exponent`` being the value."""
+        if tags is all or tags is Ellipsis:
+            picked, rest = list(self.tensors), []
+        else:
+            picked, rest = self._select(tags, which)
         if not picked:
             raise ValueError("No tags were found - nothing to contract.")
-        # indices shared with the untouched tensors must survive
-        outside = {ix for t in rest for ix in t.inds}
-        inner = {}
-        for t in picked:
-            for ix in t.inds:
-                inner[ix] = inner.get(ix, 0) + 1
-        out_inds = tuple(ix for ix, c in inner.items() if c == 1 or ix in outside)
-        opts.setdefault("output_inds", out_inds)
-        if not rest:
-            res = tensor_contract(*picked, exponent=self.exponent if self.exponent else None, **opts)
-            if inplace and isinstance(res, Tensor):
-                self.tensors = [res]
-                return self
-            return res
-        res = tensor_contract(*picked, preserve_tensor=True, **opts)
+        if output_inds is None:
+            # indices shared with the untouched tensors must survive
+            outside = {ix for t in rest for ix in t.inds}
+            inner = {}
+            for t in picked:
+                for ix in t.inds:
+                    inner[ix] = inner.get(ix, 0) + 1
+            output_inds = tuple(ix for ix, c in inner.items() if c == 1 or ix in outside)
+        if equalize_norms == "auto":
+            equalize_norms = strip_exponent
+        keep_tensor = preserve_tensor or inplace or bool(rest)
+        t = tensor_contract(*picked, output_inds=output_inds, optimize=optimize, backend=backend,
+                            strip_exponent=bool(equalize_norms), preserve_tensor=keep_tensor, **opts)
+        if equalize_norms:
+            t, exponent = t                       # scale taken out step by step inside the contraction
+        elif strip_exponent:
+            if isinstance(t, Tensor):             # take it out of the finished result
+                nrm = ops.norm_fro(t.data)
+                t = Tensor(t.data / nrm, t.inds, t.tags)
+            else:
+                nrm = abs(t)
+                t = t / nrm
+            exponent = math.log10(nrm)
+        else:
+            exponent = None
+        if not rest and not inplace:
+            total = self.exponent + (exponent or 0.0)
+            if strip_exponent:
+                return t, total
+            if total:
+                t = Tensor(t.data * 10.0**total, t.inds, t.tags) if isinstance(t, Tensor) else t * 10.0**total
+            return t
         tn = self if inplace else TensorNetwork((), self.exponent)
-        tn.tensors = rest + [res]
+        tn.tensors = rest + [t]
+        if exponent is not None:
+            tn.exponent = tn.exponent + exponent
         return tn
 
     def contract(self, tags=all, output_inds=None, optimize=None, backend=None, inplace=False,
-                 strip_exponent=False, **opts):
-        if tags is all or tags is Ellipsis:
-            kw = dict(output_inds=output_inds, optimize=optimize, backend=backend, strip_exponent=strip_exponent)
-            kw.update(opts)
-            if self.exponent:
-                kw["exponent"] = self.exponent
-            res = tensor_contract(*self.tensors, **kw)
-            if inplace:
-                if isinstance(res, Tensor):
-                    self.tensors = [res]
-                return self
-            return res
-        return self.contract_tags(tags, inplace=inplace, optimize=optimize, backend=backend, **opts)
+                 strip_exponent=False, equalize_norms="auto", **opts):
+        return self.contract_tags(tags, output_inds=output_inds, optimize=optimize, backend=backend,
+                                  strip_exponent=strip_exponent, equalize_norms=equalize_norms, inplace=inplace,
+                                  **opts)
 
-    def contract_cumulative(self, tags_seq, inplace=False, **opts):
+    # ---- norms / exponent bookkeeping (tensor_core.py:10801-10841) ------------------------------------
+    @property
+    def arrays(self):
+        return tuple(t.data for t in self.tensors)
+
+    def strip_exponent(self, tensor, value=None):
+        """Scale ``tensor`` so that its norm is ``value`` (default 1) and move the factor, log10, into
+        ``self.exponent``."""
+        value = 1.0 if value is None or value is True else float(value)
+        i = next(k for k, t in enumerate(self.tensors) if t is tensor)
+        factor = ops.norm_fro(asarray(tensor.data)) / value
+        self.tensors[i] = Tensor(asarray(tensor.data) / factor, tensor.inds, tensor.tags)
+        self.exponent = self.exponent + math.log10(factor)
+
+    def equalize_norms(self, value=None, inplace=False):
+        """Make every tensor's norm the same: ``value`` given -> that norm, the factors accumulated in
+        ``exponent``; ``value=None`` -> the geometric mean, exponent untouched (tensor_core.py:10843-10880)."""
         tn = self if inplace else self.copy()
-        acc = ()
-        for tags in tags_seq:
-            acc = acc + _tags_of(tags)
-            res = tn.contract_tags(acc, which="any", inplace=True, **opts)
-            if not isinstance(res, TensorNetwork):
-                return res
-        if len(tn.tensors) == 1 and not inplace:
-            return tn.tensors[0]
+        norms = [ops.norm_fro(asarray(t.data)) for t in tn.tensors]
+        if value is None:
+            target = 10.0 ** (sum(math.log10(n) for n in norms) / len(norms))
+        else:
+            target = float(value)
+            tn.exponent = tn.exponent + sum(math.log10(n / target) for n in norms)
+        tn.tensors = [Tensor(asarray(t.data) * (target / n), t.inds, t.tags) for t, n in zip(tn.tensors, norms)]
         return tn
+
+    def equalize_norms_(self, value=None):
+        return self.equalize_norms(value, inplace=True)
+
+    def contract_cumulative(self, tags_seq, output_inds=None, strip_exponent=False, equalize_norms="auto",
+                            inplace=False, **opts):
+        """Contract ``tags_seq[0]``, then that with ``tags_seq[1]``, ... (tensor_core.py:9720-9800); the scale of
+        every partial result goes into the exponent when ``equalize_norms``."""
+        tn = self if inplace else self.copy()
+        if equalize_norms == "auto":
+            equalize_norms = strip_exponent
+        seq = list(tags_seq)
+        acc = ()
+        for k, tags in enumerate(seq):
+            acc = acc + _tags_of(tags)
+            tn.contract_tags(acc, which="any", inplace=True, equalize_norms=equalize_norms,
+                             output_inds=output_inds if k == len(seq) - 1 else None, **opts)
+        if len(tn.tensors) != 1 or inplace:
+            if strip_exponent and not equalize_norms and len(tn.tensors) == 1:
+                tn.strip_exponent(tn.tensors[0])
+            return tn
+        t = tn.tensors[0]
+        if strip_exponent:
+            if not equalize_norms:
+                tn.strip_exponent(t)
+                t = tn.tensors[0]
+            if not t.inds:
+                t = _scalar(t)
+            return t, tn.exponent
+        if tn.exponent:
+            t = Tensor(asarray(t.data) * 10.0**tn.exponent, t.inds, t.tags)
+        return _scalar(t) if not t.inds else t
 
     def __xor__(self, tags):
         return self.contract(tags)

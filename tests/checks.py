@@ -1108,3 +1108,78 @@ def check_circuits(dtype="complex128"):
         Circuit(3).apply_gate("H", 5)
     with pytest.raises(ValueError):
         c.amplitude("0101")
+
+
+def _rand_reg_network(n, reg, D, rng, dtype="float64"):
+    """A random ``reg``-regular graph network like ``qtn.TN_rand_reg(n, reg, D)`` (tensor_builder.py:1104):
+    one tensor per node, one bond per edge, 'mostly positive' fill so the value is well conditioned."""
+    while True:                                           # configuration model, rejecting loops / multi-edges
+        stubs = [v for v in range(n) for _ in range(reg)]
+        rng.shuffle(stubs)
+        edges = {tuple(sorted(stubs[i:i + 2])) for i in range(0, len(stubs), 2)}
+        if len(edges) == n * reg // 2 and all(a != b for a, b in edges):
+            break
+    inds = {v: [] for v in range(n)}
+    for e in sorted(edges):
+        for v in e:
+            inds[v].append(("e",) + e)
+    return [qa.Tensor(rng.uniform(-0.1, 1.0, size=(D,) * reg).astype(dtype), inds[v], tags=(f"I{v}",)) for v in range(n)]
+
+
+def check_network_exponents(dtype="float64"):
+    """Restated grids of the reference (tests/test_tensor/test_contract.py:8-88): ``strip_exponent`` x
+    ``equalize_norms`` x ``inplace`` for ``contract_tags(all)`` and cumulative contraction, ``equalize_norms_``
+    with and without a value, and ``tn.exponent`` re-inserted by later contractions."""
+    rng = np.random.default_rng(8)
+    rel = 1e-3
+    tn = qa.TensorNetwork(_rand_reg_network(8, 3, 2, rng, dtype))
+    zex = tn.contract()
+    m1, e1 = qa.tensor_contract(*tn.tensors, strip_exponent=True)
+    assert m1 * 10**e1 == pytest.approx(zex, rel=rel)
+    tq = tn.copy()
+    tq.equalize_norms_(value=1.0)
+    assert tq.exponent != 0.0
+    norms = [qa.norm_fro(t.data) for t in tq.tensors]
+    assert max(norms) == pytest.approx(1.0, rel=1e-5) and min(norms) == pytest.approx(1.0, rel=1e-5)
+    assert tq.contract() == pytest.approx(zex, rel=rel)                       # exponent re-inserted
+    m3, e3 = tq.contract(strip_exponent=True)
+    assert m3 * 10**e3 == pytest.approx(zex, rel=rel)
+    tg = tn.equalize_norms()                                                  # geometric mean: value unchanged
+    norms = [qa.norm_fro(t.data) for t in tg.tensors]
+    assert max(norms) == pytest.approx(min(norms), rel=1e-5) and tg.exponent == 0.0
+    assert tg.contract() == pytest.approx(zex, rel=rel)
+    for strip_exponent, equalize_norms, inplace in itertools.product([False, True], [False, 1.0, True], [False, True]):
+        if inplace:
+            tnc = tn.copy()
+            tnc.contract_tags(all, strip_exponent=strip_exponent, equalize_norms=equalize_norms, inplace=True)
+            assert len(tnc.tensors) == 1
+            z = np.asarray(qa.asarray(tnc.arrays[0]).to_numpy()).item() * 10**tnc.exponent
+        else:
+            z = tn.contract_tags(all, strip_exponent=strip_exponent, equalize_norms=equalize_norms)
+            if strip_exponent:
+                z = z[0] * 10 ** z[1]
+        assert z == pytest.approx(zex, rel=rel), (strip_exponent, equalize_norms, inplace)
+    # cumulative contraction of <mps|mps>, with and without an exponent already on the network
+    # (test_contract.py:50-88: insert_exponent x strip_exponent x equalize_norms x inplace)
+    arrs, inputs = orc.mps_rand(7, 3, seed=5, dtype=dtype)
+    ket = [qa.Tensor(a, t, tags=(f"I{i}",)) for i, (a, t) in enumerate(zip(arrs, inputs))]
+    bra = [qa.Tensor(np.conj(t.data), tuple(("B", ix[1]) if ix[0] == "b" else ix for ix in t.inds), tags=t.tags)
+           for t in ket]
+    norm_tn = qa.TensorNetwork(ket + bra)
+    zex = norm_tn.contract()
+    scaled = norm_tn.equalize_norms(2.0)
+    assert scaled.exponent != 0.0
+    sites = [f"I{i}" for i in range(7)]
+    for net, strip_exponent, equalize_norms, inplace in itertools.product(
+            (norm_tn, scaled), [False, True], [False, 1.0, True], [False, True]):
+        if inplace:
+            tnc = net.copy()
+            tnc.contract_cumulative(sites, strip_exponent=strip_exponent, equalize_norms=equalize_norms, inplace=True)
+            assert len(tnc.tensors) == 1
+            z = np.asarray(qa.asarray(tnc.arrays[0]).to_numpy()).item() * 10**tnc.exponent
+        else:
+            z = net.contract_cumulative(sites, strip_exponent=strip_exponent, equalize_norms=equalize_norms)
+            if strip_exponent:
+                z = z[0] * 10 ** z[1]
+        assert z == pytest.approx(zex, rel=rel), (strip_exponent, equalize_norms, inplace)
+    assert (norm_tn >> sites) == pytest.approx(zex, rel=rel)

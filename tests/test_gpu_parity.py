@@ -359,3 +359,9 @@ def test_no_cpu_fallback(hip):
 
     assert isinstance(qd.default_device(), qd.HipDevice)
     assert _lib._LIB is not None and _lib._LIB.qamd_abi_version() == 1
+
+
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+def test_network_exponent_bookkeeping(hip, dtype):
+    """strip_exponent x equalize_norms x inplace grids of the reference (tests/test_tensor/test_contract.py:8-88)."""
+    checks.check_network_exponents(dtype)

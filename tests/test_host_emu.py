@@ -242,3 +242,8 @@ def test_tree_cache_on_disk(tmp_path):
     finally:
         qa.set_tree_cache(None)
     assert qa.find_path(inputs, (), size, "greedy").contraction_cost() > 0
+
+
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+def test_network_exponent_bookkeeping(emu, dtype):
+    checks.check_network_exponents(dtype)
