@@ -10,6 +10,7 @@ written the way quimb's are.  Everything else quimb's TensorNetwork does
                                         ``equalize_norms`` bookkeeping in ``tn.exponent``)
 * ``equalize_norms`` / ``strip_exponent``  :10801-10880
 * ``contract_cumulative(tags_seq)``    :9720-9800 (``>>``)
+* ``contract_structured(site_tags)``   tn1d/core.py:502-557 (blocks of ``structure_bsz`` sites, cumulative)
 * ``isel`` / ``cut_iter``              :9215-9244 / :9291-9328
 * ``apply_to_arrays`` / ``to_device``  :5304
 * ``&``, ``^``, ``>>``                 :9958 and friends
@@ -255,6 +256,16 @@ class TensorNetwork:
         if tn.exponent:
             t = Tensor(asarray(t.data) * 10.0**tn.exponent, t.inds, t.tags)
         return _scalar(t) if not t.inds else t
+
+    def contract_structured(self, site_tags, structure_bsz=5, **opts):
+        """1D structured contraction (``TensorNetwork1D.contract_structured``, quimb/tensor/tn1d/core.py:502-557):
+        the site tags present in the network, in the given order, grouped ``structure_bsz`` at a time and
+        contracted cumulatively."""
+        present = self.tags
+        seq = [t for t in site_tags if t in present]
+        if structure_bsz > 1:
+            seq = [tuple(seq[i:i + structure_bsz]) for i in range(0, len(seq), structure_bsz)]
+        return self.contract_cumulative(seq, **opts)
 
     def __xor__(self, tags):
         return self.contract(tags)

@@ -278,6 +278,11 @@ def plan_pair(a_inds, a_shape, b_inds, b_shape, out_inds, out_fixed=True, death=
     # pre[0] belongs to kernel operand A, pre[1] to kernel operand B
     if max(len(gm), len(gk), len(gb), len(gn)) > MAX_GROUPS:
         # canonicalise: permute A -> [b, m, k], B -> [b, k, n] so every bundle fuses
+        if out_fixed:
+            # the result order is the caller's: run m and batch in THAT order, or the permuted operands would
+            # still be scrambled against C (e.g. a dense vector built site by site, indices reversed)
+            m_order = sorted(mm, key=lambda ix: -sc[ix])
+            b_order = sorted(batch, key=lambda ix: -sc[ix])
         new_a = tuple(b_order + m_order + k_order)
         new_b = tuple(b_order + k_order + n_order)
         if tuple(va.inds) != new_a or not _is_contig_view(va):

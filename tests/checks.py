@@ -386,6 +386,16 @@ def check_mps_dense(dtype="float64", L=10, chi=7):
     want = orc.oracle_array_contract(arrays, inputs, out)
     got = qa.array_contract(arrays, inputs, out)
     assert_close(got, want, dtype)
+    # the reference's own route for 1D networks: blocks of 5 sites, cumulatively (tn1d/core.py:502-557)
+    tn = qa.TensorNetwork([qa.Tensor(a, t, tags=(f"I{i}",)) for i, (a, t) in enumerate(zip(arrays, inputs))])
+    sites = [f"I{i}" for i in range(L)]
+    dense = tn.contract_structured(sites, output_inds=out)
+    assert isinstance(dense, qa.Tensor) and dense.inds == out
+    assert_close(dense.data, want, dtype)
+    part = tn.contract_structured(sites[:7])                       # a partial range leaves a network behind
+    assert isinstance(part, qa.TensorNetwork) and len(part.tensors) == L - 7 + 1
+    for bsz in (1, 3):
+        assert_close(tn.contract_structured(sites, structure_bsz=bsz, output_inds=out).data, want, dtype)
 
 
 def check_stream_kernels(dtype, seed=8):
