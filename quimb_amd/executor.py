@@ -75,7 +75,24 @@ class TreeExecutor:
             sa = tuple(size[ix] for ix in la)
             sb = tuple(size[ix] for ix in lb)
             if last:
-                step = plan_pair(la, sa, lb, sb, tuple(tree.output), True, None)
+                try:
+                    step = plan_pair(la, sa, lb, sb, tuple(tree.output), True, None)
+                except NotImplementedError:
+                    # the caller's output order interleaves more index groups than one launch addresses:
+                    # contract into the kernel's own order, then one permute pass into the requested one
+                    step = plan_pair(la, sa, lb, sb, tuple(tree.output), False, None)
+                    tmp = ("unordered", res)
+                    self.plan.append(("pair", a, b, tmp, step))
+                    g = step.spec
+                    self.info.append(StepInfo(step.kind, step.mults,
+                                              isz * g.B * (g.M * g.K + g.K * g.N + g.M * g.N), (g.B, g.M, g.N, g.K),
+                                              dep[a] or dep[b]))
+                    out = tuple(tree.output)
+                    self.plan.append(("single", tmp, res, step.out_inds, out))
+                    layout[res] = out
+                    dep[res] = dep[tmp] = dep[a] or dep[b]
+                    self.info.append(StepInfo("single", 0, 2 * isz * prod(step.out_shape), (1, 1, 1, 1), dep[res]))
+                    continue
             else:
                 d = tuple(sorted(death.get(res, {}).items(), key=repr))
                 step = plan_pair(la, sa, lb, sb, tuple(keep), False, d)

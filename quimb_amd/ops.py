@@ -102,7 +102,17 @@ def einsum_pair(a, a_inds, b, b_inds, out_inds, out_fixed=True, death=None):
     """``einsum`` of two operands with arbitrary hashable index labels.
     Returns (array, out_inds)."""
     a, b, _ = _common(a, b)
-    step = plan_pair(tuple(a_inds), a.shape, tuple(b_inds), b.shape, tuple(out_inds), out_fixed, death)
+    try:
+        step = plan_pair(tuple(a_inds), a.shape, tuple(b_inds), b.shape, tuple(out_inds), out_fixed, death)
+    except NotImplementedError:
+        if not out_fixed:
+            raise
+        # the requested order interleaves more index groups than one launch can address: contract into the
+        # kernel's own order, then one permute pass
+        step = plan_pair(tuple(a_inds), a.shape, tuple(b_inds), b.shape, tuple(out_inds), False, death)
+        res = run_pair_step(step, a, b)
+        perm = [step.out_inds.index(ix) for ix in out_inds]
+        return transpose(res, perm), tuple(out_inds)
     return run_pair_step(step, a, b), step.out_inds
 
 

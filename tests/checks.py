@@ -78,6 +78,25 @@ def check_pairwise(dtype, seed=0, dims=None):
         got = qa.einsum(f"{ai},{bi}->{oi}", qa.asarray(a), qa.asarray(b))
         assert got.dtype == np.dtype(dtype)
         assert_close(got.to_numpy(), want, dtype)
+    # an output order that interleaves MORE index groups than one launch addresses (9 + 9 two-level indices,
+    # alternating): the contraction runs in the kernel's own order, one permute pass follows -- through einsum,
+    # array_contract (last step of a tree) and a three-tensor tree with a scrambled output
+    hi = np.complex128 if np.dtype(dtype).kind == "c" else np.float64
+    a = rand(rng, (2,) * 10, dtype)
+    b = rand(rng, (2,) * 10, dtype)
+    ai = tuple(f"a{i}" for i in range(9)) + ("k",)
+    bi = ("k",) + tuple(f"b{i}" for i in range(9))
+    out = tuple(x for p in zip(ai[:9], bi[1:]) for x in p)
+    sym = {ix: chr(97 + i) for i, ix in enumerate(dict.fromkeys(ai + bi))}
+    eq = "".join(sym[i] for i in ai) + "," + "".join(sym[i] for i in bi) + "->" + "".join(sym[i] for i in out)
+    want = np.einsum(eq, a.astype(hi), b.astype(hi))
+    assert_close(qa.einsum(eq, qa.asarray(a), qa.asarray(b)).to_numpy(), want, dtype)
+    assert_close(np.asarray(qa.array_contract([a, b], [ai, bi], out)), want, dtype)
+    c = rand(rng, (2, 2), dtype)
+    out3 = tuple(reversed(out[1:])) + ("z",)
+    want3 = np.einsum(eq.split("->")[0] + "," + sym["a0"] + "Z->" + "".join(sym[i] for i in out3[:-1]) + "Z",
+                      a.astype(hi), b.astype(hi), c.astype(hi))
+    assert_close(np.asarray(qa.array_contract([a, b, c], [ai, bi, ("a0", "z")], out3)), want3, dtype)
 
 
 def check_tensordot_matmul(dtype, seed=1):
