@@ -259,6 +259,11 @@ class Array:
             return self._scaled(1.0 / other)
         return NotImplemented
 
+    def __abs__(self):
+        from . import ops
+
+        return ops.abs(self)
+
     def __neg__(self):
         return self._scaled(-1.0)
 

@@ -36,4 +36,47 @@ def register():
         array_ops.norm_fro.register("quimb_amd")(qa.norm_fro)
     except Exception:  # quimb not importable: the autoray part above still stands
         pass
+    try:  # quimb's split drivers (``array_split`` dispatches to them by backend): policy in split.py, LAPACK in rocSOLVER
+        from quimb.tensor import decomp
+
+        decomp.svd_truncated.register("quimb_amd")(svd_truncated)
+        decomp.qr_stabilized.register("quimb_amd")(qr_stabilized)
+        if hasattr(decomp, "svd_via_eig_truncated"):
+            decomp.svd_via_eig_truncated.register("quimb_amd")(svd_via_eig_truncated)
+    except Exception:
+        pass
     return "quimb_amd"
+
+
+# quimb's numeric codes (quimb/tensor/decomp.py:264-298)
+_CUTOFF_MODE_NAMES = {1: "abs", 2: "rel", 3: "sum2", 4: "rsum2", 5: "sum1", 6: "rsum1"}
+_ABSORB_NAMES = {None: None, 2: "s", -12: "lsqrt", -11: "rorthog", -10: "lfactor", -1: "left", 0: "both", 1: "right",
+                 10: "lorthog", 11: "rfactor", 12: "rsqrt"}
+
+
+def _split(method, x, cutoff, cutoff_mode, max_bond, absorb, renorm, info):
+    from .split import array_split
+
+    left, s, right = array_split(
+        x, method, _ABSORB_NAMES.get(absorb, absorb), max_bond if max_bond and max_bond > 0 else None,
+        cutoff if cutoff and cutoff > 0 else 0.0, _CUTOFF_MODE_NAMES.get(cutoff_mode, cutoff_mode), renorm or None)
+    if info is not None and "error" in info:
+        info["error"] = None          # the discarded weight is not tracked on the device path
+    return left, s, right
+
+
+def svd_truncated(x, cutoff=-1.0, cutoff_mode=4, max_bond=-1, absorb=0, renorm=0, info=None, **_):
+    """Drop-in for ``quimb.tensor.decomp.svd_truncated`` (decomp.py:831) on device arrays."""
+    return _split("svd", x, cutoff, cutoff_mode, max_bond, absorb, renorm, info)
+
+
+def svd_via_eig_truncated(x, cutoff=-1.0, cutoff_mode=4, max_bond=-1, absorb=0, renorm=0, info=None, **_):
+    return _split("svd:eig", x, cutoff, cutoff_mode, max_bond, absorb, renorm, info)
+
+
+def qr_stabilized(x, absorb=1, stabilized=True, **_):
+    """Drop-in for ``quimb.tensor.decomp.qr_stabilized`` (decomp.py:2057): QR (or LQ, by ``absorb``) with the
+    triangular factor's diagonal made non-negative."""
+    from .split import array_split
+
+    return array_split(x, "qr", _ABSORB_NAMES.get(absorb, absorb), None, 0.0, "rel", None, stabilized=stabilized)

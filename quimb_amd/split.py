@@ -75,12 +75,14 @@ def _scale_rows(v, vh):
     return ops.multiply(vh, asarray(v.astype(vh.dtype))[:, None])
 
 
-def array_split(x, method="svd", absorb="both", max_bond=None, cutoff=1e-10, cutoff_mode="rsum2", renorm=None):
+def array_split(x, method="svd", absorb="both", max_bond=None, cutoff=1e-10, cutoff_mode="rsum2", renorm=None,
+                stabilized=True):
     """``(left, s, right)`` of a 2-d device array, entries ``None`` where ``absorb`` does not ask for them.
 
     ``method``: "svd" (rocSOLVER gesvd), "svd:eig" / "eig" (Gram matrix + syevd), "qr", "lq" (no truncation).
     ``absorb``: None / "U,s,VH", "both", "left", "right", "lorthog", "rorthog", "lfactor", "rfactor", "lsqrt",
-    "rsqrt", "s" (aliases as in decomp.py:264-298).  ``renorm``: True -> the power matching ``cutoff_mode``."""
+    "rsqrt", "s" (aliases as in decomp.py:264-298).  ``renorm``: True -> the power matching ``cutoff_mode``.
+    ``stabilized`` (qr / lq only): fix the phases so the triangular factor has a non-negative real diagonal."""
     x = asarray(x)
     if x.ndim != 2:
         raise ValueError("array_split needs a 2-d array")
@@ -96,6 +98,19 @@ def array_split(x, method="svd", absorb="both", max_bond=None, cutoff=1e-10, cut
             left, right = ops.transpose(r, (1, 0)), ops.transpose(q, (1, 0))
         else:
             left, right = linalg.qr(x)
+        if stabilized:
+            # make the triangular factor's diagonal real and non-negative (``qr_stabilized``, decomp.py:2112-2126):
+            # the phases go into the isometric factor, the product is unchanged, the decomposition unique
+            iso_left = not (method == "lq" or mode in ("left", "lfactor", "rorthog"))
+            tri = right if iso_left else left
+            d = ops.diagonal(tri).to_numpy()
+            mag = np.abs(d)
+            phase = np.where(mag > 0, d / np.where(mag > 0, mag, 1.0), 1.0)
+            if np.any(phase != 1.0):
+                if iso_left:
+                    left, right = _scale_cols(left, phase), _scale_rows(np.conj(phase), right)
+                else:
+                    left, right = _scale_cols(left, np.conj(phase)), _scale_rows(phase, right)
         return (left if mode in ("left", "right", "lfactor", "lorthog") else None, None,
                 right if mode in ("left", "right", "rfactor", "rorthog") else None)
     if method == "svd":

@@ -59,7 +59,10 @@ def get_lib_fn(backend, name):
 
 def do(fn, *args, like=None, **kwargs):
     if like is None:
-        backend = infer_backend(args[0]) if args else "numpy"
+        if fn == "einsum" and len(args) > 1 and isinstance(args[0], str):
+            backend = infer_backend(args[1])        # the equation comes first (autoray's einsum dispatcher)
+        else:
+            backend = infer_backend(args[0]) if args else "numpy"
     elif isinstance(like, str):
         backend = like
     else:

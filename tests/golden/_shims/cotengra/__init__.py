@@ -7,6 +7,8 @@ import math
 
 import numpy as np
 
+from autoray import do
+
 from . import utils  # noqa: F401
 
 _BASE = "abcdefghijklmnopqrstuvwxyzABCDEFGHIJKLMNOPQRSTUVWXYZ"
@@ -150,9 +152,10 @@ def _contract(arrays, inputs, output, path, strip_exponent):
         new = tuple(i for i in dict.fromkeys(itertools.chain(*tis)) if i in rest)
         syms = get_symbol_map(tis + [new])
         eq = ",".join("".join(syms[i] for i in t) for t in tis) + "->" + "".join(syms[i] for i in new)
-        x = np.einsum(eq, *ops)
+        x = do("einsum", eq, *ops)                     # autoray dispatch on the operands' backend, as cotengra does
         if strip_exponent:
-            f = np.max(np.abs(x))
+            f = do("max", do("abs", x))
+            f = float(f.item() if hasattr(f, "item") else f)
             if f > 0:
                 x = x / f
                 exponent += math.log10(f)
@@ -160,7 +163,7 @@ def _contract(arrays, inputs, output, path, strip_exponent):
         inputs.append(new)
     syms = get_symbol_map(inputs + [tuple(output)])
     eq = ",".join("".join(syms[i] for i in t) for t in inputs) + "->" + "".join(syms[i] for i in output)
-    x = np.einsum(eq, *arrays)
+    x = do("einsum", eq, *arrays)
     return (x, exponent) if strip_exponent else x
 
 
