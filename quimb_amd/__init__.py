@@ -16,6 +16,7 @@ from .ops import (  # noqa: F401  (autoray resolves these by name)
     einsum, einsum_pair, exp, expand_dims, eye, fuse, imag, log, log10, matmul, max, min, multiply, ndim, negative,
     norm_fro, ones, ravel, real, reshape, shape, size, sqrt, squeeze, subtract, sum, take, tensordot, trace,
     transpose, true_divide, zeros,
+    kron, mean, moveaxis, outer, power, square, stack, swapaxes, vdot,
 )
 from . import linalg  # noqa: F401  (do("linalg.svd" / "linalg.qr" / "linalg.eigh" / "linalg.norm"))
 from .contract import (  # noqa: F401

@@ -117,6 +117,39 @@ def eigh(x):
     return Array(x._dev, w.contiguous().reshape(-1), tuple(w.shape), _np_dtype(w)), _wrap(x, v)
 
 
+def _single(name, x, *others):
+    """torch.linalg.<name> on device storage (or the device's own answer), one array out."""
+    import torch
+
+    x, hook = _hook(x, name)
+    if hook is not None:
+        return hook(x, *others)
+    x, t = _as_torch(x)
+    ts = [_as_torch(o)[1] for o in others]
+    return _wrap(x, getattr(torch.linalg, name)(t, *ts))
+
+
+def inv(x):
+    return _single("inv", x)
+
+
+def pinv(x):
+    return _single("pinv", x)
+
+
+def solve(a, b):
+    return _single("solve", a, b)
+
+
+def cholesky(x):
+    return _single("cholesky", x)
+
+
+def eigvalsh(x):
+    w, _ = eigh(x)
+    return w
+
+
 def norm(x, ord=None):
     from .ops import norm_fro
 

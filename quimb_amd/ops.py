@@ -252,12 +252,110 @@ def take(x, indices, axis=None):
     return concatenate(parts, axis=axis)
 
 
+def swapaxes(x, axis1, axis2):
+    x = asarray(x)
+    perm = list(range(x.ndim))
+    perm[axis1 % x.ndim], perm[axis2 % x.ndim] = perm[axis2 % x.ndim], perm[axis1 % x.ndim]
+    return x.transpose(perm)
+
+
+def moveaxis(x, source, destination):
+    x = asarray(x)
+    src = [source] if isinstance(source, numbers.Integral) else list(source)
+    dst = [destination] if isinstance(destination, numbers.Integral) else list(destination)
+    src, dst = [a % x.ndim for a in src], [a % x.ndim for a in dst]
+    if len(src) != len(dst) or len(set(src)) != len(src) or len(set(dst)) != len(dst):
+        raise ValueError("moveaxis: source and destination must be the same number of distinct axes")
+    perm = [a for a in range(x.ndim) if a not in src]
+    for d, s_ in sorted(zip(dst, src)):
+        perm.insert(d, s_)
+    return x.transpose(perm)
+
+
 def concatenate(arrays, axis=0):
+    """numpy.concatenate on the device: every piece is copied (one strided pass, its ``axis`` moved to the
+    front) straight into its block of the result, which is moved back if ``axis`` is not the leading one."""
     arrays = [asarray(a) for a in arrays]
+    if not arrays:
+        raise ValueError("need at least one array to concatenate")
+    a0 = arrays[0]
+    arrays = [a.astype(a0.dtype) for a in arrays]
+    nd = a0.ndim
+    if nd == 0:
+        raise ValueError("zero-dimensional arrays cannot be concatenated")
+    axis = axis % nd
+    rest = a0.shape[:axis] + a0.shape[axis + 1:]
+    for a in arrays:
+        if a.ndim != nd or a.shape[:axis] + a.shape[axis + 1:] != rest:
+            raise ValueError("all the input array dimensions except for the concatenation axis must match exactly")
     if len(arrays) == 1:
-        return arrays[0]
-    host = np.concatenate([a.to_numpy() for a in arrays], axis=axis)  # rare, off the hot path
-    return Array.from_numpy(host, dev=arrays[0]._dev)
+        return a0
+    total = builtins.sum(a.shape[axis] for a in arrays)
+    out = Array.empty((total,) + rest, a0.dtype, a0._dev)
+    block = prod(rest)
+    pos = 0
+    perm = [axis] + [i for i in range(nd) if i != axis]
+    for a in arrays:
+        if a.size:
+            st = contig_strides(a.shape)
+            a._dev.permute(out._buf[pos * block:], a._buf, [a.shape[i] for i in perm], [st[i] for i in perm], 0, a.dtype)
+        pos += a.shape[axis]
+    return out if axis == 0 else moveaxis(out, 0, axis)
+
+
+def stack(arrays, axis=0):
+    arrays = [asarray(a) for a in arrays]
+    return concatenate([expand_dims(a, axis % (a.ndim + 1)) for a in arrays], axis % (arrays[0].ndim + 1))
+
+
+def outer(a, b):
+    return tensordot(asarray(a).ravel(), asarray(b).ravel(), axes=0)
+
+
+def kron(a, b):
+    """Kronecker product of two arrays of equal rank (numpy.kron for the common 1-d / 2-d cases and beyond)."""
+    a, b = asarray(a), asarray(b)
+    if a.ndim != b.ndim:
+        raise ValueError("kron: operands need the same number of dimensions")
+    nd = a.ndim
+    y = tensordot(a, b, axes=0)                                    # (a0.., b0..)
+    y = y.transpose([i // 2 + (i % 2) * nd for i in range(2 * nd)])  # (a0, b0, a1, b1, ...)
+    return y.reshape([a.shape[i] * b.shape[i] for i in range(nd)])
+
+
+def power(x, p):
+    x = asarray(x)
+    if isinstance(p, numbers.Integral) and p >= 0:
+        out = None
+        base, e = x, int(p)
+        if e == 0:
+            return Array.full(x.shape, 1.0, x.dtype, x._dev)
+        while e:                                                     # square-and-multiply on the device
+            if e & 1:
+                out = base if out is None else out * base
+            e >>= 1
+            if e:
+                base = base * base
+        return out
+    if p == 0.5:
+        return sqrt(x)
+    return exp(log(x) * p)
+
+
+def square(x):
+    x = asarray(x)
+    return x * x
+
+
+def mean(x, axis=None):
+    x = asarray(x)
+    n = x.size if axis is None else prod([x.shape[a % x.ndim] for a in ((axis,) if isinstance(axis, numbers.Integral) else axis)])
+    return sum(x, axis=axis) / n
+
+
+def vdot(a, b):
+    a, b = asarray(a).ravel(), asarray(b).ravel()
+    return tensordot(a.conj(), b, axes=([0], [0]))
 
 
 def squeeze(x, axis=None):

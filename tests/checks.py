@@ -139,6 +139,26 @@ def check_layout_ops(dtype, seed=2):
     np.testing.assert_array_equal(X[:, 2].to_numpy(), x[:, 2])
     np.testing.assert_array_equal(X[..., 1].to_numpy(), x[..., 1])
     np.testing.assert_array_equal(X[1:3, :, ::2, -1].to_numpy(), x[1:3, :, ::2, -1])
+    # further numpy names quimb's generic code paths ask a backend for (decomp.py / array_ops.py / gate builders)
+    np.testing.assert_array_equal(qa.swapaxes(X, 1, -1).to_numpy(), np.swapaxes(x, 1, -1))
+    np.testing.assert_array_equal(qa.moveaxis(X, 0, -1).to_numpy(), np.moveaxis(x, 0, -1))
+    np.testing.assert_array_equal(qa.moveaxis(X, (0, 1), (2, 0)).to_numpy(), np.moveaxis(x, (0, 1), (2, 0)))
+    for ax in range(-1, x.ndim):
+        np.testing.assert_array_equal(qa.concatenate([X, X[:, :1] if ax == 1 else X], axis=ax).to_numpy(),
+                                      np.concatenate([x, x[:, :1] if ax == 1 else x], axis=ax))
+        np.testing.assert_array_equal(qa.stack([X, X, X], axis=ax).to_numpy(), np.stack([x, x, x], axis=ax))
+    with pytest.raises(ValueError):
+        qa.concatenate([X, X[1:]], axis=1)
+    v1, v2 = rand(np.random.default_rng(4), (5,), dtype), rand(np.random.default_rng(5), (7,), dtype)
+    assert_close(qa.outer(v1, v2).to_numpy(), np.outer(v1, v2), dtype)
+    k1, k2 = rand(np.random.default_rng(6), (2, 3), dtype), rand(np.random.default_rng(7), (4, 2), dtype)
+    assert_close(qa.kron(k1, k2).to_numpy(), np.kron(k1, k2), dtype)
+    assert_close(qa.kron(v1, v2).to_numpy(), np.kron(v1, v2), dtype)
+    assert_close(qa.power(qa.asarray(k1), 3).to_numpy(), k1**3, dtype)
+    assert_close(qa.square(qa.asarray(k1)).to_numpy(), k1**2, dtype)
+    assert_close(np.asarray(qa.mean(qa.asarray(k1)).to_numpy()), np.mean(k1), dtype)
+    assert_close(qa.mean(qa.asarray(k1), axis=0).to_numpy(), np.mean(k1, axis=0), dtype)
+    assert_close(np.asarray(qa.vdot(v1, v1).to_numpy()), np.vdot(v1, v1), dtype)
     # reversed views: negative source strides (and negative offsets inside the copy kernel's tiles)
     np.testing.assert_array_equal(X[::-1].to_numpy(), x[::-1])
     np.testing.assert_array_equal(X[..., ::-1].to_numpy(), x[..., ::-1])
@@ -1212,3 +1232,24 @@ def check_network_exponents(dtype="float64"):
                 z = z[0] * 10 ** z[1]
         assert z == pytest.approx(zex, rel=rel), (strip_exponent, equalize_norms, inplace)
     assert (norm_tn >> sites) == pytest.approx(zex, rel=rel)
+
+
+def check_linalg_extras(dtype="float64"):
+    """``linalg.inv / pinv / solve / cholesky / eigvalsh`` (decompositions row) vs numpy."""
+    rng = np.random.default_rng(12)
+    low = np.dtype(dtype).name in ("float32", "complex64")
+    tol = 2e-4 if low else 1e-10
+    a = rand(rng, (9, 9), dtype)
+    spd = (a @ a.conj().T + 9 * np.eye(9)).astype(dtype)
+    b = rand(rng, (9, 3), dtype)
+    hi = np.complex128 if np.dtype(dtype).kind == "c" else np.float64
+    close = lambda got, want: np.max(np.abs(got.to_numpy() - want)) <= tol * np.max(np.abs(want))
+    assert close(qa.linalg.inv(qa.asarray(spd)), np.linalg.inv(spd.astype(hi)))
+    assert close(qa.linalg.solve(qa.asarray(spd), qa.asarray(b)), np.linalg.solve(spd.astype(hi), b.astype(hi)))
+    assert close(qa.linalg.cholesky(qa.asarray(spd)), np.linalg.cholesky(spd.astype(hi)))
+    assert close(qa.linalg.eigvalsh(qa.asarray(spd)), np.linalg.eigvalsh(spd.astype(hi)))
+    r = rand(rng, (9, 4), dtype)
+    assert close(qa.linalg.pinv(qa.asarray(r)), np.linalg.pinv(r.astype(hi)))
+    # the results are ordinary device arrays: feed one straight into a contraction
+    x = qa.tensordot(qa.linalg.inv(qa.asarray(spd)), qa.asarray(spd), axes=([1], [0])).to_numpy()
+    assert np.max(np.abs(x - np.eye(9))) <= 50 * tol

@@ -242,3 +242,15 @@ class EmuDevice:
     def linalg_eigh(self, x):
         w, v = np.linalg.eigh(x.to_numpy())
         return self._wrap_np(w), self._wrap_np(v)
+
+    def linalg_inv(self, x):
+        return self._wrap_np(np.linalg.inv(x.to_numpy()))
+
+    def linalg_pinv(self, x):
+        return self._wrap_np(np.linalg.pinv(x.to_numpy()))
+
+    def linalg_solve(self, a, b):
+        return self._wrap_np(np.linalg.solve(a.to_numpy(), np.asarray(b.to_numpy() if hasattr(b, "to_numpy") else b)))
+
+    def linalg_cholesky(self, x):
+        return self._wrap_np(np.linalg.cholesky(x.to_numpy()))

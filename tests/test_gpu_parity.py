@@ -365,3 +365,8 @@ def test_no_cpu_fallback(hip):
 def test_network_exponent_bookkeeping(hip, dtype):
     """strip_exponent x equalize_norms x inplace grids of the reference (tests/test_tensor/test_contract.py:8-88)."""
     checks.check_network_exponents(dtype)
+
+
+@pytest.mark.parametrize("dtype", ["float64", "float32", "complex128"])
+def test_linalg_extras(hip, dtype):
+    checks.check_linalg_extras(dtype)

@@ -247,3 +247,8 @@ def test_tree_cache_on_disk(tmp_path):
 @pytest.mark.parametrize("dtype", ["float64", "float32"])
 def test_network_exponent_bookkeeping(emu, dtype):
     checks.check_network_exponents(dtype)
+
+
+@pytest.mark.parametrize("dtype", ["float64", "complex128"])
+def test_linalg_extras(emu, dtype):
+    checks.check_linalg_extras(dtype)
