@@ -111,5 +111,15 @@ for bits in ("11000", "00000", "01100"):
     amp = circ.amplitude(bits, simplify_sequence="")
     assert launched() > n0 and abs(complex(amp) - ref.amplitude(bits, simplify_sequence="")) < 1e-12
 
+# 7. mode (b) of INTEGRATION.md: the tree quimb hands out (``tn.contraction_tree`` / ``contract(get="tree")``,
+#    tensor_core.py:194-197) adopted by the whole-tree executor, data taken from the network in tensor order
+tree = tn.contraction_tree(optimize="greedy")
+ex = qa.TreeExecutor(qa.ContractionTree.from_any(tree), "float64")
+m, e = ex([t.data for t in tn], strip_exponent=True)
+assert abs(float(m.item()) * 10**e / want - 1) < 1e-12
+assert ex.tree.contraction_cost() <= tree.contraction_cost() and ex.tree.contraction_width() == tree.contraction_width()
+info = tn.contract(all, optimize="greedy", get="tree")
+assert qa.ContractionTree.from_any(info).get_path() == tree.get_path()
+
 print("backend launches:", dev.calls)
 print("DROPIN OK")
