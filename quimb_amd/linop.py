@@ -66,7 +66,16 @@ class TNLinearOperator:
 
     def _apply(self, x, ncols):
         host = not isinstance(x, Array)
-        xd = asarray(x).astype(self.dtype)
+        xin = asarray(x)
+        if xin.dtype.kind == "c" and self.dtype.kind != "c":
+            # a real operator on complex data (``tn_lo.dot(X)`` with complex X in the reference's own test,
+            # tests/test_tensor/test_tensor_core.py:2200-2202): linear, so real and imaginary parts separately
+            from . import ops
+
+            re, im = self._apply(ops.real(xin), ncols), self._apply(ops.imag(xin), ncols)
+            out = asarray(re).astype(xin.dtype) + asarray(im).astype(xin.dtype) * 1j
+            return out.to_numpy() if host else out
+        xd = xin.astype(self.dtype)
         xd = xd.reshape(self.rdims + ((ncols,) if ncols else ()))
         if self.is_conj:
             xd = xd.conj()
@@ -108,7 +117,64 @@ class TNLinearOperator:
 
         new = copy.copy(self)
         new.is_conj = not self.is_conj
+        new._graphed = None
         return new
+
+    def _transpose(self):
+        """The transposed operator: the same tensors with the roles of ``left_inds`` and ``right_inds`` swapped
+        (``TNLinearOperator._transpose``, tensor_core.py:12480-12500)."""
+        import copy
+
+        new = copy.copy(self)
+        new.left_inds, new.right_inds = self.right_inds, self.left_inds
+        new.ldims, new.rdims = self.rdims, self.ldims
+        new.shape = (self.shape[1], self.shape[0])
+        new._exprs = {}
+        new._graphed = None
+        return new
+
+    @property
+    def T(self):
+        return self._transpose()
+
+    def _adjoint(self):
+        return self._transpose().conj()
+
+    @property
+    def H(self):
+        return self._adjoint()
+
+    def rmatvec(self, vec):
+        """``A^H @ vec`` (what scipy's ``svds`` / ``lsqr`` ask a LinearOperator for)."""
+        return self.H.matvec(vec)
+
+    _rmatvec = rmatvec
+
+    def rmatmat(self, mat):
+        return self.H.matmat(mat)
+
+    _rmatmat = rmatmat
+
+    def trace(self):
+        """Contract left and right indices pairwise without forming the matrix
+        (``TNLinearOperator.trace``, tensor_core.py:12530-12549; the reference reaches it through ``np.trace``)."""
+        if self.shape[0] != self.shape[1] or self.ldims != self.rdims:
+            raise ValueError("trace needs matching left and right index dimensions")
+        from .contract import array_contract
+
+        ren = dict(zip(self.right_inds, self.left_inds))
+        inds = [tuple(ren.get(ix, ix) for ix in t) for t in self._inds]
+        arrays = [a.conj() for a in self._arrays] if self.is_conj else self._arrays
+        out = array_contract(arrays, inds, (), optimize=self._optimize)
+        return np.asarray(out.to_numpy() if hasattr(out, "to_numpy") else out).item()
+
+    def aslinearoperator(self):
+        """A ``scipy.sparse.linalg.LinearOperator`` view (host vectors in and out) for scipy's iterative solvers."""
+        from scipy.sparse.linalg import LinearOperator
+
+        dt = np.dtype(self.dtype)
+        return LinearOperator(self.shape, matvec=self.matvec, rmatvec=self.rmatvec, matmat=self.matmat,
+                              rmatmat=self.rmatmat, dtype=dt)
 
     def to_dense(self):
         eye = np.eye(self.shape[1], dtype=self.dtype)

@@ -740,7 +740,8 @@ def check_linop(dtype, chi=12):
     A = qa.TNLinearOperator(tensors, left, right)
     n = chi * 2 * 2 * chi
     assert A.shape == (n, n)
-    dense = np.einsum("apA,pqsS,qrtT,brB->astbASTB", *[t[0].astype(np.float64) for t in tensors]).reshape(n, n)
+    hi0 = np.complex128 if np.dtype(dtype).kind == "c" else np.float64
+    dense = np.einsum("apA,pqsS,qrtT,brB->astbASTB", *[t[0].astype(hi0) for t in tensors]).reshape(n, n)
     rng = np.random.default_rng(1)
     x = rand(rng, (n,), dtype)
     assert_close(A.matvec(x), dense @ x, dtype)
@@ -755,6 +756,31 @@ def check_linop(dtype, chi=12):
     for _ in range(3):
         x2 = rand(rng, (n,), dtype)
         assert_close((Ag @ qa.asarray(x2)).to_numpy(), dense @ x2, dtype)
+    # the reference's own operator test (tests/test_tensor/test_tensor_core.py:2181-2215): a 4-tensor ring viewed
+    # as a (a, b) x (c, d) operator -- singular values through scipy's svds (needs the adjoint), a COMPLEX block
+    # of vectors through a real operator, the trace without forming the matrix
+    ring = [(rand(rng, (3, 5, 5), dtype), "aef"), (rand(rng, (3, 5, 5), dtype), "beg"),
+            (rand(rng, (3, 5, 5), dtype), "cfh"), (rand(rng, (3, 5, 5), dtype), "dhg")]
+    lo = qa.TNLinearOperator(ring, ("a", "b"), ("c", "d"))
+    hi = np.complex128 if np.dtype(dtype).kind == "c" else np.float64
+    d = np.einsum("aef,beg,cfh,dhg->abcd", *[t[0].astype(hi) for t in ring]).reshape(9, 9)
+    assert lo.shape == (9, 9)
+    assert_close(lo.to_dense(), d, dtype)
+    assert_close(lo.H.to_dense(), d.conj().T, dtype)
+    assert_close(lo.T.to_dense(), d.T, dtype)
+    y = rand(rng, (9,), dtype)
+    assert_close(lo.rmatvec(y), d.conj().T @ y, dtype)
+    X = (rng.normal(size=(9, 8)) + 1j * rng.normal(size=(9, 8))).astype(
+        np.complex64 if np.dtype(dtype).itemsize <= 8 and np.dtype(dtype).name in ("float32", "complex64") else np.complex128)
+    got = lo.dot(X)
+    assert np.iscomplexobj(got)
+    assert_close(got, d @ X, dtype)
+    assert np.asarray(lo.trace()).item() == pytest.approx(np.trace(d), rel=2e-4 if np.dtype(dtype).itemsize <= 8 and np.dtype(dtype).name in ("float32", "complex64") else 1e-10)
+    from scipy.sparse.linalg import svds
+
+    s_lo = np.sort(svds(lo.aslinearoperator(), k=5, return_singular_vectors=False))
+    s_d = np.sort(np.linalg.svd(d, compute_uv=False))[-5:]
+    assert np.max(np.abs(s_lo - s_d)) <= (2e-3 if np.dtype(dtype).name in ("float32", "complex64") else 1e-8) * s_d[-1]
 
 
 def check_random_pairs(dtype, ncases=120, seed=77):

@@ -163,8 +163,9 @@ def test_circuit_amplitude(emu):
     checks.check_circuit_amplitude("complex128", n=8, depth=4)
 
 
-def test_linop(emu):
-    checks.check_linop("float64")
+@pytest.mark.parametrize("dtype", ["float64", "float32", "complex128"])
+def test_linop(emu, dtype):
+    checks.check_linop(dtype)
 
 
 def test_tensor_network_semantics(emu):
