@@ -1279,3 +1279,74 @@ def check_linalg_extras(dtype="float64"):
     # the results are ordinary device arrays: feed one straight into a contraction
     x = qa.tensordot(qa.linalg.inv(qa.asarray(spd)), qa.asarray(spd), axes=([1], [0])).to_numpy()
     assert np.max(np.abs(x - np.eye(9))) <= 50 * tol
+
+
+def check_tensor_methods(dtype="float64"):
+    """The reference's Tensor-level tests for the layout methods on the path, restated
+    (tests/test_tensor/test_tensor_core.py:184-323): fuse / unfuse / fuse leftover / transpose / moveindex /
+    trace (single and multi) / sum_reduce / vector_reduce / isel, on device data."""
+    rng = np.random.default_rng(21)
+    T = qa.Tensor
+    mk = lambda shape, inds, **kw: T(qa.asarray(rand(rng, shape, dtype)), inds, **kw)
+    a = mk((2, 3, 4, 5), "abcd", tags={"blue"})
+    b = a.fuse({"bra": ["a", "c"], "ket": "bd"})
+    assert b.shape == (8, 15) and b.inds == ("bra", "ket") and b.tags == ("blue",)
+    assert_close(b.data, np.transpose(a.data.to_numpy(), (0, 2, 1, 3)).reshape(8, 15), dtype)
+    b2 = a.fuse({"ket": "bd", "bra": "ac"})
+    assert b2.shape == (15, 8) and b2.inds == ("ket", "bra")
+    c = b.unfuse({"bra": ["a", "c"], "ket": "bd"}, {"bra": [2, 4], "ket": [3, 5]})
+    assert c.inds == ("a", "c", "b", "d") and c.shape == (2, 4, 3, 5)
+    assert np.array_equal(c.data.to_numpy().reshape(8, 15), b.data.to_numpy())
+    assert c.almost_equals(a)
+    with pytest.raises(ValueError):
+        b.unfuse({"bra": ["a", "c"]}, {"bra": [3, 4]})
+    a6 = mk((2, 3, 4, 5, 2, 2), "abcdef", tags={"blue"})
+    b6 = a6.fuse({"bra": "ac", "ket": "bd"})
+    assert b6.shape == (8, 15, 2, 2) and b6.inds == ("bra", "ket", "e", "f") and b6.tags == ("blue",)
+    at = a6.transpose(*"cdfeba")
+    assert at.shape == (4, 5, 2, 2, 3, 2) and at.inds == tuple("cdfeba")
+    assert_close(at.data, np.transpose(a6.data.to_numpy(), [2, 3, 5, 4, 1, 0]), dtype)
+    with pytest.raises(ValueError):
+        a6.transpose(*"cdfebz")
+    A, B = mk((3, 4, 5), "abc"), mk((3, 4, 5), "abc")
+    x = A @ B
+    A.moveindex_("b", 0)
+    B.moveindex_("b", -1)
+    assert A.inds[0] == "b" and B.inds[2] == "b"
+    assert A @ B == pytest.approx(x, rel=1e-5)
+    t = mk((3, 3, 3), "abc")
+    tb = t.trace("a", "c")
+    assert tb.inds == ("b",)
+    assert_close(tb.data, np.trace(t.data.to_numpy(), axis1=0, axis2=2), dtype)
+    tc = t.trace("a", "b")
+    assert tc.inds == ("c",)
+    assert_close(tc.data, np.trace(t.data.to_numpy(), axis1=0, axis2=1), dtype)
+    with pytest.raises(ValueError):
+        t.trace("a", "z")
+    sq = mk((2, 2), "ab")
+    assert not isinstance(sq.trace("a", "b"), T) and isinstance(sq.trace("a", "b", preserve_tensor=True), T)
+    t5 = mk((3, 3, 3, 3, 3), "abcde")
+    assert t5.trace(["a", "c"], ["e", "b"]).almost_equals(t5.trace("a", "e").trace("c", "b"), rtol=1e-4, atol=1e-5)
+    with pytest.raises(ValueError):
+        t5.trace(["a", "b", "c"], ["d", "e"])
+    t3 = mk((2, 3, 4), "abc")
+    for ax, ix in enumerate("abc"):
+        r = t3.sum_reduce(ix)
+        assert r.ndim == 2 and r.inds == tuple(i for i in "abc" if i != ix)
+        assert_close(r.data, t3.data.to_numpy().sum(axis=ax), dtype)
+    with pytest.raises(ValueError):
+        t3.sum_reduce("d")
+    g = rand(rng, (3,), dtype)
+    tv = t3.vector_reduce("b", g)
+    assert tv.shape == (2, 4) and tv.inds == ("a", "c")
+    assert_close(tv.data, np.einsum("abc,b->ac", t3.data.to_numpy(), g), dtype)
+    Ti = mk((2, 3, 4, 5, 6), ["a", "b", "c", "d", "e"])
+    tis = Ti.isel({"d": 2, "b": 0})
+    assert tis.shape == (2, 4, 6) and tis.inds == ("a", "c", "e")
+    assert np.array_equal(tis.data.to_numpy(), Ti.data.to_numpy()[:, 0, :, 2, :])
+    assert_close(a6.to_dense("ac", "bd", "ef"), np.transpose(a6.data.to_numpy(), (0, 2, 1, 3, 4, 5)).reshape(8, 15, 4), dtype)
+    tl, tr = a.split(["a", "c"], cutoff=0.0, bond_ind="k")
+    assert tl.inds == ("a", "c", "k") and tr.inds == ("k", "b", "d")
+    assert (tl @ tr).almost_equals(a, rtol=1e-4, atol=1e-5)
+    assert a.conj().H.almost_equals(a) and a.norm() == pytest.approx(np.linalg.norm(a.data.to_numpy().ravel()), rel=1e-5)
+    assert a.reindex({"a": "z"}).inds == ("z", "b", "c", "d")

@@ -370,3 +370,9 @@ def test_network_exponent_bookkeeping(hip, dtype):
 @pytest.mark.parametrize("dtype", ["float64", "float32", "complex128"])
 def test_linalg_extras(hip, dtype):
     checks.check_linalg_extras(dtype)
+
+
+@pytest.mark.parametrize("dtype", ["float64", "float32", "complex64"])
+def test_tensor_methods(hip, dtype):
+    """The reference's Tensor-level layout tests (test_tensor_core.py:184-323) on device data."""
+    checks.check_tensor_methods(dtype)

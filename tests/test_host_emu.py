@@ -253,3 +253,8 @@ def test_network_exponent_bookkeeping(emu, dtype):
 @pytest.mark.parametrize("dtype", ["float64", "complex128"])
 def test_linalg_extras(emu, dtype):
     checks.check_linalg_extras(dtype)
+
+
+@pytest.mark.parametrize("dtype", ["float64", "float32", "complex128"])
+def test_tensor_methods(emu, dtype):
+    checks.check_tensor_methods(dtype)
