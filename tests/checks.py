@@ -435,6 +435,11 @@ def check_mps_dense(dtype="float64", L=10, chi=7):
     assert isinstance(part, qa.TensorNetwork) and len(part.tensors) == L - 7 + 1
     for bsz in (1, 3):
         assert_close(tn.contract_structured(sites, structure_bsz=bsz, output_inds=out).data, want, dtype)
+    # amplitudes: isel every physical index, contract what is left == the dense vector's entry
+    # (reference tests/test_tensor/test_tn1d/test_core.py:368-373)
+    for bits in ((0,) * L, (1, 0) * (L // 2), tuple(int(c) for c in format(0b1011001110 % (1 << L), f"0{L}b"))):
+        amp = tn.isel({("k", i): b for i, b in enumerate(bits)}).contract(all)
+        assert amp == pytest.approx(want[bits], rel=1e-4 if np.dtype(dtype).itemsize == 4 else 1e-10, abs=1e-12)
 
 
 def check_stream_kernels(dtype, seed=8):
