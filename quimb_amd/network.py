@@ -257,6 +257,25 @@ class TensorNetwork:
             t = Tensor(asarray(t.data) * 10.0**tn.exponent, t.inds, t.tags)
         return _scalar(t) if not t.inds else t
 
+    def to_dense(self, *inds_seq, **opts):
+        """Contract everything and fuse the open indices into one axis per group (``TensorNetwork.to_dense``,
+        tensor_core.py:10230-10260)."""
+        out = tuple(ix for g in inds_seq for ix in g)
+        t = self.contract(all, output_inds=out, preserve_tensor=True, **opts)
+        if isinstance(t, tuple):
+            raise ValueError("to_dense does not combine with strip_exponent")
+        return t.to_dense(*inds_seq)
+
+    def aslinearoperator(self, left_inds, right_inds, **opts):
+        """This network as an operator from ``right_inds`` to ``left_inds`` without forming the matrix
+        (``TensorNetwork.aslinearoperator``, tensor_core.py:10262-10290)."""
+        from .linop import TNLinearOperator
+
+        lo = TNLinearOperator(self.tensors, left_inds, right_inds, **opts)
+        if self.exponent:
+            raise ValueError("aslinearoperator: fold tn.exponent into a tensor first (distribute it)")
+        return lo
+
     def contract_structured(self, site_tags, structure_bsz=5, **opts):
         """1D structured contraction (``TensorNetwork1D.contract_structured``, quimb/tensor/tn1d/core.py:502-557):
         the site tags present in the network, in the given order, grouped ``structure_bsz`` at a time and

@@ -766,9 +766,11 @@ def check_linop(dtype, chi=12):
     # of vectors through a real operator, the trace without forming the matrix
     ring = [(rand(rng, (3, 5, 5), dtype), "aef"), (rand(rng, (3, 5, 5), dtype), "beg"),
             (rand(rng, (3, 5, 5), dtype), "cfh"), (rand(rng, (3, 5, 5), dtype), "dhg")]
-    lo = qa.TNLinearOperator(ring, ("a", "b"), ("c", "d"))
+    ring_tn = qa.TensorNetwork([qa.Tensor(a, i) for a, i in ring])
+    lo = ring_tn.aslinearoperator(("a", "b"), ("c", "d"))          # tn.aslinearoperator, as the reference's test does
     hi = np.complex128 if np.dtype(dtype).kind == "c" else np.float64
     d = np.einsum("aef,beg,cfh,dhg->abcd", *[t[0].astype(hi) for t in ring]).reshape(9, 9)
+    assert_close(ring_tn.to_dense(["a", "b"], ["c", "d"]), d, dtype)
     assert lo.shape == (9, 9)
     assert_close(lo.to_dense(), d, dtype)
     assert_close(lo.H.to_dense(), d.conj().T, dtype)
