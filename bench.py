@@ -98,7 +98,7 @@ def main():
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
 
     import quimb_amd as qa
-    from quimb_amd.distributed import rank_slices
+    from quimb_amd.distributed import contract_sliced, rank_slices
 
     dev = qa.default_device()
     dtype = "float32"
@@ -110,18 +110,15 @@ def main():
     ex = qa.TreeExecutor(tree, dtype)
     xs = [qa.asarray(a) for a in arrays]  # resident in HBM before the timed region
     my = list(rank_slices(tree.nslices, rank, world)) if sliced else None
-    red = torch.zeros(2, dtype=torch.float64, device=dev.tdev)
 
     def step():
         if sliced:
-            m, e = ex(xs, strip_exponent=True, slices=my)
             if world > 1:
-                et = torch.tensor([e if np.isfinite(e) else -1e300], dtype=torch.float64, device=dev.tdev)
-                dist.all_reduce(et, op=dist.ReduceOp.MAX)
-                emax = float(et.cpu()[0])
-                t = m._buf[:1].double() * (10.0 ** (e - emax) if np.isfinite(e) else 0.0)
-                dist.all_reduce(t, op=dist.ReduceOp.SUM)
-                return float(t.cpu()[0]), emax
+                # this rank's slices, then ONE all-reduce of the (mantissa, exponent) pair at the join -- the
+                # library routine the gloo tests exercise (tests/test_distributed_gloo.py), RCCL here
+                m, e = contract_sliced(ex, xs, strip_exponent=True)
+                return float(np.asarray(m).reshape(-1)[0]), e
+            m, e = ex(xs, strip_exponent=True, slices=my)
             return m.item(), e
         m, e = ex(xs, strip_exponent=True)
         return m.item(), e
