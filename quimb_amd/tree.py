@@ -163,6 +163,7 @@ class ContractionTree:
         tensor (contraction is associative); ids, inputs and output are unchanged."""
         n = len(self.inputs)
         best = self
+        size = self.size_dict
         si = 0
         while si + 1 < len(best.ssa_path):
             ssa = best.ssa_path
@@ -171,15 +172,23 @@ class ContractionTree:
             if len(c1) == 2 and len(c2) == 2 and r1 in c2 and c2[0] != c2[1]:
                 w2 = c2[0] if c2[1] == r1 else c2[1]
                 if w2 < r1:
-                    for a, w1 in (c1, c1[::-1]):
-                        trial = list(ssa)
-                        trial[si], trial[si + 1] = (w1, w2), (a, r1)
-                        t = ContractionTree(self.inputs, self.output, self.size_dict, ssa_path=trial,
-                                            sliced_inds=self.sliced_inds)
-                        small = prod(self.size_dict[ix] for ix in t.steps[si][3])
-                        old_cost = best.steps[si][4] + best.steps[si + 1][4]
-                        if small <= max_small and t.steps[si][4] + t.steps[si + 1][4] < gain * old_cost:
-                            best = t
+                    # local evaluation (no tree rebuild): only the two steps' index sets matter.  An index of
+                    # W1 u W2 survives into W12 iff A or the pair's final result still carries it.
+                    _, _, ops1, _, m1 = best.steps[si]
+                    _, _, ops2, keep2, m2 = best.steps[si + 1]
+                    w2_inds = set(ops2[0] if c2[1] == r1 else ops2[1])
+                    final = set(keep2)
+                    for (a, w1), (a_inds, w1_inds) in (((c1[0], c1[1]), (ops1[0], ops1[1])),
+                                                      ((c1[1], c1[0]), (ops1[1], ops1[0]))):
+                        a_set, pair = set(a_inds), set(w1_inds) | w2_inds
+                        w12 = pair & (a_set | final)
+                        small = prod(size[ix] for ix in w12)
+                        cost = prod(size[ix] for ix in pair) + prod(size[ix] for ix in a_set | w12)
+                        if small <= max_small and cost < gain * (m1 + m2):
+                            trial = list(ssa)
+                            trial[si], trial[si + 1] = (w1, w2), (a, r1)
+                            best = ContractionTree(self.inputs, self.output, self.size_dict, ssa_path=trial,
+                                                   sliced_inds=self.sliced_inds)
                             break
             si += 1
         return best
