@@ -42,6 +42,26 @@ def build_network(Lx, Ly, D, seed, dtype):
     return arrays, inputs, size
 
 
+def _result_with_parity(res, args):
+    """(mantissa, exponent) of the contraction, plus -- when the fp64 numpy oracle of exactly this full-size network
+    has been evaluated (tests/golden/make_full_size_oracle.py, ~10 min on the host, value stored) -- the relative
+    error of this run against it (north_star: 1e-6)."""
+    out = {"mantissa": res[0], "exponent_log10": res[1]}
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests", "golden", "full_size_oracle.json")
+    try:
+        ref = json.load(open(path)).get(str(args.seed))
+    except (OSError, ValueError):
+        ref = None
+    if ref and (ref["Lx"], ref["Ly"], ref["D"]) == (args.Lx, args.Ly, args.D) and res[0]:
+        import math
+
+        log10_abs = math.log10(abs(res[0])) + res[1]
+        out["fp64_oracle_log10_abs"] = ref["log10_abs"]
+        out["rel_err_vs_fp64_oracle"] = abs(10.0 ** (log10_abs - ref["log10_abs"]) - 1.0)
+        out["sign_matches_oracle"] = (res[0] > 0) == (ref["sign"] > 0)
+    return out
+
+
 def cpu_baseline(D, Ly, seed, budget_s=20.0):
     """numpy (OpenBLAS) port of the same sweep on a bounded sample: the top rows
     of the same 10-wide D=6 network, as many rows as fit the time budget."""
@@ -240,7 +260,7 @@ def main():
                 "parallelism": f"slices{world}" if sliced else "single",
             },
             "pct_mfma_peak": 100.0 * value / (MFMA_F32_PEAK_TF * world),
-            "result": {"mantissa": res[0], "exponent_log10": res[1]},
+            "result": _result_with_parity(res, args),
             "roofline": roof,
             "cpu_baseline": cpu,
         }

@@ -1,0 +1,37 @@
+#!/usr/bin/env python
+"""fp64 oracle value of the FULL-SIZE headline network (10x10, D=6, the bench's tensors cast to float64, the same
+site-by-site sweep path), for the seeds given on the command line.  About 10 minutes per seed on 8 host cores
+(1.7e12 FLOP through numpy), which is why the value is stored instead of recomputed by the tests:
+
+    python tests/golden/make_full_size_oracle.py 0 7      ->  tests/golden/full_size_oracle.json
+
+``tests/test_gpu_parity.py::test_full_size_10x10_D6_properties`` compares the fp32 device result with it at the
+tolerance north_star names (1e-6 relative)."""
+import json
+import os
+import sys
+import time
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+
+import numpy as np  # noqa: E402
+
+import quimb_amd as qa  # noqa: E402  (tree bookkeeping only: no device is touched)
+from oracle import np_oracle as orc  # noqa: E402
+
+out_file = os.path.join(HERE, "full_size_oracle.json")
+res = json.load(open(out_file)) if os.path.exists(out_file) else {}
+for seed in [int(s) for s in sys.argv[1:]] or [7]:
+    arrays, inputs = orc.tn2d_rand(10, 10, 6, seed=seed, dtype="float32")       # exactly the bench / test inputs
+    size = {ix: 6 for t in inputs for ix in t}
+    tree = qa.ContractionTree(inputs, (), size, path=qa.sweep_path_2d(10, 10))
+    t0 = time.time()
+    m, e = orc.oracle_array_contract([a.astype(np.float64) for a in arrays], inputs, (), path=tree.get_path(),
+                                     strip_exponent=True)
+    m = float(np.asarray(m).item())
+    res[str(seed)] = {"sign": float(np.sign(m)), "log10_abs": float(np.log10(abs(m)) + e),
+                      "seconds": round(time.time() - t0, 1), "Lx": 10, "Ly": 10, "D": 6}
+    print(seed, res[str(seed)], flush=True)
+    with open(out_file, "w") as f:
+        json.dump(res, f, indent=1, sort_keys=True)

@@ -329,6 +329,13 @@ def test_full_size_10x10_D6_properties(hip):
 
     s0, l0 = log_value(ex(arrays, strip_exponent=True))
     assert np.isfinite(l0) and s0 != 0
+    # ... and against the fp64 numpy oracle of the SAME full-size network and tree, evaluated once on the host
+    # (~10 min; tests/golden/make_full_size_oracle.py -> full_size_oracle.json) at north_star's tolerance:
+    # 1e-6 relative = 4.3e-7 in log10
+    import json
+
+    ref = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "full_size_oracle.json")))["7"]
+    assert s0 == ref["sign"] and abs(l0 - ref["log10_abs"]) < np.log10(1.0 + 1e-6)
     # reproducibility: same executor, same inputs -> bit-identical (no atomics in the data path)
     assert log_value(ex(arrays, strip_exponent=True)) == (s0, l0)
     # fused pairs (chain2r) against one launch per step (sweep kernels)
@@ -350,6 +357,7 @@ def test_full_size_10x10_D6_properties(hip):
     assert sliced_tree.nslices == 6
     s3, l3 = log_value(qa.TreeExecutor(sliced_tree, "float32")(arrays, strip_exponent=True))
     assert s3 == s0 and abs(l3 - l0) < 1e-5
+    assert abs(l3 - ref["log10_abs"]) < np.log10(1.0 + 1e-6)          # the sliced sum meets the same bar
 
 
 def test_no_cpu_fallback(hip):
