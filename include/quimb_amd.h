@@ -166,6 +166,38 @@ int qamd_contract_chain2(const qamd_chain2_plan* plan, const void* A, const void
                          const void* scale_2, void* absmax_out, void* stream);
 
 /*
+ * Fused TRIPLE of streaming contractions (three adjacent interior site absorptions of a boundary
+ * sweep, quimb/tensor/tn2d/core.py:1393-1402 three times) -- neither intermediate touches HBM; the
+ * chunk state is exchanged through LDS between the stages (chain3.hip):
+ *
+ *   X1[h1, x, b, c, m] = sum_{h, a}   W1[h, a, h1, x]  * A[(h, a), b, c, m]
+ *   X2[h2, y, x, c, m] = sum_{h1, b}  W2[h1, b, h2, y] * X1[h1, x, b, c, m]
+ *   C[h3, m, x, y, z]  = sum_{h2, c}  W3[h2, c, h3, z] * X2[h2, y, x, c, m]
+ *
+ * every index has size D (fp32, D in {2, 4, 6}).  A: element offset of row (h, a) from
+ * offK1_dev[h*D + a], b / c at strides sa_b / sa_c, m over the bundle (dim_m, sa_m) with the innermost
+ * group stride-1 and a multiple of qamd_chain3_chunk().  W1 / W2 / W3 are the ORIGINAL site tensors,
+ * addressed in place with w*_strides = element strides of (bond in, carried index, bond out, new index).
+ * C (16-byte aligned): the innermost m group has stride D^3 and is followed by the contiguous block
+ * [x][y][z]; h3 at element offset offCo_dev[h3]; every offCo entry and every outer sc_m is a multiple
+ * of 4 elements.  scale_* / absmax_out: absmax slots as for the epilogue struct above; any may be NULL.
+ */
+typedef struct {
+  int32_t dtype, D, nm, flags;   /* flags: reserved, 0 */
+  int64_t dim_m[QAMD_MAX_GROUPS], sa_m[QAMD_MAX_GROUPS], sc_m[QAMD_MAX_GROUPS];
+  int64_t sa_b, sa_c;
+  int64_t w1_strides[4], w2_strides[4], w3_strides[4];
+} qamd_chain3_plan;
+/* m-chunk the fused triple works in for (dtype, D); 0 = combination not supported */
+int qamd_chain3_chunk(int32_t dtype, int32_t D);
+/* kernel instantiation the fused triple would run (matches rocprofv3's kernel names) */
+int qamd_chain3_describe(const qamd_chain3_plan* plan, char* buf, int32_t buflen);
+int qamd_contract_chain3(const qamd_chain3_plan* plan, const void* A, const void* W1, const void* W2, const void* W3,
+                         void* C, const void* offK1_dev, const void* offCo_dev, const void* scale_a,
+                         const void* scale_1, const void* scale_2, const void* scale_3, void* absmax_out,
+                         void* stream);
+
+/*
  * slots: n_tensors x QAMD_ABSMAX_SLOTS values (float for F32/C64, double
  * otherwise).  *out_dev (double, device) = sum_t log10(max over tensor t's slots),
  * tensors whose max is 0 are skipped.

@@ -759,6 +759,71 @@ extern "C" int qamd_contract_chain2(const qamd_chain2_plan* p, const void* A, co
 }
 
 // ---------------------------------------------------------------------------
+// fused triple of streaming contractions (chain3.hip)
+// ---------------------------------------------------------------------------
+extern "C" int qamd_chain3_chunk(int32_t dtype, int32_t D) { return qamd_chain3_supported(dtype, D) ? 16 : 0; }
+
+// waves per workgroup of the triple kernel (QAMD_C3_NW = 4 | 8 | 12; one workgroup per CU)
+static int chain3_waves() {
+  const char* e = getenv("QAMD_C3_NW");
+  const int nw = e ? atoi(e) : 8;
+  return (nw == 4 || nw == 12) ? nw : 8;
+}
+
+static int chain3_check(const qamd_chain3_plan* p, int64_t& chunks) {
+  if (!p || p->nm < 1 || p->nm > QAMD_MAX_GROUPS) return QAMD_EINVAL;
+  if (!qamd_chain3_chunk(p->dtype, p->D)) return QAMD_EUNSUPPORTED;
+  const int64_t D3 = (int64_t)p->D * p->D * p->D;
+  int64_t M = 1;
+  for (int i = 0; i < p->nm; ++i) {
+    if (p->dim_m[i] <= 0) return QAMD_EINVAL;
+    M *= p->dim_m[i];
+    if (M >= (1ll << 31)) return QAMD_EUNSUPPORTED;
+    if (i < p->nm - 1 && (p->sc_m[i] & 3)) return QAMD_EUNSUPPORTED;   // 16-byte stores
+  }
+  const int64_t inner = p->dim_m[p->nm - 1];
+  if (p->sa_m[p->nm - 1] != 1 || p->sc_m[p->nm - 1] != D3 || inner % 16) return QAMD_EUNSUPPORTED;
+  chunks = M / 16;
+  return QAMD_OK;
+}
+
+extern "C" int qamd_chain3_describe(const qamd_chain3_plan* p, char* buf, int32_t buflen) {
+  int64_t chunks = 0;
+  if (!buf || buflen <= 0) return QAMD_EINVAL;
+  int rc = chain3_check(p, chunks);
+  if (rc) return rc;
+  snprintf(buf, buflen, "chain3_kernel<%d, %d>", p->D, chain3_waves());
+  return QAMD_OK;
+}
+
+extern "C" int qamd_contract_chain3(const qamd_chain3_plan* p, const void* A, const void* W1, const void* W2,
+                                    const void* W3, void* C, const void* offK1_dev, const void* offCo_dev,
+                                    const void* scale_a, const void* scale_1, const void* scale_2, const void* scale_3,
+                                    void* absmax_out, void* stream) {
+  if (!p || !A || !W1 || !W2 || !W3 || !C || !offK1_dev || !offCo_dev) return QAMD_EINVAL;
+  int64_t chunks = 0;
+  int rc = chain3_check(p, chunks);
+  if (rc) return rc;
+  if ((uintptr_t)C & 15) return QAMD_EUNSUPPORTED;
+  Chain3Args a;
+  memset(&a, 0, sizeof(a));
+  a.nm = p->nm;
+  for (int i = 0; i < p->nm; ++i) { a.dim_m[i] = (uint32_t)p->dim_m[i]; a.sa_m[i] = p->sa_m[i]; a.sc_m[i] = p->sc_m[i]; }
+  a.sa_b = p->sa_b;
+  a.sa_c = p->sa_c;
+  a.chunks = (uint32_t)chunks;
+  // one workgroup per CU (the chunk state takes 83 of the CU's 160 KB of LDS at D = 6), persistent over its chunks;
+  // QAMD_C3_GRID overrides the workgroup count (experiments)
+  int grid = 256;
+  if (const char* e = getenv("QAMD_C3_GRID")) grid = std::max(1, atoi(e));
+  a.grid = (uint32_t)std::min<int64_t>(grid, chunks);
+  for (int i = 0; i < 4; ++i) { a.w1s[i] = p->w1_strides[i]; a.w2s[i] = p->w2_strides[i]; a.w3s[i] = p->w3_strides[i]; }
+  rc = qamd_chain3_launch(p->D, chain3_waves(), &a, A, W1, W2, W3, C, offK1_dev, offCo_dev, scale_a, scale_1, scale_2,
+                          scale_3, absmax_out, stream);
+  return rc == 0 ? QAMD_OK : (rc == -2 ? QAMD_EUNSUPPORTED : QAMD_ELAUNCH);
+}
+
+// ---------------------------------------------------------------------------
 // device-resident tree of small contractions (microtree.hip)
 // ---------------------------------------------------------------------------
 extern "C" int qamd_microtree_launch(int dtype, const qamd_micro_step* steps_dev, int nsteps, const int32_t* etab,

@@ -250,6 +250,47 @@ class HipDevice:
             e1.record()
             prof.append((c2, np.dtype(dtype), name, 1, e0, e1))
 
+    # ---- fused triple of streaming steps --------------------------------------------
+    def contract_chain3(self, c3, dtype, a, w1, w2, w3, c, ep=None):
+        """C = ((A . W1) . W2) . W3 in one pass (chain3.hip).  ``c3``: pairwise.Chain3Spec; the small tensors
+        are addressed in place; ``ep`` = (slots_a, slots_w1, slots_w2, slots_w3, slots_out) or None."""
+        key = ("chain3", c3, dtype_code(dtype), os.environ.get("QAMD_C3_NW"))
+        ent = self._pairs.get(key)
+        if ent is None:
+            pl = _lib.Chain3PlanStruct()
+            pl.dtype, pl.D, pl.nm = dtype_code(dtype), c3.D, len(c3.m)
+            for i, (d, sa, sc) in enumerate(c3.m):
+                pl.dim_m[i], pl.sa_m[i], pl.sc_m[i] = d, sa, sc
+            pl.sa_b, pl.sa_c = c3.sa_b, c3.sa_c
+            for i in range(4):
+                pl.w1_strides[i], pl.w2_strides[i], pl.w3_strides[i] = c3.w1s[i], c3.w2s[i], c3.w3s[i]
+            buf = C.create_string_buffer(128)
+            _lib.check(self.lib.qamd_chain3_describe(C.byref(pl), buf, 128), "qamd_chain3_describe")
+            k1 = self.torch.tensor(c3.off_k1, dtype=self.torch.int64, device=self.tdev)
+            co = self.torch.tensor(c3.off_co, dtype=self.torch.int64, device=self.tdev)
+            ent = (pl, k1, co, buf.value.decode())
+            self._pairs[key] = ent
+        pl, k1, co, name = ent
+        ptr = lambda t: (t.data_ptr() if t is not None else None)
+        sa = s1 = s2 = s3 = so = None
+        if ep is not None:
+            sa, s1, s2, s3, so = (ptr(t) for t in ep)
+        prof = self.profile
+        if prof is not None:
+            e0 = self.torch.cuda.Event(enable_timing=True)
+            e1 = self.torch.cuda.Event(enable_timing=True)
+            e0.record()
+        _lib.check(
+            self.lib.qamd_contract_chain3(
+                C.byref(pl), a.data_ptr(), w1.data_ptr(), w2.data_ptr(), w3.data_ptr(), c.data_ptr(), k1.data_ptr(),
+                co.data_ptr(), sa, s1, s2, s3, so, self.stream(),
+            ),
+            "qamd_contract_chain3",
+        )
+        if prof is not None:
+            e1.record()
+            prof.append((c3, np.dtype(dtype), name, 1, e0, e1))
+
     # ---- layout / elementwise -----------------------------------------------
     def permute(self, dst, src, shape, strides, offset, dtype):
         nd = len(shape)

@@ -21,7 +21,7 @@ import os
 
 from .array import Array, asarray, _coerce_dtype
 from .ops import _einsum_single, run_pair_step
-from .pairwise import plan_chain2, plan_pair, prod
+from .pairwise import plan_chain2, plan_chain3, plan_pair, prod
 from .tree import ContractionTree
 
 
@@ -129,25 +129,42 @@ class TreeExecutor:
             return
         plan, info = self.plan, self.info
         new_plan, new_info = [], []
+        isz = self.dtype.itemsize
+        use3 = os.environ.get("QAMD_CHAIN3", "1") != "0"
+
+        def big_small(entry):
+            """(big operand id, small operand id, result id, step) of a plain big-x-small GETT step, else None"""
+            if entry[0] != "pair":
+                return None
+            _, a, b, r, st = entry
+            if st.kind != "gett" or any(st.pre) or st.spec.b:
+                return None
+            return ((b, a) if st.swapped else (a, b)) + (r, st)
+
         i = 0
         while i < len(plan):
             fused = None
-            if i + 1 < len(plan) and plan[i][0] == "pair" and plan[i + 1][0] == "pair":
-                _, a, b, r1, st1 = plan[i]
-                _, a2, b2, r2, st2 = plan[i + 1]
-                ok = st1.kind == "gett" and st2.kind == "gett" and not any(st1.pre) and not any(st2.pre)
-                ok = ok and self.dep[r1] == self.dep[r2]
-                if ok:
-                    A_id, W1_id = (b, a) if st1.swapped else (a, b)
-                    X_id, W2_id = (b2, a2) if st2.swapped else (a2, b2)
-                    if X_id == r1 and not st1.spec.b and not st2.spec.b:
-                        c2 = plan_chain2(self.layout[A_id], self.layout[W1_id], st1.out_inds, self.layout[W2_id],
-                                         st2.out_inds, size, self.dtype.name)
-                        if c2 is not None:
-                            fused = ("chain2", A_id, W1_id, W2_id, r2, c2)
+            s1 = big_small(plan[i])
+            s2 = big_small(plan[i + 1]) if i + 1 < len(plan) else None
+            s3 = big_small(plan[i + 2]) if i + 2 < len(plan) else None
+            if use3 and s1 and s2 and s3 and s2[0] == s1[2] and s3[0] == s2[2] \
+                    and self.dep[s1[2]] == self.dep[s2[2]] == self.dep[s3[2]]:
+                # three interior sites in one pass: the chunk state is exchanged through LDS (chain3.hip)
+                c3 = plan_chain3(self.layout[s1[0]], self.layout[s1[1]], s1[3].out_inds, self.layout[s2[1]],
+                                 s2[3].out_inds, self.layout[s3[1]], s3[3].out_inds, size, self.dtype.name)
+                if c3 is not None:
+                    new_plan.append(("chain3", s1[0], s1[1], s2[1], s3[1], s3[2], c3))
+                    new_info.append(StepInfo("chain3", c3.mults, isz * (c3.a_size + c3.c_size + 3 * c3.D**4),
+                                             (1, c3.M * c3.D**2, c3.D**2, c3.D**2), self.dep[s3[2]]))
+                    i += 3
+                    continue
+            if s1 and s2 and s2[0] == s1[2] and self.dep[s1[2]] == self.dep[s2[2]]:
+                c2 = plan_chain2(self.layout[s1[0]], self.layout[s1[1]], s1[3].out_inds, self.layout[s2[1]],
+                                 s2[3].out_inds, size, self.dtype.name)
+                if c2 is not None:
+                    fused = ("chain2", s1[0], s1[1], s2[1], s2[2], c2)
             if fused is not None:
                 c2 = fused[5]
-                isz = self.dtype.itemsize
                 new_plan.append(fused)
                 new_info.append(StepInfo("chain2", c2.mults, isz * (c2.a_size + c2.c_size + 2 * c2.D**4),
                                          (1, c2.M, c2.D**2, c2.D**2), self.dep[fused[4]]))
@@ -213,6 +230,8 @@ class TreeExecutor:
                 return (entry[1],)
             if entry[0] == "chain2":
                 return (entry[1], entry[2], entry[3])
+            if entry[0] == "chain3":
+                return (entry[1], entry[2], entry[3], entry[4])
             return (entry[1], entry[2])
 
         for entry in self.plan:
@@ -253,6 +272,26 @@ class TreeExecutor:
                     if independent and cache is not None:
                         cache[res] = x
                 ids = (a, w1, w2)
+            elif entry[0] == "chain3":
+                _, a, w1, w2, w3, res, c3 = entry
+                independent = not self.dep[res]
+                if independent and cache is not None and res in cache:
+                    live[res] = cache[res]
+                elif only_independent and not independent:
+                    continue
+                else:
+                    x = Array.empty(c3.out_shape, self.dtype, dev)
+                    ep = None
+                    if exponent is not None:
+                        ep = tuple(dev.slots_row(slots, s_) if s_ in has_scale else None for s_ in (a, w1, w2, w3))
+                        ep = ep + (dev.slots_row(slots, res),)
+                        has_scale.add(res)
+                    dev.contract_chain3(c3, self.dtype, live[a]._buf, live[w1]._buf, live[w2]._buf, live[w3]._buf,
+                                        x._buf, ep)
+                    live[res] = x
+                    if independent and cache is not None:
+                        cache[res] = x
+                ids = (a, w1, w2, w3)
             else:
                 _, a, b, res, step = entry
                 independent = not self.dep[res]

@@ -72,6 +72,46 @@ def test_fast_tiles(hip, dtype):
     assert any(s > 1 for s in splits), splits
 
 
+@pytest.mark.parametrize("Lx,Ly,D", [(6, 6, 4), (8, 8, 2), (5, 8, 4), (3, 8, 6), (3, 9, 6)])
+def test_fused_triples(hip, Lx, Ly, D):
+    """Three adjacent interior site absorptions in ONE launch (chain3 kernel, chunk state exchanged through
+    LDS): same value as the fp64 oracle, with and without exponent stripping, for every workgroup width, and
+    the same as the executor with triples switched off."""
+    import os
+
+    from oracle import np_oracle as orc
+    import quimb_amd as qa
+
+    arrays, inputs = orc.tn2d_rand(Lx, Ly, D, seed=21, dtype="float32")
+    size = {ix: D for t in inputs for ix in t}
+    tree = qa.ContractionTree(inputs, (), size, path=qa.sweep_path_2d(Lx, Ly))
+    wm, we = orc.oracle_array_contract([a.astype(np.float64) for a in arrays], inputs, (), path=tree.get_path(),
+                                       strip_exponent=True)
+    want = wm.item() * 10.0**we
+    ex = qa.TreeExecutor(tree, "float32")
+    assert any(e[0] == "chain3" for e in ex.plan)
+    for nw in ("8", "4", "12"):
+        os.environ["QAMD_C3_NW"] = nw
+        try:
+            hip.profile = []
+            m, e = ex(arrays, strip_exponent=True)
+            names = {n for (_, _, n, _, _, _) in hip.profile}
+            hip.profile = None
+            assert f"chain3_kernel<{D}, {nw}>" in names, names
+            assert m.to_numpy().item() * 10.0**e == pytest.approx(want, rel=1e-6)
+            assert ex(arrays).to_numpy().item() == pytest.approx(want, rel=1e-6)
+        finally:
+            del os.environ["QAMD_C3_NW"]
+            hip.profile = None
+    os.environ["QAMD_CHAIN3"] = "0"
+    try:
+        ex2 = qa.TreeExecutor(tree, "float32")
+    finally:
+        del os.environ["QAMD_CHAIN3"]
+    assert not any(e[0] == "chain3" for e in ex2.plan) and ex2.flops() == ex.flops()
+    assert ex2(arrays).to_numpy().item() == pytest.approx(want, rel=1e-6)
+
+
 @pytest.mark.parametrize("Lx,Ly,D,dtype", [(4, 8, 2, "float64"), (4, 8, 2, "float32"), (3, 6, 4, "float32"),
                                            (4, 10, 4, "float32"), (5, 12, 2, "float32"),
                                            (3, 5, 4, "float64"), (3, 8, 6, "float32"), (3, 7, 6, "float64")])
