@@ -190,9 +190,13 @@ def main():
         # ---- dominant kernel from HIP-event timings over the timed region ------
         agg = {}
         for spec, dt_, name, sk, e0, e1 in prof:
-            if hasattr(spec, "off_k1"):  # fused pair of steps (Chain2Spec)
+            if hasattr(spec, "off_k1") and hasattr(spec, "K1"):  # fused pair of steps (Chain2Spec)
                 shape = {"fused_steps": 2, "M": spec.M, "D": spec.D, "K": spec.K1, "N": spec.NO * spec.D}
                 nbytes = 4 * (spec.a_size + spec.c_size + spec.K1 * spec.D**2 + spec.D**3 * spec.NO)
+                nflops = 2 * spec.mults
+            elif hasattr(spec, "off_k1"):  # fused triple of steps (Chain3Spec)
+                shape = {"fused_steps": 3, "M": spec.a_size // spec.D**4, "D": spec.D, "K": spec.D**2, "N": spec.D**2}
+                nbytes = 4 * (spec.a_size + spec.c_size + 3 * spec.D**4)
                 nflops = 2 * spec.mults
             else:
                 shape = {"B": spec.B, "M": spec.M, "N": spec.N, "K": spec.K}
@@ -202,6 +206,10 @@ def main():
             a = agg.setdefault(key, [0.0, 0, shape, nbytes, nflops])
             a[0] += e0.elapsed_time(e1) * 1e-3
             a[1] += 1
+        if os.environ.get("QAMD_BENCH_KERNELS"):   # per-kernel table of the timed region (stderr)
+            for (name, shp), (tsum, cnt, _, nb, nf) in sorted(agg.items(), key=lambda kv: -kv[1][0]):
+                print(f"  {tsum / args.steps * 1e3:8.3f} ms/step  {cnt // args.steps:4d} x {tsum / cnt * 1e3:7.3f} ms  "
+                      f"{nb / (tsum / cnt) / 1e9:7.0f} GB/s {nf / (tsum / cnt) / 1e12:6.1f} TF  {name}  {dict(shp)}", file=sys.stderr)
         roof = None
         if agg:
             key, (tsum, cnt, shape, bytes_launch, flops_launch) = max(agg.items(), key=lambda kv: kv[1][0])

@@ -128,7 +128,8 @@ def check(rc, what):
 
 
 def library_path():
-    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "libquimb_amd.so")
+    # QAMD_LIBRARY: an experiment build of the SAME library (e.g. -DQAMD_CHAIN2_TIMING), see scripts/README.md
+    return os.environ.get("QAMD_LIBRARY") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libquimb_amd.so")
 
 
 _LIB = None

@@ -663,6 +663,18 @@ static bool chain2_uses_registers(const qamd_chain2_plan* p, const void* C) {
   return qamd_chain2r_supported(p->dtype, p->D) && qamd_chain2_chunk(p->dtype, p->D) == 16;
 }
 
+// the 4x4x1 multi-block variant (chain2q.hip): fp32, D in {4, 6}, innermost m group a whole number of 64-m chunks,
+// and enough chunks to give every wave of the persistent grid a few (QAMD_CHAIN2Q=0 off, =2 no size threshold)
+static bool chain2_uses_quad(const qamd_chain2_plan* p, const void* C) {
+  const char* e = getenv("QAMD_CHAIN2Q");
+  if (e && e[0] == '0') return false;
+  if (!chain2_uses_registers(p, C) || !qamd_chain2q_supported(p->dtype, p->D)) return false;
+  if (p->nm < 1 || p->dim_m[p->nm - 1] % 64) return false;
+  int64_t M = 1;
+  for (int i = 0; i < p->nm; ++i) M *= p->dim_m[i];
+  return (e && e[0] == '2') || M / 64 >= 4096;
+}
+
 // chunks per workgroup of the fused-pair kernels: the largest divisor of the innermost m group's chunk count
 // that still leaves ~12 workgroups per CU; ``sc``: the opt-in super-chunk variant (QAMD_C2R_SC=1: pairs of
 // adjacent chunks per wave, whole-line loads -- measured equal to the default, 0.762 vs 0.764 ms per pair)
@@ -699,6 +711,11 @@ extern "C" int qamd_chain2_describe(const qamd_chain2_plan* p, char* buf, int32_
   if (!ch) return QAMD_EUNSUPPORTED;
   const bool variant = (p->flags & (QAMD_CHAIN2_K1_SINGLE | QAMD_CHAIN2_NO_N2OUT)) != 0;
   if (variant && !chain2_uses_registers(p, nullptr)) return QAMD_EUNSUPPORTED;
+  if (chain2_uses_quad(p, nullptr)) {
+    snprintf(buf, buflen, "chain2q_kernel<%d, %d, %d>", p->D, (p->flags & QAMD_CHAIN2_K1_SINGLE) ? 1 : 2,
+             (p->flags & QAMD_CHAIN2_NO_N2OUT) ? 0 : 1);
+    return QAMD_OK;
+  }
   if (chain2_uses_registers(p, nullptr))
   {
     uint32_t chunks = 0, cpb = 0;
@@ -749,6 +766,13 @@ extern "C" int qamd_contract_chain2(const qamd_chain2_plan* p, const void* A, co
     const int64_t N2 = (no_n2out ? 1 : p->D) * (int64_t)p->D;
     a.w1s[0] = k1_single ? DD : (int64_t)p->D * DD; a.w1s[1] = DD; a.w1s[2] = p->D; a.w1s[3] = 1;
     a.w2s[0] = (int64_t)p->D * N2; a.w2s[1] = N2; a.w2s[2] = p->D; a.w2s[3] = 1;
+  }
+  if (chain2_uses_quad(p, C)) {
+    a.chunks = (uint32_t)(M / 64);
+    a.chunks_per_block = 0;
+    a.grid = std::min<uint32_t>((a.chunks + 3) / 4, 256);   // persistent: one workgroup (4 waves, 1 per SIMD) per CU
+    return qamd_chain2q_launch(p->D, k1_single, no_n2out, &a, A, W1p, W2p, C, offK1_dev, offCo_dev, scale_a, scale_1,
+                               scale_2, absmax_out, stream);
   }
   if (chain2_uses_registers(p, C))
     return qamd_chain2r_launch(p->D, k1_single, no_n2out, &a, A, W1p, W2p, C, offK1_dev, offCo_dev, scale_a, scale_1,

@@ -7,7 +7,7 @@ import torch
 import quimb_amd as qa
 from quimb_amd.pairwise import plan_chain2
 dev = qa.default_device()
-D, nm = 6, 8
+D, nm = int(os.environ.get("QAMD_C2_D", "6")), int(os.environ.get("QAMD_C2_NM", "8"))
 variant = os.environ.get("QAMD_C2_VARIANT", "interior")   # interior | start (k1 = u only) | end (n2 = one index)
 ms = tuple(f"m{i}" for i in range(nm))
 if variant == "start":
@@ -34,6 +34,30 @@ w1p, w2p = W1, W2   # the device addresses the small tensors in place (or packs 
 out = qa.Array.empty(c2.out_shape, "float32", dev)
 def run():
     dev.contract_chain2(c2, "float32", A._buf, w1p._buf, w2p._buf, out._buf)
+run()
+torch.cuda.synchronize()
+print("kernel:", [e[3] for k, e in dev._pairs.items() if k[0] == "chain2"])
+if os.environ.get("QAMD_C2_CHECK", "1") != "0":
+    # whole-tensor check against torch (fp32 library GEMMs) -- every element of C
+    M = D ** nm
+    At = A._buf[: A.size].view((D,) * (len(la) - nm) + (M,))
+    w1, w2 = W1._buf[: W1.size].view((D,) * len(l1)), W2._buf[: W2.size].view((D,) * len(l2))
+    if variant == "start":
+        X = torch.einsum("uvm,uyx->vymx", At, w1)
+    else:
+        X = torch.einsum("huvm,hyux->vymx", At, w1)
+    if variant == "end":
+        want = torch.einsum("vymx,yvz->mxz", X, w2)
+        got = out._buf[: out.size].view(M, D, D)
+    else:
+        want = torch.einsum("vymx,ywvz->wmxz", X, w2)           # [yy, m, x, xx]
+        got = out._buf[: out.size].view(D, D, M // D, D, D).permute(1, 0, 2, 3, 4).reshape(D, M, D, D)
+    del X
+    err = ((got - want).abs().max() / want.abs().max()).item()
+    bad = int(((got - want).abs() > 1e-4 * want.abs().max()).sum().item())
+    print(f"check: max |diff| / max |C| = {err:.2e}; elements off by > 1e-4: {bad}; NaN: {int(torch.isnan(got).sum().item())}")
+    assert err < 1e-5 and bad == 0
+    del want
 for _ in range(3): run()
 torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -63,7 +87,8 @@ if os.environ.get("QAMD_TIMING"):
     torch.cuda.synchronize()
     t = tb.cpu().numpy().reshape(-1, 8)
     t = t[t.sum(1) > 0]
-    names = ["s1 t0", "copyout", "ld issue", "s2 t0", "s1 t1", "s2 t1", "s1 t2", "s2 t2"]
+    names = (["bookkeep", "s1 side", "s1 rest", "stage 2", "drain", "-", "-", "-"] if "chain2q" in str([e[3] for e in dev._pairs.values() if len(e) > 3])
+             else ["s1 t0", "copyout", "ld issue", "s2 t0", "s1 t1", "s2 t1", "s1 t2", "s2 t2"])
     tot = t.sum(1).mean()
     print(f"waves {len(t)}  mean total cycles/wave {tot:.0f}")
     for i, n in enumerate(names):
