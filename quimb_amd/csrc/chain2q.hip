@@ -220,9 +220,9 @@ __global__ __launch_bounds__(256, 1) void chain2q_kernel(const Chain2Args p, con
   };
   // copy-out of group g (tile at ``tile``, chunk C offset cb) in CPG + 1 steps: step s stores what step s - 1 read
   q_vec4 stage[2];
-  auto side_copy = [&](int g, int s, uint32_t tile, int64_t cb) {
+  auto side_copy = [&](int g, int s, uint32_t tile, int64_t cb, bool live) {
     constexpr int IPN = CPG / GN;                // 1-KB pieces per `no`
-    if (s > 0) {
+    if (s > 0 && live) {
       const int q = s - 1, nol = q / IPN, it = q - nol * IPN;
       const q_vec4 val = stage[q & 1];
       asm volatile("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(vmax) : "v"(val[0]), "v"(val[1]));
@@ -249,7 +249,7 @@ __global__ __launch_bounds__(256, 1) void chain2q_kernel(const Chain2Args p, con
 #pragma unroll
   for (int gi = 0; gi < RGRP; ++gi) load_group(abase, gi, gi * D);
 
-  bool have_prev = false;                        // a previous chunk's last pair / last group is still pending
+  bool have_prev = false;                        // a previous chunk's last pair / last group is pending (uniform)
   uint32_t tprev = 0;                            // ... in this tile
 
   // stage 1 of one row group; SIDE: thread the previous chunk's leftovers (one step per row) through it
@@ -268,7 +268,7 @@ __global__ __launch_bounds__(256, 1) void chain2q_kernel(const Chain2Args p, con
       if (side) {
         const int op = gi * D + uu;
         if (op < NWR) side_write(LASTSET, NP - 1, op, tprev);
-        else if (op < NWR + NCP) side_copy(NG - 1, op - NWR, tprev, cprev);
+        else if (op < NWR + NCP) side_copy(NG - 1, op - NWR, tprev, cprev, have_prev);
       }
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -296,13 +296,9 @@ __global__ __launch_bounds__(256, 1) void chain2q_kernel(const Chain2Args p, con
 
     QAMD_QSTAMP(0);   // chunk bookkeeping
     // ================= stage 1: X[v] = W1^T . A[:, v]  (+ the previous chunk's leftovers) =====================
-    if (have_prev) {
+    // (on the first chunk the leftovers are dummies: the accumulators hold zeros, the stores are skipped)
 #pragma unroll
-      for (int gi = 0; gi < SGRP; ++gi) stage1_group(gi, true);
-    } else {
-#pragma unroll
-      for (int gi = 0; gi < SGRP; ++gi) stage1_group(gi, false);
-    }
+    for (int gi = 0; gi < SGRP; ++gi) stage1_group(gi, true);
     QAMD_QSTAMP(1);   // stage 1, row groups carrying the leftovers
 #pragma unroll
     for (int gi = SGRP; gi < NGRP; ++gi) stage1_group(gi, false);
@@ -332,7 +328,7 @@ __global__ __launch_bounds__(256, 1) void chain2q_kernel(const Chain2Args p, con
           // side work of this slot: the previous pair's LDS writes first, then the previous group's copy-out
           if (xp > 0) {
             if (k2 < NWR) side_write(pset, xp - 1, k2, tcur);
-            else if (xp == 1 && g > 0 && k2 - NWR < NCP) side_copy(g - 1, k2 - NWR, tcur ^ (uint32_t)TILE, cbase);
+            else if (xp == 1 && g > 0 && k2 - NWR < NCP) side_copy(g - 1, k2 - NWR, tcur ^ (uint32_t)TILE, cbase, true);
           } else if (g > 0) {
             if (k2 < NWR) side_write(pset, NP - 1, k2, tcur ^ (uint32_t)TILE);
           }
@@ -357,7 +353,7 @@ __global__ __launch_bounds__(256, 1) void chain2q_kernel(const Chain2Args p, con
 #pragma unroll
   for (int w = 0; w < NWR; ++w) side_write(LASTSET, NP - 1, w, tprev);
 #pragma unroll
-  for (int s = 0; s < NCP; ++s) side_copy(NG - 1, s, tprev, cprev);
+  for (int s = 0; s < NCP; ++s) side_copy(NG - 1, s, tprev, cprev, true);
 
 #ifdef QAMD_CHAIN2_TIMING
   QAMD_QSTAMP(4);   // drain

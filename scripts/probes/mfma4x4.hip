@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <cstdint>
 #include <vector>
+#include <cstdlib>
 
 typedef __attribute__((ext_vector_type(4))) float acc_t;
 
@@ -22,7 +23,7 @@ template <int NACC, int MODE>
 __global__ __launch_bounds__(256) void rate_kernel(float* out, int iters, const float* src) {
   acc_t acc[NACC];
   for (int i = 0; i < NACC; ++i) acc[i] = acc_t{0, 0, 0, 0};
-  float a = threadIdx.x * 1e-3f, b = 1.0f + threadIdx.x * 1e-4f;
+  float a = src[threadIdx.x + 4096 + 64 * (blockIdx.x & 7)], b = src[threadIdx.x + 8192 + 64 * (blockIdx.x & 15)];   // random mantissas
   extern __shared__ float sm[];
   sm[threadIdx.x] = a;
   __syncthreads();
@@ -53,11 +54,12 @@ void run_rate(const char* name, int wgs_per_cu, float* out, const float* src) {
   hipEvent_t e0, e1;
   hipEventCreate(&e0); hipEventCreate(&e1);
   dim3 grid(256 * wgs_per_cu), block(256);
-  hipLaunchKernelGGL((rate_kernel<NACC, MODE>), grid, block, 1024, 0, out, iters, src);
+  const int REP = 40;
+  for (int r = 0; r < REP; ++r) hipLaunchKernelGGL((rate_kernel<NACC, MODE>), grid, block, 1024, 0, out, iters, src);
   hipEventRecord(e0);
-  hipLaunchKernelGGL((rate_kernel<NACC, MODE>), grid, block, 1024, 0, out, iters, src);
+  for (int r = 0; r < REP; ++r) hipLaunchKernelGGL((rate_kernel<NACC, MODE>), grid, block, 1024, 0, out, iters, src);
   hipEventRecord(e1); hipEventSynchronize(e1);
-  float ms; hipEventElapsedTime(&ms, e0, e1);
+  float ms; hipEventElapsedTime(&ms, e0, e1); ms /= REP;
   const double n_mfma = (double)iters * NACC;                 // per wave
   const double flop_per = (MODE == 1) ? 2048.0 : 512.0;
   const double tf = n_mfma * flop_per * 4 * 256 * wgs_per_cu / (ms * 1e-3) / 1e12;
@@ -95,8 +97,14 @@ int main() {
   check("4x4x1", sem_kernel<4, 15>, 4, 15);
 
   float *out, *src;
-  hipMalloc(&out, 4096); hipMalloc(&src, 16384);
-  hipMemset(src, 0, 16384);
+  hipMalloc(&out, 4096); hipMalloc(&src, 65536);
+  {
+    std::vector<float> hs(16384);
+    uint32_t st = 12345;
+    for (auto& x : hs) { st = st * 1664525u + 1013904223u; x = ((st >> 8) * (1.0f / 16777216.0f) - 0.5f) * 1e-3f; }
+    if (getenv("ZERO")) for (auto& x : hs) x = 0.f;
+    hipMemcpy(src, hs.data(), 65536, hipMemcpyHostToDevice);
+  }
   run_rate<9, 0>("4x4x1_16b cbsz=4, 9 independent acc", 1, out, src);
   run_rate<9, 0>("4x4x1_16b cbsz=4, 9 independent acc", 2, out, src);
   run_rate<36, 0>("4x4x1_16b cbsz=4, 36 independent acc", 1, out, src);
