@@ -226,12 +226,17 @@ def main():
             roof["kernel"] = cfg  # instantiation name from qamd_pair_describe
             # HBM traffic of this kernel from the committed rocprofv3 PMC passes (profiles/):
             # FETCH_SIZE x 2 (gfx950 correction, MI355X_MICROARCH.md section HBM) + WRITE_SIZE, per launch
-            try:
-                tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
-                if tj.get("kernel") == cfg and tj.get("shape") == shape:
+            import glob
+
+            for tpath in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")), reverse=True):
+                try:
+                    tj = json.load(open(tpath))
+                except Exception:
+                    continue
+                if tj.get("kernel") == cfg and tj.get("shape") == shape:   # newest round that profiled THIS kernel
                     roof["traffic"] = tj["hbm_bytes_per_launch"]
-            except Exception:
-                pass
+                    roof["traffic_source"] = "profiles/" + os.path.basename(tpath)
+                    break
             roof["shape"] = shape
             roof["arithmetic_intensity_flop_per_byte"] = ai
             roof["tflops"] = flops_launch / avg / 1e12

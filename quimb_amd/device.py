@@ -86,6 +86,7 @@ class HipDevice:
         }
         self._pairs = {}
         self._ws = None
+        self._ws_retired = []   # outgrown split-K workspaces, kept alive for captured graphs (see _workspace)
         self._scratch = torch.zeros(4, dtype=torch.float64, device=self.tdev)
         #: set to a list to collect (spec, dtype, tile_cfg, split_k, start_event, end_event)
         #: per qamd_contract_pair launch (HIP events on the launch stream)
@@ -123,7 +124,14 @@ class HipDevice:
         if nbytes <= 0:
             return None, 0
         if self._ws is None or self._ws.numel() < nbytes:
-            self._ws = self.torch.empty(int(nbytes), dtype=self.torch.uint8, device=self.tdev)
+            # captured hipGraphs (TreeExecutor slice graphs, GraphedContraction, TNLinearOperator(graph=True)) bake
+            # the raw pointer of the workspace they were recorded with into their split-K nodes: a workspace that
+            # is outgrown is RETIRED, never freed, so that replaying such a graph later still writes into memory
+            # nothing else owns.  Sizes grow geometrically, so the retired list stays short.
+            if self._ws is not None:
+                self._ws_retired.append(self._ws)
+            grow = max(int(nbytes), 2 * (self._ws.numel() if self._ws is not None else 0))
+            self._ws = self.torch.empty(grow, dtype=self.torch.uint8, device=self.tdev)
         return self._ws.data_ptr(), self._ws.numel()
 
     # ---- pairwise contraction ---------------------------------------------

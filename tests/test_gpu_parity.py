@@ -52,10 +52,10 @@ def test_sweep_3x8_D6_streams(hip):
     kinds = {name.split("<")[0] for (_, _, name, _, _, _) in hip.profile}
     hip.profile = None
     assert kinds & {"sweep_kernel", "stream_kernel"}  # at least one step ran on a streaming kernel
-    assert m.to_numpy().item() * 10.0**e == pytest.approx(wm.item() * 10.0**we, rel=5e-6)
+    assert m.to_numpy().item() * 10.0**e == pytest.approx(wm.item() * 10.0**we, rel=1e-6)
     # and without exponent stripping
     out = qa.TreeExecutor(tree, "float32")(arrays)
-    assert out.to_numpy().item() == pytest.approx(wm.item() * 10.0**we, rel=5e-6)
+    assert out.to_numpy().item() == pytest.approx(wm.item() * 10.0**we, rel=1e-6)
 
 
 @pytest.mark.parametrize("dtype", ["float32", "float64"])
@@ -88,7 +88,11 @@ def test_fused_triples(hip, Lx, Ly, D):
     wm, we = orc.oracle_array_contract([a.astype(np.float64) for a in arrays], inputs, (), path=tree.get_path(),
                                        strip_exponent=True)
     want = wm.item() * 10.0**we
-    ex = qa.TreeExecutor(tree, "float32")
+    os.environ["QAMD_CHAIN3"] = "1"      # opt-in (the fused pairs of chain2q.hip are faster per site)
+    try:
+        ex = qa.TreeExecutor(tree, "float32")
+    finally:
+        del os.environ["QAMD_CHAIN3"]
     assert any(e[0] == "chain3" for e in ex.plan)
     for nw in ("8", "4", "12"):
         os.environ["QAMD_C3_NW"] = nw
@@ -103,11 +107,7 @@ def test_fused_triples(hip, Lx, Ly, D):
         finally:
             del os.environ["QAMD_C3_NW"]
             hip.profile = None
-    os.environ["QAMD_CHAIN3"] = "0"
-    try:
-        ex2 = qa.TreeExecutor(tree, "float32")
-    finally:
-        del os.environ["QAMD_CHAIN3"]
+    ex2 = qa.TreeExecutor(tree, "float32")   # default: no triples
     assert not any(e[0] == "chain3" for e in ex2.plan) and ex2.flops() == ex.flops()
     assert ex2(arrays).to_numpy().item() == pytest.approx(want, rel=1e-6)
 
@@ -139,14 +139,14 @@ def test_fused_pairs(hip, Lx, Ly, D, dtype):
     assert any(e[0] == "chain2" for e in ex.plan)
     exr = qa.TreeExecutor(tree, dtype)   # default: small operands regrouped where that is a clear win
     assert exr.flops() <= ex.flops()
-    assert exr(arrays).to_numpy().item() == pytest.approx(want, rel=5e-6 if dtype == "float32" else 1e-11)
+    assert exr(arrays).to_numpy().item() == pytest.approx(want, rel=1e-6 if dtype == "float32" else 1e-11)
     if dtype == "float32":   # the opt-in super-chunk variant (whole-line loads + lane swaps) must agree as well
         os.environ["QAMD_C2R_SC"] = "1"
         try:
             msc, esc = ex(arrays, strip_exponent=True)
         finally:
             del os.environ["QAMD_C2R_SC"]
-        assert msc.to_numpy().item() * 10.0**esc == pytest.approx(want, rel=5e-6)
+        assert msc.to_numpy().item() * 10.0**esc == pytest.approx(want, rel=1e-6)
     if dtype == "float32":   # row-start and row-end pairs are fused too (register kernel only)
         assert any(e[0] == "chain2" and e[5].k1_single for e in ex.plan)
         assert any(e[0] == "chain2" and e[5].no_n2out for e in ex.plan)
@@ -167,8 +167,8 @@ def test_fused_pairs(hip, Lx, Ly, D, dtype):
             del os.environ["QAMD_CHAIN2R"]
             hip.profile = None
         assert "chain2_kernel" in names1
-        assert v1 == pytest.approx(want, rel=5e-6)
-    rel = 5e-6 if dtype == "float32" else 1e-11
+        assert v1 == pytest.approx(want, rel=1e-6)
+    rel = 1e-6 if dtype == "float32" else 1e-11
     assert m.to_numpy().item() * 10.0**e == pytest.approx(want, rel=rel)
     assert ex(arrays).to_numpy().item() == pytest.approx(want, rel=rel)
     os.environ["QAMD_CHAIN2"] = "0"
@@ -177,6 +177,47 @@ def test_fused_pairs(hip, Lx, Ly, D, dtype):
     finally:
         del os.environ["QAMD_CHAIN2"]
     assert ex0(arrays).to_numpy().item() == pytest.approx(want, rel=rel)
+
+
+@pytest.mark.parametrize("Lx,Ly,D", [(3, 8, 4), (4, 8, 4), (3, 10, 6)])   # even widths: every row has a start and an end pair
+def test_fused_pairs_quad(hip, Lx, Ly, D):
+    """The fused pair on v_mfma_f32_4x4x1_16b (chain2q.hip: 64-m chunks, lanes = m): interior, row-start and
+    row-end shapes against the fp64 oracle at north_star's 1e-6, with and without exponent stripping, and
+    bit-for-bit the plan the 16x16x4 kernel (chain2r.hip) runs."""
+    import os
+
+    from oracle import np_oracle as orc
+    import quimb_amd as qa
+
+    arrays, inputs = orc.tn2d_rand(Lx, Ly, D, seed=17, dtype="float32")
+    size = {ix: D for t in inputs for ix in t}
+    tree = qa.ContractionTree(inputs, (), size, path=qa.sweep_path_2d(Lx, Ly))
+    wm, we = orc.oracle_array_contract([a.astype(np.float64) for a in arrays], inputs, (), path=tree.get_path(),
+                                       strip_exponent=True)
+    want = wm.item() * 10.0**we
+    os.environ["QAMD_CHAIN2Q"] = "2"     # no size threshold: the small test networks take the kernel too
+    os.environ["QAMD_REGROUP"] = "0"
+    try:
+        ex = qa.TreeExecutor(tree, "float32")
+        hip.profile = []
+        m, e = ex(arrays, strip_exponent=True)
+        names = {n for (_, _, n, _, _, _) in hip.profile}
+        hip.profile = None
+        plain = ex(arrays).to_numpy().item()
+    finally:
+        del os.environ["QAMD_CHAIN2Q"]
+        del os.environ["QAMD_REGROUP"]
+        hip.profile = None
+    for variant in (f"chain2q_kernel<{D}, 2, 1>", f"chain2q_kernel<{D}, 1, 1>", f"chain2q_kernel<{D}, 2, 0>"):
+        assert variant in names, names
+    assert m.to_numpy().item() * 10.0**e == pytest.approx(want, rel=1e-6)
+    assert plain == pytest.approx(want, rel=1e-6)
+    os.environ["QAMD_CHAIN2Q"] = "0"
+    try:
+        mr, er = qa.TreeExecutor(tree, "float32")(arrays, strip_exponent=True)
+    finally:
+        del os.environ["QAMD_CHAIN2Q"]
+    assert mr.to_numpy().item() * 10.0**er == pytest.approx(want, rel=1e-6)
 
 
 @pytest.mark.parametrize("dtype", ["complex64", "complex128"])
@@ -345,7 +386,7 @@ def test_peps_6x6_D6_fp32_vs_fp64_oracle(hip):
     m, e = qa.TreeExecutor(tree, "float32")(arrays, strip_exponent=True)
     got = m.to_numpy().item() * 10.0**e
     ref = want[0].item() * 10.0 ** want[1]
-    assert got == pytest.approx(ref, rel=5e-6)
+    assert got == pytest.approx(ref, rel=1e-6)
 
 
 def test_full_size_10x10_D6_properties(hip):

@@ -162,7 +162,11 @@ def test_fused_triples_in_sweeps(emu, Lx, Ly, D):
     size = {ix: D for t in inputs for ix in t}
     tree = qa.ContractionTree(inputs, (), size, path=qa.sweep_path_2d(Lx, Ly))
     want = orc.oracle_array_contract([a.astype(np.float64) for a in arrays], inputs, (), path=tree.get_path())
-    ex = qa.TreeExecutor(tree, "float32")
+    os.environ["QAMD_CHAIN3"] = "1"      # opt-in
+    try:
+        ex = qa.TreeExecutor(tree, "float32")
+    finally:
+        del os.environ["QAMD_CHAIN3"]
     n3 = sum(1 for e in ex.plan if e[0] == "chain3")
     assert n3 >= 1, [e[0] for e in ex.plan]
     assert ex.flops() == ex.tree.total_flops("float32")
@@ -170,11 +174,7 @@ def test_fused_triples_in_sweeps(emu, Lx, Ly, D):
     assert emu.calls.get("chain3", 0) == n3
     m, e = ex(arrays, strip_exponent=True)
     checks.assert_close(m.to_numpy() * 10.0**e, want, "float32")
-    os.environ["QAMD_CHAIN3"] = "0"
-    try:
-        ex0 = qa.TreeExecutor(tree, "float32")
-    finally:
-        del os.environ["QAMD_CHAIN3"]
+    ex0 = qa.TreeExecutor(tree, "float32")   # default: pairs only
     assert not any(e[0] == "chain3" for e in ex0.plan)
     assert ex0.algorithmic_bytes() >= ex.algorithmic_bytes()     # the triple never moves more bytes for the same FLOPs
     checks.assert_close(ex0(arrays).to_numpy(), want, "float32")
