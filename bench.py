@@ -100,7 +100,8 @@ def main():
     ap.add_argument("--Ly", type=int, default=10)
     ap.add_argument("--D", type=int, default=6)
     ap.add_argument("--slices", type=int, default=216)
-    ap.add_argument("--sliced", action="store_true", help="run the sliced workload even on one GPU")
+    ap.add_argument("--sliced", action="store_true", help="run the 216-slice workload of round 1 (one rank, or round-robin over ranks)")
+    ap.add_argument("--two-sided", action="store_true", help="run the branch decomposition (N > 1 default) on one GPU too")
     ap.add_argument("--seed", type=int, default=7)
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
@@ -132,14 +133,28 @@ def main():
     dtype = "float32"
     arrays, inputs, size = build_network(args.Lx, args.Ly, args.D, args.seed, dtype)
     tree = qa.ContractionTree(inputs, (), size, path=qa.sweep_path_2d(args.Lx, args.Ly))
-    sliced = args.sliced or world > 1
+    # N > 1: the BRANCH decomposition (top / bottom half sweeps on two groups of ranks, cut-row slices inside a
+    # group, quimb_amd/twosided.py) -- round 1's 216 slices of the one-sided sweep cost 140x the FLOPs
+    two_sided = (world > 1 and not args.sliced) or args.two_sided
+    sliced = args.sliced and not two_sided
+    plan = None
+    if two_sided:
+        from quimb_amd.distributed import contract_two_sided, sliced_cols_for_world, two_sided_layout
+        from quimb_amd.twosided import TwoSidedContraction
+
+        k = sliced_cols_for_world([args.D] * args.Ly, world)
+        plan = TwoSidedContraction(inputs, size, args.Lx, args.Ly, dtype, sliced_cols=k)
     if sliced:
         tree = qa.find_slices(tree, target_slices=args.slices)
-    ex = qa.TreeExecutor(tree, dtype)
+    ex = qa.TreeExecutor(tree, dtype) if not two_sided else None
     xs = [qa.asarray(a) for a in arrays]  # resident in HBM before the timed region
     my = list(rank_slices(tree.nslices, rank, world)) if sliced else None
 
+    rank_stats = {}
+
     def step():
+        if two_sided:
+            return contract_two_sided(plan, xs, strip_exponent=True, stats=rank_stats)
         if sliced:
             if world > 1:
                 # this rank's slices, then ONE all-reduce of the (mantissa, exponent) pair at the join -- the
@@ -162,7 +177,7 @@ def main():
     # N = 1 (unsliced): per-kernel HIP events are recorded inside the timed region.  Sliced runs replay one
     # recorded hipGraph per slice, which hides the individual launches from the host: their kernel timings
     # come from ONE extra, untimed, launch-by-launch pass after the timed region.
-    if rank == 0 and not sliced:
+    if rank == 0 and not sliced and not two_sided:
         dev.profile = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -170,7 +185,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     prof, dev.profile = dev.profile, None
-    if sliced:
+    if sliced or two_sided:
         os.environ["QAMD_SLICE_GRAPH"] = "0"
         if rank == 0:
             dev.profile = []
@@ -178,13 +193,52 @@ def main():
         fence()
         prof, dev.profile = dev.profile, None
         del os.environ["QAMD_SLICE_GRAPH"]
+    scaling_report = None
+    if two_sided:
+        # honest strong-scaling context: what the ranks executed, how evenly, and the one-GPU unsliced time
+        layout = two_sided_layout(plan.nslices, world)
+        rep = plan.cost_report(layout)
+        mine_t = torch.tensor([rank_stats.get("hoist_s", 0.0), rank_stats.get("compute_s", 0.0)], dtype=torch.float64,
+                              device="cpu" if backend == "gloo" else dev.tdev)
+        if world > 1:
+            allt = [torch.empty_like(mine_t) for _ in range(world)]
+            dist.all_gather(allt, mine_t)
+            allt = [[float(v) for v in t.cpu()] for t in allt]
+        else:
+            allt = [[float(v) for v in mine_t.cpu()]]
+        one_gpu_ms = None
+        if rank == 0:
+            ex1 = qa.TreeExecutor(tree, dtype)
+            for _ in range(2):
+                ex1(xs, strip_exponent=True)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(3):
+                ex1(xs, strip_exponent=True)[0].item()
+            torch.cuda.synchronize()
+            one_gpu_ms = (time.perf_counter() - t1) / 3 * 1e3
+        if world > 1:
+            dist.barrier()
+        scaling_report = {
+            "decomposition": f"two-sided: top / bottom half sweeps on {world // 2 or 1} + {world - world // 2} ranks, "
+                             f"{plan.nslices} cut-row slice(s) in contiguous blocks per group, point-to-point hand-off of the "
+                             f"cut boundary, one all-gather",
+            "flops_useful": 2 * rep["useful_mults"], "flops_executed_all_ranks": 2 * rep["executed_mults"],
+            "slice_flop_inflation": rep["inflation"],
+            "hoisted_fraction_of_executed": rep["hoisted_mults_all_ranks"] / rep["executed_mults"],
+            "ideal_speedup_from_flops": rep["ideal_speedup_vs_one_rank"],
+            "per_rank_hoist_ms": [1e3 * a for a, _ in allt], "per_rank_compute_ms": [1e3 * b for _, b in allt],
+            "unsliced_one_sided_1gpu_ms_on_rank0": one_gpu_ms,
+        }
     tt = torch.tensor([dt], dtype=torch.float64, device=dev.tdev)
     if world > 1:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     dt = float(tt.cpu()[0])
 
     if rank == 0:
-        flops_step = ex.flops()  # whole job, all slices (hoisted steps counted once)
+        # whole job: FLOPs of the tree executed (all slices, hoisted steps once); for the branch decomposition the
+        # USEFUL count -- the one-sided sweep's -- so that values at different N compare as time to solution
+        flops_step = 2 * plan.one_sided_mults if two_sided else ex.flops()
         ms = dt / args.steps * 1e3
         value = flops_step / (dt / args.steps) / 1e12
         # ---- dominant kernel from HIP-event timings over the timed region ------
@@ -242,8 +296,8 @@ def main():
             roof["tflops"] = flops_launch / avg / 1e12
             roof["avg_launch_ms"] = avg * 1e3
             roof["launches_timed"] = cnt
-            roof["timed_in"] = "one untimed launch-by-launch pass after the timed region (the timed region replays hipGraphs)" if sliced else "the timed region"
-            roof["share_of_step_time"] = tsum / (dt / args.steps * (1 if sliced else args.steps))
+            roof["timed_in"] = "one untimed launch-by-launch pass after the timed region (the timed region replays hipGraphs)" if sliced else ("rank 0's launches of one untimed pass after the timed region" if two_sided else "the timed region")
+            roof["share_of_step_time"] = tsum / (dt / args.steps * (1 if (sliced or two_sided) else args.steps))
             roof["algorithmic_bytes_per_launch"] = bytes_launch
             roof["flops_per_launch"] = flops_launch
         cpu = None if (args.no_cpu or world > 1) else cpu_baseline(args.D, args.Ly, args.seed)   # N=1 only
@@ -263,20 +317,26 @@ def main():
             "config": {
                 "workload": (
                     f"{args.Lx}x{args.Ly} D={args.D} PEPS amplitude (single-layer TN), exact, "
-                    + (f"{tree.nslices} slices over {world} GPU(s), one all-reduce" if sliced else "unsliced, 1 GPU")
+                    + (f"{tree.nslices} slices over {world} GPU(s), one all-reduce" if sliced else
+                       (f"two-sided branch decomposition over {world} GPU(s), {plan.nslices} cut-row slice(s)" if two_sided
+                        else "unsliced, 1 GPU"))
                 ),
                 "tree": "site-by-site boundary sweep",
                 "tree_mults": tree.contraction_cost(),
                 "flops_per_step": flops_step,
-                "nslices": tree.nslices,
+                "nslices": plan.nslices if two_sided else tree.nslices,
                 "contraction_width_log2": tree.contraction_width(),
-                "parallelism": f"slices{world}" if sliced else "single",
+                "parallelism": f"slices{world}" if sliced else (f"branches2xslices{max(world // 2, 1)}" if two_sided else "single"),
             },
             "pct_mfma_peak": 100.0 * value / (MFMA_F32_PEAK_TF * world),
             "result": _result_with_parity(res, args),
             "roofline": roof,
             "cpu_baseline": cpu,
         }
+        if scaling_report is not None:
+            out["strong_scaling_report"] = scaling_report
+            if scaling_report["unsliced_one_sided_1gpu_ms_on_rank0"]:
+                out["strong_scaling_report"]["time_vs_unsliced_1gpu"] = ms / scaling_report["unsliced_one_sided_1gpu_ms_on_rank0"]
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

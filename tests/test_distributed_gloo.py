@@ -1,6 +1,8 @@
-"""world_size-2 test of the multi-GPU path on CPU: slices sharded round-robin
-over two gloo ranks, one all-reduce at the join (the RCCL collective's stand-in),
-device ops interpreted by tests/emu_device.py."""
+"""Multi-process tests of the multi-GPU path on CPU (gloo = the RCCL collectives' stand-in, device ops
+interpreted by tests/emu_device.py): slices sharded round-robin with one collective at the join
+(world 2, 4, 8, uneven slice counts, unsliced trees), and the branch decomposition -- the two half sweeps
+of a 2D network on two groups of ranks, cut-row slices inside a group, point-to-point hand-off of the cut
+boundary, one all-gather (world 2, 3, 4, 8)."""
 
 import os
 import socket
@@ -61,3 +63,96 @@ def test_sliced_two_ranks_gloo(tmp_path, strip):
     for r in range(2):
         got = np.load(tmp_path / f"r{r}.npy")
         assert got.item() == pytest.approx(want.item(), rel=1e-10)
+
+
+def _worker_sliced_uneven(rank, world, port, nslices_target, outdir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+
+    import quimb_amd as qa
+    import quimb_amd.device as qd
+    from emu_device import EmuDevice
+    from oracle import np_oracle as orc
+    from quimb_amd.distributed import contract_sliced
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        qd.set_default_device(EmuDevice())
+        arrays, inputs = orc.tn2d_rand(3, 4, 3, seed=5, dtype="float64")
+        size = {ix: 3 for t in inputs for ix in t}
+        tree = qa.ContractionTree(inputs, (), size, path=qa.sweep_path_2d(3, 4))
+        if nslices_target > 1:
+            tree = qa.find_slices(tree, target_slices=nslices_target)
+        ex = qa.TreeExecutor(tree, "float64")
+        m, e = contract_sliced(ex, arrays, strip_exponent=True)
+        plain = contract_sliced(ex, arrays)
+        np.save(os.path.join(outdir, f"r{rank}.npy"), np.asarray([np.asarray(m).item() * 10.0**e, np.asarray(plain).item()]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,nslices", [(4, 9), (8, 27), (8, 3), (2, 1), (4, 1)])
+def test_sliced_uneven_and_unsliced(tmp_path, world, nslices):
+    """Slice counts that do not divide the world size, more ranks than slices, and an UNSLICED tree (one slice:
+    only rank 0 owns it -- every other rank must contribute zero, not the full value)."""
+    import torch.multiprocessing as mp
+
+    from oracle import np_oracle as orc
+
+    mp.spawn(_worker_sliced_uneven, args=(world, _free_port(), nslices, str(tmp_path)), nprocs=world, join=True)
+    arrays, inputs = orc.tn2d_rand(3, 4, 3, seed=5, dtype="float64")
+    want = orc.oracle_array_contract(arrays, inputs, ()).item()
+    for r in range(world):
+        got = np.load(tmp_path / f"r{r}.npy")
+        assert got[0] == pytest.approx(want, rel=1e-10) and got[1] == pytest.approx(want, rel=1e-10)
+
+
+def _worker_two_sided(rank, world, port, Lx, Ly, D, k, outdir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+
+    import quimb_amd.device as qd
+    from emu_device import EmuDevice
+    from oracle import np_oracle as orc
+    from quimb_amd.distributed import contract_two_sided, sliced_cols_for_world
+    from quimb_amd.twosided import TwoSidedContraction
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        qd.set_default_device(EmuDevice())
+        arrays, inputs = orc.tn2d_rand(Lx, Ly, D, seed=11, dtype="float64")
+        size = {ix: D for t in inputs for ix in t}
+        if k is None:
+            k = sliced_cols_for_world([D] * Ly, world)
+        plan = TwoSidedContraction(inputs, size, Lx, Ly, "float64", sliced_cols=k)
+        stats = {}
+        m, e = contract_two_sided(plan, arrays, strip_exponent=True, stats=stats)
+        plain = contract_two_sided(plan, arrays)
+        assert "compute_s" in stats
+        np.save(os.path.join(outdir, f"r{rank}.npy"), np.asarray([m * 10.0**e, plain]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,Lx,Ly,D,k", [(2, 4, 4, 3, None), (2, 4, 4, 3, 1), (3, 5, 3, 2, None), (4, 4, 4, 3, None),
+                                              (4, 4, 3, 2, 2), (8, 4, 4, 2, None), (8, 3, 4, 3, 1)])
+def test_two_sided_branches(tmp_path, world, Lx, Ly, D, k):
+    """Top / bottom half sweeps on two groups of ranks, the cut row's slices in contiguous blocks inside a
+    group (uneven blocks, ranks without a slice, odd world sizes), slabs handed over point to point, one
+    all-gather: every rank ends with the oracle's value."""
+    import torch.multiprocessing as mp
+
+    from oracle import np_oracle as orc
+
+    mp.spawn(_worker_two_sided, args=(world, _free_port(), Lx, Ly, D, k, str(tmp_path)), nprocs=world, join=True)
+    arrays, inputs = orc.tn2d_rand(Lx, Ly, D, seed=11, dtype="float64")
+    want = orc.oracle_array_contract(arrays, inputs, ()).item()
+    for r in range(world):
+        got = np.load(tmp_path / f"r{r}.npy")
+        assert got[0] == pytest.approx(want, rel=1e-10) and got[1] == pytest.approx(want, rel=1e-10)

@@ -299,3 +299,53 @@ def test_linalg_extras(emu, dtype):
 @pytest.mark.parametrize("dtype", ["float64", "float32", "complex128"])
 def test_tensor_methods(emu, dtype):
     checks.check_tensor_methods(dtype)
+
+
+@pytest.mark.parametrize("Lx,Ly,D,dtype", [(4, 4, 3, "float64"), (5, 3, 2, "float64"), (4, 5, 2, "float32")])
+def test_two_sided_contraction(emu, Lx, Ly, D, dtype):
+    """The branch decomposition on one rank: both half sweeps, every number of sliced cut bonds, every cut
+    position -- always the oracle's value; the cost model says the slices add no work inside a half."""
+    from oracle import np_oracle as orc
+    from quimb_amd.distributed import two_sided_layout
+    from quimb_amd.twosided import TwoSidedContraction
+
+    arrays, inputs = orc.tn2d_rand(Lx, Ly, D, seed=5, dtype=dtype)
+    size = {ix: D for t in inputs for ix in t}
+    want = orc.oracle_array_contract([a.astype(np.float64) for a in arrays], inputs, ()).item()
+    rel = 1e-5 if dtype == "float32" else 1e-10
+    for k in range(Ly + 1):
+        for cut in (None, 1, Lx - 1):
+            plan = TwoSidedContraction(inputs, size, Lx, Ly, dtype, cut=cut, sliced_cols=k)
+            assert plan(arrays) == pytest.approx(want, rel=rel)
+            m, e = plan(arrays, strip_exponent=True)
+            assert abs(m) == 1.0 and m * 10.0**e == pytest.approx(want, rel=rel)
+    plan0 = TwoSidedContraction(inputs, size, Lx, Ly, dtype, sliced_cols=0)
+    plan1 = TwoSidedContraction(inputs, size, Lx, Ly, dtype, sliced_cols=1)
+    r0 = plan0.cost_report(two_sided_layout(plan0.nslices, 1))
+    r1 = plan1.cost_report(two_sided_layout(plan1.nslices, 1))
+    assert r1["executed_mults"] <= r0["executed_mults"] * 1.0001       # prefix sharing: slicing adds nothing on one rank
+    r2 = plan0.cost_report(two_sided_layout(plan0.nslices, 2))
+    assert r2["inflation"] == pytest.approx(r0["inflation"]) and r2["ideal_speedup_vs_one_rank"] > 1.5
+
+
+def test_slices_argument_is_validated(emu):
+    """``slices=`` on an unsliced tree: slice 0 is the whole contraction, an empty list contributes zero (what a
+    rank without work must return before the reduce); out-of-range and duplicate numbers are rejected."""
+    import quimb_amd as qa
+
+    rng = np.random.default_rng(0)
+    a, b = rng.standard_normal((3, 4)), rng.standard_normal((4, 5))
+    tree = qa.ContractionTree([("i", "j"), ("j", "k")], ("i", "k"), {"i": 3, "j": 4, "k": 5}, path=[(0, 1)])
+    ex = qa.TreeExecutor(tree, "float64")
+    np.testing.assert_allclose(ex([a, b], slices=[0]).to_numpy(), a @ b)
+    np.testing.assert_array_equal(ex([a, b], slices=[]).to_numpy(), np.zeros((3, 5)))
+    z, e = ex([a, b], slices=[], strip_exponent=True)
+    assert e == float("-inf") and not z.to_numpy().any()
+    st = tree.with_slices(["j"])
+    exs = qa.TreeExecutor(st, "float64")
+    np.testing.assert_allclose(exs([a, b], slices=[0, 2]).to_numpy(), a[:, [0, 2]] @ b[[0, 2]])
+    for bad in ([4], [-1], [1, 1]):
+        with pytest.raises(ValueError):
+            exs([a, b], slices=bad)
+    with pytest.raises(ValueError):
+        ex([a, b], slices=[1])
