@@ -217,6 +217,7 @@ __global__ __launch_bounds__(256, 1) void chain2q_kernel(const Chain2Args p, con
     val[0] = acc[set][xx][rl / 4][rl & 3];
     val[1] = acc[set][xx][rl / 4][(rl & 3) + 1];
     *reinterpret_cast<q_vec2*>(Tl + tile + nol * (64 * DD) + x * D + ni) = val;
+    asm volatile("" ::: "memory");   // the copy-out reads these bytes through another vector type: no reordering across
   };
   // copy-out of group g (tile at ``tile``, chunk C offset cb) in CPG + 1 steps: step s stores what step s - 1 read
   q_vec4 stage[2];
@@ -235,6 +236,7 @@ __global__ __launch_bounds__(256, 1) void chain2q_kernel(const Chain2Args p, con
     }
     if (s < CPG) {
       const int nol = s / IPN, it = s - nol * IPN;
+      asm volatile("" ::: "memory");
       stage[s & 1] = *reinterpret_cast<const q_vec4*>(Tw + tile + nol * (64 * DD) + it * 256 + lane * 4);
     }
   };

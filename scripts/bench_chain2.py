@@ -55,6 +55,13 @@ if os.environ.get("QAMD_C2_CHECK", "1") != "0":
     del X
     err = ((got - want).abs().max() / want.abs().max()).item()
     bad = int(((got - want).abs() > 1e-4 * want.abs().max()).sum().item())
+    if bad and os.environ.get("QAMD_C2_DIAG"):
+        idx = ((got - want).abs() > 1e-4 * want.abs().max()).nonzero().cpu().numpy()
+        names = ("m", "x", "z") if variant == "end" else ("no", "m", "x", "z")
+        for c, n in enumerate(names):
+            u = np.unique(idx[:, c] % (64 if n == "m" else 10**9))
+            print(f"  bad {n}{' mod 64' if n == 'm' else ''}: {u[:70]}")
+        print("  bad m // 64 (chunks):", np.unique(idx[:, names.index('m')] // 64)[:40])
     print(f"check: max |diff| / max |C| = {err:.2e}; elements off by > 1e-4: {bad}; NaN: {int(torch.isnan(got).sum().item())}")
     assert err < 1e-5 and bad == 0
     del want
