@@ -16,7 +16,7 @@ from .ops import (  # noqa: F401  (autoray resolves these by name)
     einsum, einsum_pair, exp, expand_dims, eye, fuse, imag, log, log10, matmul, max, min, multiply, ndim, negative,
     norm_fro, ones, ravel, real, reshape, shape, size, sqrt, squeeze, subtract, sum, take, tensordot, trace,
     transpose, true_divide, zeros,
-    kron, mean, moveaxis, outer, power, square, stack, swapaxes, vdot,
+    kron, mean, moveaxis, outer, power, square, stack, swapaxes, vdot, implementation_pair,
 )
 from . import linalg  # noqa: F401  (do("linalg.svd" / "linalg.qr" / "linalg.eigh" / "linalg.norm"))
 from .contract import (  # noqa: F401
@@ -36,6 +36,7 @@ from .circuit import Circuit, CircuitMPS
 from .network import TensorNetwork
 from .pathfind import find_path, find_slices, geometry_hash, greedy_path, random_greedy, set_tree_cache, sweep_path_2d
 from .tree import ContractionTree
+from .twosided import TwoSidedContraction
 from .device import HipDevice, default_device
 
 # the class must report the top-level module for autoray's backend inference

@@ -211,8 +211,54 @@ def array_contract_expression(
     return expr
 
 
+def _transpose_any(x, perm):
+    if isinstance(x, Array):
+        from . import ops
+
+        return ops.transpose(x, perm)
+    return np.transpose(x, perm)
+
+
+def contract_with_implementation(tree, arrays, implementation):
+    """Walk ``tree`` step by step through a caller-supplied ``(tensordot, einsum)`` pair -- what cotengra does
+    with ``implementation=(tensordot, einsum)`` (the kwarg quimb forwards untouched: tensor_core.py:293-294,:327;
+    contraction.py:279,:291).  A step without batch / hyper indices is ``tensordot(a, b, axes)`` followed by a
+    transpose into the kept order, anything else ``einsum(eq, a, b)``; single-operand steps go to ``einsum`` too."""
+    tensordot, einsum = implementation
+    live = dict(enumerate(arrays))
+    sym = {}
+
+    def letters(inds):
+        return "".join(sym.setdefault(ix, chr(ord("a") + len(sym)) if len(sym) < 26 else chr(ord("A") + len(sym) - 26))
+                       for ix in inds)
+
+    nsteps = len(tree.steps)
+    for si, (con, res, ops_inds, keep, _) in enumerate(tree.steps):
+        out = tuple(tree.output) if (si == nsteps - 1 and len(tree.remaining) == 1) else tuple(keep)
+        xs = [live.pop(c) for c in con]
+        if len(con) == 2:
+            la, lb = ops_inds
+            shared = [ix for ix in la if ix in lb]
+            plain = (len(set(la)) == len(la) and len(set(lb)) == len(lb) and not any(ix in out for ix in shared))
+            if plain:
+                axes = ([la.index(ix) for ix in shared], [lb.index(ix) for ix in shared])
+                x = tensordot(xs[0], xs[1], axes)
+                got = tuple(ix for ix in la if ix not in shared) + tuple(ix for ix in lb if ix not in shared)
+                if got != out:
+                    x = _transpose_any(x, [got.index(ix) for ix in out])
+            else:
+                sym.clear()
+                x = einsum(f"{letters(la)},{letters(lb)}->{letters(out)}", xs[0], xs[1])
+        else:
+            sym.clear()
+            x = einsum(f"{letters(ops_inds[0])}->{letters(out)}", xs[0])
+        live[res] = x
+    (root,) = tree.remaining
+    return live[root]
+
+
 def array_contract(arrays, inputs, output=None, optimize=None, backend=None, strip_exponent=False,
-                   slicing=None, **kwargs):
+                   slicing=None, implementation=None, **kwargs):
     """Contract ``arrays`` labelled by ``inputs`` into ``output`` on the MI355X.
 
     Same call shape as ``quimb.tensor.contraction.array_contract``
@@ -226,6 +272,13 @@ def array_contract(arrays, inputs, output=None, optimize=None, backend=None, str
     arrays = list(arrays)
     if not arrays:
         raise ValueError("nothing to contract")
+    if implementation is not None and not isinstance(implementation, str):
+        # cotengra's injection point B2: a (tensordot, einsum) pair executes every pairwise step
+        shapes = [tuple(np.shape(a)) if not isinstance(a, Array) else a.shape for a in arrays]
+        tree = array_contract_tree(inputs, output, shapes=shapes, optimize=optimize, slicing=slicing)
+        if tree.nslices != 1 or strip_exponent:
+            raise NotImplementedError("implementation=(tensordot, einsum) runs unsliced trees without exponent stripping")
+        return contract_with_implementation(tree, arrays, implementation)
     shapes = [tuple(np.shape(a)) if not isinstance(a, Array) else a.shape for a in arrays]
     dt = np.result_type(*[a.dtype if hasattr(a, "dtype") else np.asarray(a).dtype for a in arrays])
     if dt.kind in "iub":
@@ -301,6 +354,39 @@ class Tensor:
         t = self.moveindex(ind, axis)
         self.data, self.inds = t.data, t.inds
         return self
+
+    def gate(self, G, ind, preserve_inds=True, transpose=False, inplace=False, transposed=None):
+        """Contract the matrix ``G`` into index ``ind`` without changing the index set: ``x <- G x`` (or ``x G``
+        with ``transpose``) -- ``Tensor.gate``, tensor_core.py:3076-3166.  The reference does tensordot + a
+        transpose back into place; here it is ONE GETT launch that writes the gated index where it was
+        (``preserve_inds``) or in front (the reference's no-transpose form)."""
+        from . import ops
+
+        if transposed is not None:
+            import warnings
+
+            warnings.warn("`transposed` has been renamed to `transpose`, for consistency with the other gating methods.",
+                          FutureWarning)
+            transpose = transposed
+        ax = self.inds.index(ind)
+        nd = self.ndim
+        sym = [chr(ord("a") + i) for i in range(nd)]
+        new, old_ = "Z", sym[ax]
+        g_eq = (old_ + new) if transpose else (new + old_)
+        out_syms = [new if i == ax else c for i, c in enumerate(sym)]
+        if preserve_inds:
+            new_inds = self.inds
+        else:
+            out_syms = [new] + [c for i, c in enumerate(sym) if i != ax]
+            new_inds = (ind,) + self.inds[:ax] + self.inds[ax + 1:]
+        data = ops.einsum(f"{g_eq},{''.join(sym)}->{''.join(out_syms)}", G, self.data)
+        if inplace:
+            self.data, self.inds = data, tuple(new_inds)
+            return self
+        return Tensor(data, new_inds, self.tags)
+
+    def gate_(self, G, ind, **kw):
+        return self.gate(G, ind, inplace=True, **kw)
 
     def reindex(self, index_map):
         return Tensor(self.data, tuple(index_map.get(ix, ix) for ix in self.inds), self.tags)

@@ -199,6 +199,86 @@ class TensorNetwork:
                                   **opts)
 
     # ---- norms / exponent bookkeeping (tensor_core.py:10801-10841) ------------------------------------
+    # ---- local contractions (tensor_core.py:6206-6289) ------------------------------------------------------
+    def _contracted_inds(self, picked, rest, output_inds=None):
+        """Indices the contraction of ``picked`` must keep: those still used by ``rest`` or wanted as output
+        (``compute_contracted_inds``)."""
+        if output_inds is None:
+            cnt = {}
+            for t in self.tensors:
+                for ix in dict.fromkeys(t.inds):
+                    cnt[ix] = cnt.get(ix, 0) + 1
+            output_inds = {ix for ix, c in cnt.items() if c == 1}
+        else:
+            output_inds = set(output_inds)
+        outside = {ix for t in rest for ix in t.inds}
+        keep = []
+        for t in picked:
+            for ix in t.inds:
+                if ix not in keep and (ix in outside or ix in output_inds):
+                    keep.append(ix)
+        return tuple(keep)
+
+    def _unique(self, tags):
+        picked, _ = self._select(tags, which="all")
+        if len(picked) != 1:
+            raise ValueError(f"tags {tags!r} must identify exactly one tensor, found {len(picked)}")
+        return picked[0]
+
+    def contract_between(self, tags1, tags2, output_inds=None, equalize_norms=False, **contract_opts):
+        """Contract the two tensors identified by ``tags1`` / ``tags2`` in place (no-op if they are the same
+        tensor) -- ``contract_between`` / ``_contract_between_tids``, tensor_core.py:6206-6262."""
+        t1, t2 = self._unique(tags1), self._unique(tags2)
+        if t1 is t2:
+            return self
+        rest = [t for t in self.tensors if t is not t1 and t is not t2]
+        out = self._contracted_inds([t1, t2], rest, output_inds)
+        t12 = tensor_contract(t1, t2, output_inds=out, preserve_tensor=True, **contract_opts)
+        pos = self.tensors.index(t2)
+        self.tensors[pos] = t12
+        self.tensors.remove(t1)
+        if equalize_norms:
+            self.strip_exponent(t12, equalize_norms)
+        return self
+
+    def contract_ind(self, ind, output_inds=None, **contract_opts):
+        """Contract every tensor carrying ``ind`` into one, in place (``contract_ind``, tensor_core.py:6264-6289);
+        ``ind`` survives if it is an output index."""
+        picked = [t for t in self.tensors if ind in t.inds]
+        if not picked:
+            raise ValueError(f"index {ind!r} not found")
+        rest = [t for t in self.tensors if not any(t is p for p in picked)]
+        out = self._contracted_inds(picked, rest, output_inds)
+        tnew = tensor_contract(*picked, output_inds=out, preserve_tensor=True, **contract_opts)
+        pos = self.tensors.index(picked[0])
+        self.tensors[pos] = tnew
+        for p in picked[1:]:
+            self.tensors.remove(p)
+        return self
+
+    # ---- whole-network queries (tensor_core.py:9880-10030) ------------------------------------------------------
+    def contraction_tree(self, optimize=None, output_inds=None, **kwargs):
+        from .contract import array_contract_tree
+
+        return array_contract_tree([t.inds for t in self.tensors], output_inds, shapes=[t.shape for t in self.tensors],
+                                   optimize=optimize, **kwargs)
+
+    def contraction_width(self, optimize=None, **kwargs):
+        return self.contraction_tree(optimize, **kwargs).contraction_width()
+
+    def contraction_cost(self, optimize=None, **kwargs):
+        return self.contraction_tree(optimize, **kwargs).contraction_cost()
+
+    def trace(self, left_inds, right_inds, **contract_opts):
+        """Trace over ``left_inds`` joined with ``right_inds`` (``TensorNetwork.trace``): the right indices are
+        renamed onto the left ones and the network is contracted."""
+        left = (left_inds,) if isinstance(left_inds, str) else tuple(left_inds)
+        right = (right_inds,) if isinstance(right_inds, str) else tuple(right_inds)
+        ren = dict(zip(right, left))
+        tn = TensorNetwork([t.reindex(ren) for t in self.tensors], self.exponent)
+        return tn.contract(output_inds=contract_opts.pop("output_inds", None) or
+                           tuple(ix for ix in tn.outer_inds() if ix not in left), **contract_opts)
+
     @property
     def arrays(self):
         return tuple(t.data for t in self.tensors)

@@ -565,3 +565,19 @@ def ndim(x):
 
 def size(x):
     return asarray(x).size
+
+
+def implementation_pair():
+    """The ``(tensordot, einsum)`` pair for cotengra's ``implementation=`` injection point:
+    ``tn.contract(..., implementation=quimb_amd.implementation_pair())``.  quimb forwards unknown contraction
+    kwargs to ``cotengra.array_contract`` untouched (tensor_core.py:293-294, :327; contraction.py:279, :291), and
+    cotengra then calls ``tensordot(a, b, axes)`` / ``einsum(eq, a, b)`` for every pairwise step of its tree.
+    Host arrays are moved into HBM on first touch and every intermediate stays there (the result is an
+    ``Array``)."""
+    def _td(a, b, axes=2):
+        return tensordot(asarray(a), asarray(b), axes)
+
+    def _es(eq, *xs):
+        return einsum(eq, *[asarray(x) for x in xs])
+
+    return _td, _es

@@ -1357,3 +1357,77 @@ def check_tensor_methods(dtype="float64"):
     assert (tl @ tr).almost_equals(a, rtol=1e-4, atol=1e-5)
     assert a.conj().H.almost_equals(a) and a.norm() == pytest.approx(np.linalg.norm(a.data.to_numpy().ravel()), rel=1e-5)
     assert a.reindex({"a": "z"}).inds == ("z", "b", "c", "d")
+
+
+def check_gate_and_local_contractions(dtype="float64"):
+    """``Tensor.gate`` as the reference tests it (test_tensor_core.py:173-182: ``G @ t``, ``G.T @ t``, the deprecated
+    ``transposed`` spelling warns), its ``preserve_inds=False`` form and in-place form (tensor_core.py:3076-3166);
+    ``contract_between`` / ``contract_ind`` (tensor_core.py:6206-6289: in place, fewer tensors, same network value,
+    kept indices = those the rest of the network or the output still needs); ``TensorNetwork.trace`` and
+    ``contraction_tree / width / cost``; the (tensordot, einsum) pair of cotengra's ``implementation=``."""
+    import warnings
+
+    rng = np.random.default_rng(33)
+    T = qa.Tensor
+    dev = lambda x: qa.asarray(x)
+    t = T(dev(rand(rng, (2, 3), dtype)), "ab")
+    G = rand(rng, (2, 2), dtype)
+    td = t.data.to_numpy()
+    assert_close(t.gate(dev(G), "a").data.to_numpy(), G @ td, dtype)
+    assert_close(t.gate(dev(G), "a", transpose=True).data.to_numpy(), G.T @ td, dtype)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        tt = t.gate(dev(G), "a", transposed=True)
+    assert any(issubclass(x.category, FutureWarning) for x in w)
+    assert_close(tt.data.to_numpy(), G.T @ td, dtype)
+    t3 = T(dev(rand(rng, (2, 3, 4), dtype)), "abc", tags="X")
+    G3 = rand(rng, (3, 3), dtype)
+    g = t3.gate(dev(G3), "b")
+    assert g.inds == ("a", "b", "c") and g.tags == ("X",)
+    assert_close(g.data.to_numpy(), np.einsum("zb,abc->azc", G3, t3.data.to_numpy()), dtype)
+    g = t3.gate(dev(G3), "b", preserve_inds=False)
+    assert g.inds == ("b", "a", "c")
+    assert_close(g.data.to_numpy(), np.einsum("zb,abc->zac", G3, t3.data.to_numpy()), dtype)
+    t4 = t3.copy()
+    assert t4.gate_(dev(G3), "b") is t4
+    assert_close(t4.data.to_numpy(), np.einsum("zb,abc->azc", G3, t3.data.to_numpy()), dtype)
+    assert t3.gate(G3, "b").almost_equals(g.transpose("a", "b", "c"), rtol=1e-4)     # a host matrix gates device data
+
+    # a ring of four tensors with one dangling index
+    shapes = {"i": 3, "j": 4, "k": 2, "l": 3, "o": 5}
+    spec = [("A", "ij"), ("B", "jk"), ("C", "kl"), ("D", "lio")]
+    arrays = [rand(rng, tuple(shapes[c] for c in inds), dtype) for _, inds in spec]
+    want = np.einsum("ij,jk,kl,lio->o", *arrays)
+    mk = lambda: qa.TensorNetwork([T(dev(a), inds, tags=tg) for a, (tg, inds) in zip(arrays, spec)])
+    tn = mk()
+    tn.contract_between("A", "B")
+    assert len(tn) == 3 and set(tn.tensors[0].inds) == {"i", "k"} and set(tn.tensors[0].tags) == {"A", "B"}
+    assert_close(tn.contract().data.to_numpy(), want, dtype)
+    tn.contract_between("A", "B")                       # same tensor twice: a no-op
+    assert len(tn) == 3
+    tn = mk()
+    tn.contract_ind("l")
+    assert len(tn) == 3 and set(next(t for t in tn if "C" in t.tags).inds) == {"k", "i", "o"}
+    assert_close(tn.contract().data.to_numpy(), want, dtype)
+    tn = mk()
+    tn.contract_ind("i", output_inds=("o", "i"))        # an output index survives the local contraction
+    assert "i" in next(t for t in tn if "A" in t.tags).inds
+    with np.testing.assert_raises(ValueError):
+        mk().contract_between("A", "nope")
+    tn = mk()
+    tree = tn.contraction_tree(optimize="greedy")
+    assert tn.contraction_cost("greedy") == tree.contraction_cost() and tn.contraction_width("greedy") == tree.contraction_width()
+    # trace of an operator network  M[a, b] = sum_x P[a, x] Q[x, b]
+    P, Q = rand(rng, (3, 4), dtype), rand(rng, (4, 3), dtype)
+    op = qa.TensorNetwork([T(dev(P), ("a", "x")), T(dev(Q), ("x", "b"))])
+    got = op.trace("a", "b")
+    assert_close(np.asarray(got), np.trace(P @ Q), dtype)
+    # cotengra's implementation=(tensordot, einsum) injection point: our pair, and numpy's, on the same tree
+    ins = [tuple(inds) for _, inds in spec]
+    got_dev = qa.array_contract(arrays, ins, ("o",), implementation=qa.implementation_pair())
+    assert isinstance(got_dev, qa.Array)
+    assert_close(got_dev.to_numpy(), want, dtype)
+    assert_close(qa.array_contract(arrays, ins, ("o",), implementation=(np.tensordot, np.einsum)), want, dtype)
+    hyper = qa.array_contract([arrays[0], rand(rng, (3, 4), dtype)], [("i", "j"), ("i", "j")], ("i",),
+                              implementation=qa.implementation_pair())        # batch index -> the einsum callable
+    assert hyper.shape == (3,)

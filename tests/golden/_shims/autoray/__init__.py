@@ -163,10 +163,16 @@ def imag(x):
 
 
 def to_numpy(x):
+    b = infer_backend(x)
+    if (b, "to_numpy") in _REGISTRY:
+        return _REGISTRY[b, "to_numpy"](x)
     return np.asarray(x)
 
 
 def astype(x, dtype):
+    b = infer_backend(x)
+    if b != "numpy":                      # autoray.astype dispatches on the array's backend
+        return get_lib_fn(b, "astype")(x, dtype)
     return np.asarray(x).astype(dtype)
 
 
@@ -179,9 +185,27 @@ def get_common_dtype(*arrays):
 
 
 def to(x, like=None, backend=None, dtype=None, device=None):
-    if dtype is not None:
-        return astype(x, dtype)
-    return x
+    """autoray.to: convert every array leaf of a pytree to a target backend / dtype (``TensorNetwork.to``,
+    quimb/tensor/tensor_core.py:5312-5356)."""
+    if isinstance(like, str):            # "backend-dtype-device", each part optional
+        for part in like.split("-"):
+            if part.startswith(("float", "complex", "int")):
+                dtype = dtype or part
+            elif ":" in part or part in ("cpu", "cuda"):
+                device = device or part
+            elif backend is None:
+                backend = part
+
+    def conv(a):
+        if not hasattr(a, "shape"):
+            return a
+        if backend is not None and infer_backend(a) != backend:
+            a = do("asarray", a, like=backend)
+        if dtype is not None:
+            a = astype(a, dtype)
+        return a
+
+    return tree_map(conv, x)
 
 
 def tree_map(f, tree, is_leaf=None):

@@ -138,7 +138,33 @@ def array_contract_path(*args, **kwargs):
     return array_contract_tree(*args, **kwargs).get_path()
 
 
-def _contract(arrays, inputs, output, path, strip_exponent):
+def _pair_step(ops, tis, new, backend, implementation):
+    """One pairwise step the way cotengra executes it: ``tensordot`` (+ a transpose into the kept order) when
+    no index is batched / repeated, ``einsum`` otherwise; through the caller's ``implementation=(tensordot,
+    einsum)`` pair if one was given, else through autoray on ``backend`` (default: the operands' own)."""
+    la, lb = tis
+    shared = [ix for ix in la if ix in lb]
+    plain = len(set(la)) == len(la) and len(set(lb)) == len(lb) and not any(ix in new for ix in shared)
+    if isinstance(implementation, tuple):
+        td, es = implementation
+        tr = lambda x, perm: do("transpose", x, perm)
+    else:
+        td = lambda a, b, axes: do("tensordot", a, b, axes, like=backend)
+        es = lambda eq, *xs: do("einsum", eq, *xs, like=backend)
+        tr = lambda x, perm: do("transpose", x, perm)
+    if plain and isinstance(implementation, tuple):
+        axes = ([la.index(ix) for ix in shared], [lb.index(ix) for ix in shared])
+        x = td(ops[0], ops[1], axes)
+        got = tuple(ix for ix in la if ix not in shared) + tuple(ix for ix in lb if ix not in shared)
+        if got != tuple(new):
+            x = tr(x, tuple(got.index(ix) for ix in new))
+        return x
+    syms = get_symbol_map(list(tis) + [new])
+    eq = ",".join("".join(syms[i] for i in t) for t in tis) + "->" + "".join(syms[i] for i in new)
+    return es(eq, *ops)
+
+
+def _contract(arrays, inputs, output, path, strip_exponent, backend=None, implementation=None):
     arrays = list(arrays)
     inputs = [tuple(t) for t in inputs]
     exponent = 0.0
@@ -150,9 +176,12 @@ def _contract(arrays, inputs, output, path, strip_exponent):
         for t in inputs:
             rest.update(t)
         new = tuple(i for i in dict.fromkeys(itertools.chain(*tis)) if i in rest)
-        syms = get_symbol_map(tis + [new])
-        eq = ",".join("".join(syms[i] for i in t) for t in tis) + "->" + "".join(syms[i] for i in new)
-        x = do("einsum", eq, *ops)                     # autoray dispatch on the operands' backend, as cotengra does
+        if len(ops) == 2 and (backend is not None or implementation is not None):
+            x = _pair_step(ops, tis, new, backend, implementation)
+        else:
+            syms = get_symbol_map(tis + [new])
+            eq = ",".join("".join(syms[i] for i in t) for t in tis) + "->" + "".join(syms[i] for i in new)
+            x = do("einsum", eq, *ops)                 # autoray dispatch on the operands' backend, as cotengra does
         if strip_exponent:
             f = do("max", do("abs", x))
             f = float(f.item() if hasattr(f, "item") else f)
@@ -163,7 +192,10 @@ def _contract(arrays, inputs, output, path, strip_exponent):
         inputs.append(new)
     syms = get_symbol_map(inputs + [tuple(output)])
     eq = ",".join("".join(syms[i] for i in t) for t in inputs) + "->" + "".join(syms[i] for i in output)
-    x = do("einsum", eq, *arrays)
+    if isinstance(implementation, tuple):
+        x = implementation[1](eq, *arrays)
+    else:
+        x = do("einsum", eq, *arrays, like=backend)
     return (x, exponent) if strip_exponent else x
 
 
@@ -184,10 +216,15 @@ def array_contract_expression(inputs, output=None, size_dict=None, shapes=None, 
     return _Expression(tree, strip_exponent, constants)
 
 
-def array_contract(arrays, inputs, output=None, optimize="auto", backend=None, strip_exponent=False, **kwargs):
+def array_contract(arrays, inputs, output=None, optimize="auto", backend=None, strip_exponent=False,
+                   implementation=None, **kwargs):
+    """``backend``: explicit backend for the pairwise calls (cotengra: "by default determined from the input
+    arrays"); ``implementation``: "auto" / a (tensordot, einsum) pair of callables (cotengra's documented kwarg)."""
     shapes = [np.shape(a) for a in arrays]
     tree = array_contract_tree(inputs, output, shapes=shapes, optimize=optimize)
-    return _contract(arrays, tree.inputs, tree.output, tree.get_path(), strip_exponent)
+    if isinstance(implementation, str):
+        implementation = None
+    return _contract(arrays, tree.inputs, tree.output, tree.get_path(), strip_exponent, backend, implementation)
 
 
 def get_hypergraph(*a, **k):

@@ -121,5 +121,70 @@ assert ex.tree.contraction_cost() <= tree.contraction_cost() and ex.tree.contrac
 info = tn.contract(all, optimize="greedy", get="tree")
 assert qa.ContractionTree.from_any(info).get_path() == tree.get_path()
 
+# 8. mode (c) of INTEGRATION.md: numpy data left in place, the contraction routed by ``contract_backend``
+#    (quimb/tensor/contraction.py:173-200 -> the ``backend=`` of cotengra's array_contract)
+n0 = launched()
+with qtn.contract_backend("quimb_amd"):
+    got_c = tn.contract(all, optimize="greedy")
+assert launched() - n0 == 15 and abs(float(got_c) / want - 1) < 1e-12
+assert all(type(t.data) is np.ndarray for t in tn)                      # the network itself was not touched
+
+# 9. ``tn.to(backend=...)`` via autoray.to (tensor_core.py:5312-5356)
+tn_dev = tn.to(backend="quimb_amd")
+assert all(type(t.data) is qa.Array for t in tn_dev) and all(type(t.data) is np.ndarray for t in tn)
+assert abs(float(tn_dev.contract(all, optimize="greedy")) / want - 1) < 1e-12
+tn32 = tn.to("quimb_amd-float32")
+assert all(type(t.data) is qa.Array and str(t.dtype) == "float32" for t in tn32)
+
+# 10. quimb's own ``Tensor.gate`` (tensor_core.py:3076-3166) on device data: do("tensordot") + do("transpose")
+tg, tgd = tn.tensors[5], on_device(tn).tensors[5]
+Gm = np.random.default_rng(2).normal(size=(tg.shape[1],) * 2)
+n0 = launched()
+gd = tgd.gate(qa.asarray(Gm), tg.inds[1])
+assert launched() > n0 and type(gd.data) is qa.Array and gd.inds == tg.inds
+assert np.allclose(host(gd.data), tg.gate(Gm, tg.inds[1]).data, rtol=1e-13, atol=0)
+assert np.allclose(host(tgd.gate(qa.asarray(Gm), tg.inds[1], transpose=True, preserve_inds=False).data),
+                   tg.gate(Gm, tg.inds[1], transpose=True, preserve_inds=False).data, rtol=1e-13, atol=0)
+
+# 11. the injection point B2: a (tensordot, einsum) pair handed to cotengra through quimb's untouched kwargs
+#     (tensor_core.py:293-294, :327; contraction.py:279, :291), numpy data in, every step on the backend
+n0 = launched()
+got_i = tn.contract(all, optimize="greedy", implementation=qa.implementation_pair())
+assert launched() - n0 == 15 and abs(float(got_i) / want - 1) < 1e-12
+ti = qtn.tensor_contract(tn.tensors[0], tn.tensors[1], implementation=qa.implementation_pair())
+assert type(ti.data) is qa.Array and np.allclose(host(ti.data), (tn.tensors[0] @ tn.tensors[1]).data, rtol=1e-13, atol=0)
+
+# 12. ``Circuit.amplitude`` on its DEFAULT path: ``full_simplify_("ADCRS")`` leaves a hyper-index network
+#     (circuit/exact.py:421, :481-497; hyper-edge note tests/test_tensor/test_circuit/test_exact.py:136), which is
+#     converted (``_maybe_convert`` -> to_backend) and contracted on the backend
+import itertools  # noqa: E402
+import random  # noqa: E402
+
+random.seed(11)
+nq = depth = 12                      # the circuit family of the reference's own simplification test (test_exact.py:93-139)
+layers = itertools.cycle([
+    lambda: [(random.choice(["X_1_2", "Y_1_2", "W_1_2"]), i) for i in range(nq)],
+    lambda: [("cz", i, i + 1) for i in range(0, nq, 2)],
+    lambda: [(random.choice(["X_1_2", "Y_1_2", "W_1_2"]), i) for i in range(nq)],
+    lambda: [("cz", i, i + 1) for i in range(1, nq - 1, 2)],
+])
+g2 = [g for _, layer in zip(range(depth), layers) for g in layer()]
+circ2 = qtn.Circuit(nq, to_backend=qa.asarray, dtype="complex128")
+ref2 = qtn.Circuit(nq)
+circ2.apply_gates(g2)
+ref2.apply_gates(g2)
+n_hyper = 0
+for bits in ("01" * 6, "0" * 12, "110100101101"):
+    tn_b = circ2.amplitude(bits, rehearse="tn")                    # simplified + converted network, not yet contracted
+    assert all(type(t.data) is qa.Array for t in tn_b)
+    n_hyper += sum(1 for tids in tn_b.ind_map.values() if len(tids) > 2)
+    n0 = launched()
+    amp = circ2.amplitude(bits, optimize="greedy")                 # simplify_sequence defaults to "ADCRS"
+    want_amp = ref2.amplitude(bits, optimize="greedy")
+    assert abs(complex(amp) - complex(want_amp)) < 1e-12, (bits, amp, want_amp)
+    assert launched() > n0 or tn_b.num_tensors == 1
+print("hyper indices met in the simplified amplitude networks:", n_hyper)
+assert n_hyper > 0, "the default ADCRS path must have produced hyper-index networks for this circuit family"
+
 print("backend launches:", dev.calls)
 print("DROPIN OK")

@@ -22,16 +22,20 @@ from oracle import np_oracle as orc  # noqa: E402
 
 out_file = os.path.join(HERE, "full_size_oracle.json")
 res = json.load(open(out_file)) if os.path.exists(out_file) else {}
-for seed in [int(s) for s in sys.argv[1:]] or [7]:
-    arrays, inputs = orc.tn2d_rand(10, 10, 6, seed=seed, dtype="float32")       # exactly the bench / test inputs
+# keys: "7" = seed 7 of the reference's 'mostly positive' fill uniform(-0.1, 1); "7@-0.6" = the same generator with
+# low = -0.6 (sign-mixed entries: partial sums cancel, which is where fp32 loses digits -- the test RECORDS the error)
+for key in sys.argv[1:] or ["7"]:
+    seed, low = (key.split("@") + ["-0.1"])[:2]
+    seed, low = int(seed), float(low)
+    arrays, inputs = orc.tn2d_rand(10, 10, 6, seed=seed, low=low, dtype="float32")       # exactly the bench / test inputs
     size = {ix: 6 for t in inputs for ix in t}
     tree = qa.ContractionTree(inputs, (), size, path=qa.sweep_path_2d(10, 10))
     t0 = time.time()
     m, e = orc.oracle_array_contract([a.astype(np.float64) for a in arrays], inputs, (), path=tree.get_path(),
                                      strip_exponent=True)
     m = float(np.asarray(m).item())
-    res[str(seed)] = {"sign": float(np.sign(m)), "log10_abs": float(np.log10(abs(m)) + e),
-                      "seconds": round(time.time() - t0, 1), "Lx": 10, "Ly": 10, "D": 6}
-    print(seed, res[str(seed)], flush=True)
+    res[key] = {"sign": float(np.sign(m)), "log10_abs": float(np.log10(abs(m)) + e),
+                      "seconds": round(time.time() - t0, 1), "Lx": 10, "Ly": 10, "D": 6, "low": low}
+    print(key, res[key], flush=True)
     with open(out_file, "w") as f:
         json.dump(res, f, indent=1, sort_keys=True)

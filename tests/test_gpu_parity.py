@@ -465,3 +465,8 @@ def test_linalg_extras(hip, dtype):
 def test_tensor_methods(hip, dtype):
     """The reference's Tensor-level layout tests (test_tensor_core.py:184-323) on device data."""
     checks.check_tensor_methods(dtype)
+
+
+@pytest.mark.parametrize("dtype", ["float64", "float32", "complex128"])
+def test_gate_and_local_contractions(hip, dtype):
+    checks.check_gate_and_local_contractions(dtype)

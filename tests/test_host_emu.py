@@ -349,3 +349,8 @@ def test_slices_argument_is_validated(emu):
             exs([a, b], slices=bad)
     with pytest.raises(ValueError):
         ex([a, b], slices=[1])
+
+
+@pytest.mark.parametrize("dtype", ["float64", "float32", "complex128"])
+def test_gate_and_local_contractions(emu, dtype):
+    checks.check_gate_and_local_contractions(dtype)
