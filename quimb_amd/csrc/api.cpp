@@ -498,6 +498,86 @@ static int fill_bundle(const std::vector<Dim>& v, uint32_t* dim, int64_t* ss, in
   return 0;
 }
 
+// Plan for permute_stream_kernel (elementwise.hip): the tile is a set of (parts of) dims holding a contiguous
+// run of >= 32 elements on the source side AND on the destination side where the shape allows, <= 4096
+// elements in all; a dim that is too long is split into (outer, inner) and the outer part joins Z, the loop
+// of a workgroup; offsets fit 32 bits.
+static int64_t largest_divisor_le(int64_t n, int64_t limit) {
+  for (int64_t t = std::min(n, limit); t >= 2; --t)
+    if (n % t == 0) return t;
+  return 1;
+}
+
+static bool plan_permute_stream(const std::vector<Dim>& d0, int64_t src_offset, PermArgs& a) {
+  std::vector<Dim> pool = d0, tile;
+  int64_t span_s = 0, span_d = 0;
+  for (const Dim& x : pool) { span_s += (x.n - 1) * std::llabs(x.ss); span_d += (x.n - 1) * x.sd; }
+  if (span_s >= (1ll << 31) || span_d >= (1ll << 31)) return false;
+  for (const Dim& x : pool) if (x.ss <= 0) return false;      // reversed / broadcast views: the general kernel
+  int64_t vol = 1;
+  // move (a part of) pool[idx], at most ``room`` elements, into the tile; the outer remainder stays in the pool
+  auto take = [&](size_t idx, int64_t room) -> bool {
+    Dim x = pool[idx];
+    if (x.n <= room) { tile.push_back(x); vol *= x.n; pool.erase(pool.begin() + idx); return true; }
+    const int64_t t = largest_divisor_le(x.n, room);
+    if (t < 2) return false;
+    tile.push_back(Dim{t, x.ss, x.sd});
+    vol *= t;
+    pool[idx] = Dim{x.n / t, x.ss * t, x.sd * t};
+    return true;
+  };
+  // length of the contiguous run the tile holds on one side: groups chained stride -> stride * n from stride 1
+  auto run_len = [&](bool by_src) -> int64_t {
+    int64_t run = 1;
+    for (bool grown = true; grown;) {
+      grown = false;
+      for (const Dim& x : tile)
+        if ((by_src ? x.ss : x.sd) == run && x.n > 1) { run *= x.n; grown = true; break; }
+    }
+    return run;
+  };
+  // the pool dim that continues that run, or -1
+  auto next_of = [&](bool by_src, int64_t run) -> int {
+    for (size_t i = 0; i < pool.size(); ++i)
+      if ((by_src ? pool[i].ss : pool[i].sd) == run) return (int)i;
+    return -1;
+  };
+  auto grow = [&](bool by_src, int64_t want, int64_t cap) {
+    for (;;) {
+      const int64_t run = run_len(by_src);
+      if (run >= want || vol >= cap) return;
+      const int idx = next_of(by_src, run);
+      if (idx < 0 || !take((size_t)idx, std::min<int64_t>(cap / vol, std::max<int64_t>(2, 4 * want / run)))) return;
+    }
+  };
+  grow(true, 32, 4096);            // a source run of >= 32 elements ...
+  grow(false, 32, 4096);           // ... and a destination run of >= 32
+  for (int round = 0; round < 8 && vol < 2048; ++round) {       // then lengthen both, in turn
+    const int64_t before = vol;
+    grow(true, 2 * run_len(true), 4096);
+    if (vol < 2048) grow(false, 2 * run_len(false), 4096);
+    if (vol == before) break;
+  }
+  if (vol < 512 || run_len(true) < 8) return false;
+  std::stable_sort(tile.begin(), tile.end(), [](const Dim& p, const Dim& q) { return p.ss > q.ss; });   // outermost first
+  memset(&a, 0, sizeof(a));
+  if (fill_bundle(tile, a.dim_x, a.ss_x, a.sd_x, a.nx, a.X)) return false;
+  if (fill_bundle(pool, a.dim_z, a.ss_z, a.sd_z, a.nz, a.Z)) return false;
+  std::vector<int> ord(a.nx);
+  for (int i = 0; i < a.nx; ++i) ord[i] = i;
+  std::stable_sort(ord.begin(), ord.end(), [&](int p, int q) { return a.sd_x[p] < a.sd_x[q]; });
+  a.direct = 1;
+  for (int i = 0; i < a.nx; ++i) {
+    a.xorder[i] = ord[i];
+    if (ord[i] != a.nx - 1 - i) a.direct = 0;       // same order on both sides inside the tile: no LDS stage
+  }
+  a.Y = 1; a.TX = (int32_t)a.X; a.TY = 1; a.tiles_x = a.tiles_y = 1;
+  a.src_offset = src_offset;
+  const uint64_t zsplit = std::max<uint64_t>(1, std::min<uint64_t>(a.Z, 4096));   // ~16 workgroups per CU
+  a.zchunk = (uint32_t)((a.Z + zsplit - 1) / zsplit);
+  return true;
+}
+
 extern "C" int qamd_permute(void* dst, const void* src, int32_t ndim, const int64_t* shape,
                             const int64_t* src_strides, int64_t src_offset, int32_t dtype, void* stream) {
   if (ndim < 0 || ndim > QAMD_MAX_NDIM || dtype < 0 || dtype > 3) return QAMD_EINVAL;
@@ -513,6 +593,15 @@ extern "C" int qamd_permute(void* dst, const void* src, int32_t ndim, const int6
   fuse_dims(d);
   if (d.empty()) d.push_back(Dim{1, 1, 1});
   const int n = (int)d.size();
+  {
+    // the z-looping, offset-caching kernel first (QAMD_PERMUTE_STREAM=0 keeps the tile-per-workgroup one)
+    const char* e = getenv("QAMD_PERMUTE_STREAM");
+    PermArgs ps;
+    if (!(e && e[0] == '0') && plan_permute_stream(d, src_offset, ps)) {
+      int rc = qamd_permute_stream_launch(kEsize[dtype], dst, src, &ps, stream);
+      if (rc != -2) return rc;
+    }
+  }
 
   // src-fastest dim
   int fi = n - 1;

@@ -7,6 +7,7 @@
 //  * strided sum-reduction, strided binary op, scale/axpby/conj/cast/fill,
 //    absmax + exponent stripping (tensor_core.py:330-340 semantics).
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <stdint.h>
 #include "ew_args.h"
 
@@ -105,6 +106,112 @@ __global__ __launch_bounds__(256) void permute_kernel(T* __restrict__ dst, const
     int y = e % p.TY, x = e / p.TY;
     int64_t a = xd[x], b = yd[y];
     if (a != kNone && b != kNone) dst[zd + a + b] = tile[y * pitch + x];
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Streaming permute.  The TILE is a set of (parts of) dims -- bundle X, listed in source order -- chosen by
+// the host so that it holds a long contiguous run on the source side AND on the destination side
+// (plan_permute_stream, api.cpp); everything else is bundle Z, and a workgroup walks a whole chunk of z
+// values with the same tile geometry.  Per-element address work is done ONCE per workgroup: every thread
+// caches, in registers, the 32-bit source offset / destination offset / LDS slots of its <= 16 elements
+// (element e of the tile in SOURCE order when reading, in DESTINATION order when writing: both sides see
+// whole contiguous runs whatever the permutation inside the tile is).  Per z a thread issues its loads back
+// to back -- the NEXT z's loads go out before this z's tile is written, so up to 2 x 16 KB of reads are in
+// flight per workgroup -- scatters them into a skewed LDS tile and writes them out.  ``direct``: the two
+// orders coincide inside the tile, no LDS stage.
+// ---------------------------------------------------------------------------
+template <typename T, int EPT>
+__global__ __launch_bounds__(256) void permute_stream_kernel(T* __restrict__ dst, const T* __restrict__ src,
+                                                              const PermArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem_s[];
+  T* tile = reinterpret_cast<T*>(smem_s);
+  const int tid = threadIdx.x;
+  const uint32_t z0 = blockIdx.x * p.zchunk;
+  const uint32_t z1 = min(p.Z, z0 + p.zchunk);
+  if (z0 >= z1) return;
+  constexpr int32_t kNone = INT32_MIN;
+  const int total = (int)p.X;
+  // LDS rows = the innermost source group, padded to an odd pitch: lanes that walk ACROSS rows when writing
+  // out (any destination order) then hit distinct banks
+  const uint32_t inner = p.dim_x[p.nx - 1];
+  const uint32_t skew = (inner & 1) ? 0x7fffffffu : inner;
+
+  int32_t so[EPT], dofs[EPT];
+  uint32_t slots[EPT];                               // (LDS slot written) | (LDS slot read) << 16
+#pragma unroll
+  for (int i = 0; i < EPT; ++i) {
+    const int e = tid + 256 * i;
+    so[i] = kNone;
+    dofs[i] = kNone;
+    slots[i] = 0;
+    if (e < total) {
+      so[i] = (int32_t)decomp1((uint32_t)e, p.nx, p.dim_x, p.ss_x);
+      if (p.direct) {
+        dofs[i] = (int32_t)decomp1((uint32_t)e, p.nx, p.dim_x, p.sd_x);
+      } else {
+        // e enumerates the tile in DESTINATION order: digits over the groups sorted by destination stride
+        uint32_t idx = (uint32_t)e, pos = 0;
+        int64_t off = 0;
+        for (int k = 0; k < p.nx; ++k) {
+          const int g = p.xorder[k];
+          const uint32_t d = p.dim_x[g];
+          const uint32_t q = idx / d, r = idx - q * d;
+          off += (int64_t)r * p.sd_x[g];
+          uint32_t place = 1;                      // place value of group g in the source-order linear index
+          for (int h = g + 1; h < p.nx; ++h) place *= p.dim_x[h];
+          pos += r * place;
+          idx = q;
+        }
+        dofs[i] = (int32_t)off;
+        slots[i] = ((uint32_t)e + (uint32_t)e / skew) | ((pos + pos / skew) << 16);
+      }
+    }
+  }
+
+  auto zbases = [&](uint32_t z, int64_t& zs, int64_t& zd) {
+    zs = p.src_offset;
+    zd = 0;
+    uint32_t idx = z;
+    for (int g = p.nz - 1; g >= 0; --g) {
+      const uint32_t d = p.dim_z[g];
+      const uint32_t q = idx / d, r = idx - q * d;
+      zs += (int64_t)r * p.ss_z[g];
+      zd += (int64_t)r * p.sd_z[g];
+      idx = q;
+    }
+  };
+
+  T cur[EPT], nxt[EPT];
+  int64_t zs, zd;
+  zbases(z0, zs, zd);
+#pragma unroll
+  for (int i = 0; i < EPT; ++i)
+    if (so[i] != kNone) cur[i] = src[zs + so[i]];
+  for (uint32_t z = z0; z < z1; ++z) {
+    const int64_t zd_cur = zd;
+    if (z + 1 < z1) {
+      zbases(z + 1, zs, zd);
+#pragma unroll
+      for (int i = 0; i < EPT; ++i)
+        if (so[i] != kNone) nxt[i] = src[zs + so[i]];
+    }
+    if (p.direct) {
+#pragma unroll
+      for (int i = 0; i < EPT; ++i)
+        if (dofs[i] != kNone) dst[zd_cur + dofs[i]] = cur[i];
+    } else {
+      if (z != z0) __syncthreads();                  // the previous tile has been read out
+#pragma unroll
+      for (int i = 0; i < EPT; ++i)
+        if (so[i] != kNone) tile[slots[i] & 0xffffu] = cur[i];
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < EPT; ++i)
+        if (dofs[i] != kNone) dst[zd_cur + dofs[i]] = tile[slots[i] >> 16];
+    }
+#pragma unroll
+    for (int i = 0; i < EPT; ++i) cur[i] = nxt[i];
   }
 }
 
@@ -410,6 +517,25 @@ extern "C" int qamd_permute_launch(int esize, void* dst, const void* src, const 
     case 16: QAMD_LAUNCH(permute_kernel<c128>, dim3((uint32_t)grid), dim3(256), lds, st, (c128*)dst, (const c128*)src, *p); break;
     default: return -2;
   }
+  QAMD_CHECK_LAUNCH();
+}
+
+extern "C" int qamd_permute_stream_launch(int esize, void* dst, const void* src, const PermArgs* p, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  const uint64_t grid = (p->Z + p->zchunk - 1) / p->zchunk;
+  if (grid == 0 || grid > 0x7fffffffull) return -1;
+  const int total = (int)p->X;
+  if (total > 4096) return -2;
+  const size_t lds = (size_t)(total + total / std::max<uint32_t>(p->dim_x[p->nx - 1], 1) + 2) * esize;
+#define QAMD_PS(T, E) QAMD_LAUNCH((permute_stream_kernel<T, E>), dim3((uint32_t)grid), dim3(256), lds, st, (T*)dst, (const T*)src, *p)
+  const int ept = (total + 255) / 256;
+  switch (esize) {
+    case 4: if (ept <= 8) QAMD_PS(float, 8); else QAMD_PS(float, 16); break;
+    case 8: if (ept <= 8) QAMD_PS(double, 8); else QAMD_PS(double, 16); break;
+    case 16: if (ept <= 8) QAMD_PS(c128, 8); else QAMD_PS(c128, 16); break;
+    default: return -2;
+  }
+#undef QAMD_PS
   QAMD_CHECK_LAUNCH();
 }
 

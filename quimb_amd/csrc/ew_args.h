@@ -15,6 +15,9 @@ struct PermArgs {
   int64_t ss_y[QAMD_PG], sd_y[QAMD_PG];
   int64_t ss_z[QAMD_PG], sd_z[QAMD_PG];
   int64_t src_offset;
+  // permute_stream_kernel: bundle X = the tile's groups in source order, Z = the loop; see elementwise.hip
+  int32_t xorder[QAMD_PG];   // X groups sorted by destination stride, fastest first
+  uint32_t zchunk;     // z values per workgroup
 };
 
 struct ReduceArgs {
@@ -35,6 +38,7 @@ struct BinaryArgs {
 extern "C" {
 #endif
 int qamd_permute_launch(int esize, void* dst, const void* src, const PermArgs* p, void* stream);
+int qamd_permute_stream_launch(int esize, void* dst, const void* src, const PermArgs* p, void* stream);
 int qamd_reduce_sum_launch(int dtype, void* out, const void* x, const ReduceArgs* p, void* stream);
 int qamd_binary_launch(int dtype, void* out, const void* a, const void* b, const BinaryArgs* p, void* stream);
 #ifdef __cplusplus

@@ -65,3 +65,25 @@ def test_fuse_rule():
     assert y.shape == (24, 10, 3)
     np.testing.assert_array_equal(y, np.transpose(x, (4, 2, 3, 0, 1)).reshape(24, 10, 3))
     np.testing.assert_array_equal(orc.oracle_fuse(x, (1, 2)), x.reshape(2, 12, 5, 6))
+
+
+def test_bench_generator_matches_oracle_generator():
+    """bench.py builds its input itself (the product bench must not depend on the checker); the tensors have to be
+    the oracle generator's, bit for bit -- tests/golden/full_size_oracle.json is keyed on them."""
+    import importlib.util
+    import os
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    from oracle import np_oracle as orc
+
+    for (Lx, Ly, D, seed, low) in [(3, 4, 3, 7, -0.1), (4, 3, 2, 0, -0.6), (2, 2, 6, 3, -0.1)]:
+        a1, i1 = bench.tn2d_rand(Lx, Ly, D, seed=seed, low=low, dtype="float32")
+        a2, i2 = orc.tn2d_rand(Lx, Ly, D, seed=seed, low=low, dtype="float32")
+        assert [t.shape for t in a1] == [t.shape for t in a2]
+        assert all(np.array_equal(x, y) for x, y in zip(a1, a2))
+        # same network structure (index names may differ): same sharing pattern
+        rel = lambda ins: [[[j for j, u in enumerate(ins) if ix in u] for ix in t] for t in ins]
+        assert rel(i1) == rel([tuple(t) for t in i2])
