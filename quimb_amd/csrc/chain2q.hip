@@ -40,7 +40,12 @@ typedef float q_vec4 __attribute__((ext_vector_type(4), aligned(16)));
 typedef const __attribute__((address_space(1))) char* q_gptr_t;
 
 __device__ __forceinline__ float qload(uint64_t sbase, uint32_t voff) {
+#ifdef QAMD_C2Q_NT_LOADS   // experiment: every row is read once, by one wave, as whole 256-byte runs
+  return __builtin_nontemporal_load(
+      reinterpret_cast<const __attribute__((address_space(1))) float*>(reinterpret_cast<q_gptr_t>(sbase) + voff));
+#else
   return *reinterpret_cast<const __attribute__((address_space(1))) float*>(reinterpret_cast<q_gptr_t>(sbase) + voff);
+#endif
 }
 
 __device__ __forceinline__ float qread_scale(const float* slots) {
@@ -100,7 +105,11 @@ __global__ __launch_bounds__(256, 1) void chain2q_kernel(const Chain2Args p, con
   constexpr int NH = K1D == 2 ? D : 1;           // values of the outer k1 index
   constexpr int NT1 = DD / 4;                    // stage-1 row tiles (rows = (x, y))
   constexpr int ROWS = D * K1;                   // A rows of one chunk, consumed in the order (v, k1)
+#ifdef QAMD_C2Q_RING54
+  constexpr int RING = (ROWS > 54 && ROWS % 54 == 0) ? 54 : ((ROWS <= 48) ? ROWS : ROWS / 2);
+#else
   constexpr int RING = (ROWS > 108 && ROWS % 108 == 0) ? 108 : ((ROWS <= 48) ? ROWS : ROWS / 2);   // rows in flight
+#endif
   static_assert(ROWS % RING == 0 && RING % D == 0, "ring positions must repeat from chunk to chunk, in whole row groups");
   constexpr int NO = NOD ? D : 1;
   constexpr int GN = NOD ? ((D % 4 == 0) ? 1 : 2) : 1;   // `no` values per stage-2 group

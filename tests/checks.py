@@ -1431,3 +1431,30 @@ def check_gate_and_local_contractions(dtype="float64"):
     hyper = qa.array_contract([arrays[0], rand(rng, (3, 4), dtype)], [("i", "j"), ("i", "j")], ("i",),
                               implementation=qa.implementation_pair())        # batch index -> the einsum callable
     assert hyper.shape == (3,)
+
+
+def check_linop_full_chi(chi=512, dtype="float64"):
+    """BASELINE config #5 at its real bond dimension: the chi = 512 effective-Hamiltonian matvec (1.1e10 FLOP, a
+    2^20-dimensional operator that cannot be formed densely) against the same contraction done by numpy in
+    float64, staged the way the reference's greedy path does it (L into x, then W1, W2, R); plain call and
+    hipGraph replay, random vectors."""
+    tensors, left, right = dmrg_effective_ham(chi, dtype=dtype)
+    (L, _), (W1, _), (W2, _), (R, _) = tensors
+    n = chi * 2 * 2 * chi
+    rng = np.random.default_rng(5)
+    A = qa.TNLinearOperator(tensors, left, right, optimize="random-greedy")
+    Ag = qa.TNLinearOperator(tensors, left, right, optimize="random-greedy", graph=True)
+
+    def ref(x):
+        x4 = x.astype(np.float64).reshape(chi, 2, 2, chi)                 # x[A, S1, S2, B]
+        t = np.tensordot(L.astype(np.float64), x4, axes=([2], [0]))        # [a, p, S1, S2, B]
+        t = np.einsum("apSTB,pqsS->aqsTB", t, W1.astype(np.float64), optimize=True)
+        t = np.einsum("aqsTB,qrtT->arstB", t, W2.astype(np.float64), optimize=True)
+        t = np.einsum("arstB,brB->astb", t, R.astype(np.float64), optimize=True)
+        return t.reshape(n)
+
+    for k in range(2):
+        x = rand(rng, (n,), dtype)
+        want = ref(x)
+        assert_close(A.matvec(x), want, dtype)
+        assert_close((Ag @ qa.asarray(x)).to_numpy(), want, dtype)

@@ -415,8 +415,23 @@ def test_full_size_10x10_D6_properties(hip):
     # 1e-6 relative = 4.3e-7 in log10
     import json
 
-    ref = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "full_size_oracle.json")))["7"]
+    refs = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "full_size_oracle.json")))
+    ref = refs["7"]
     assert s0 == ref["sign"] and abs(l0 - ref["log10_abs"]) < np.log10(1.0 + 1e-6)
+    # further networks of the same family (other seeds): the same 1e-6 bar; and a SIGN-MIXED fill ("7@-0.6":
+    # entries uniform in [-0.6, 1], partial sums cancel), whose achieved error is recorded, not hidden -- the
+    # bar for it is what an fp32 k-ordered accumulation of a 99-step tree can promise (1e-5), printed with -s
+    achieved = {}
+    for key, r in sorted(refs.items()):
+        if key == "7" or (r["Lx"], r["Ly"], r["D"]) != (10, 10, 6):
+            continue
+        seed, low = (key.split("@") + ["-0.1"])[:2]
+        arr_k, _ = orc.tn2d_rand(10, 10, 6, seed=int(seed), low=float(low), dtype="float32")
+        sk, lk = log_value(ex(arr_k, strip_exponent=True))
+        achieved[key] = abs(10.0 ** (lk - r["log10_abs"]) - 1.0)
+        assert sk == r["sign"], key
+        assert achieved[key] < (1e-6 if float(low) >= -0.1 else 1e-5), (key, achieved[key])
+    print("full-size fp32 relative errors vs the fp64 oracle:", {k: f"{v:.2e}" for k, v in achieved.items()})
     # reproducibility: same executor, same inputs -> bit-identical (no atomics in the data path)
     assert log_value(ex(arrays, strip_exponent=True)) == (s0, l0)
     # fused pairs (chain2r) against one launch per step (sweep kernels)
@@ -470,3 +485,8 @@ def test_tensor_methods(hip, dtype):
 @pytest.mark.parametrize("dtype", ["float64", "float32", "complex128"])
 def test_gate_and_local_contractions(hip, dtype):
     checks.check_gate_and_local_contractions(dtype)
+
+
+def test_linop_chi512_parity(hip):
+    """The chi = 512 TNLinearOperator of BASELINE config #5 (timed since round 1) is now also CHECKED."""
+    checks.check_linop_full_chi(512, "float64")
