@@ -10,6 +10,8 @@ part of this build, so the executor ships its own finders:
 * ``sweep_path_2d``    -- row-by-row, site-by-site boundary sweep of an Lx x Ly grid
 * ``find_slices``      -- greedy choice of sliced indices (what cotengra's
                           SliceFinder does) so that the slices can be sharded
+* ``modeled_time``     -- roofline time of the executor's plan for a tree; ``minimize="time"`` /
+                          ``optimize="auto-time"`` make the finders intensity-aware
 * ``set_tree_cache``   -- on-disk cache of found trees keyed by ``geometry_hash``
 """
 
@@ -109,8 +111,10 @@ def greedy_path(inputs, output, size_dict):
     return ssa_to_linear(greedy_ssa(inputs, output, size_dict), n)
 
 
-def random_greedy(inputs, output, size_dict, repeats=32, seed=0, temperature=0.3):
-    """Best of ``repeats`` perturbed greedy runs (by total multiplications)."""
+def random_greedy(inputs, output, size_dict, repeats=32, seed=0, temperature=0.3, minimize="flops", dtype="float32"):
+    """Best of ``repeats`` perturbed greedy runs: by total multiplications (``minimize="flops"``, what
+    cotengra's default objective does) or by ``modeled_time`` (``"time"``: bytes moved and launch count matter
+    as much as multiplications for the HBM-bound steps that dominate boundary-like networks)."""
     rng = random.Random(seed)
     best, best_cost = None, None
     for r in range(max(1, repeats)):
@@ -121,10 +125,44 @@ def random_greedy(inputs, output, size_dict, repeats=32, seed=0, temperature=0.3
             costmod=1.0 if r == 0 else rng.choice([0.5, 1.0, 1.0, 2.0]),
         )
         tree = ContractionTree(inputs, output, size_dict, ssa_path=ssa)
-        c = tree.contraction_cost()
+        c = tree.contraction_cost() if minimize == "flops" else modeled_time(tree, dtype)
         if best_cost is None or c < best_cost:
             best, best_cost = tree, c
     return best
+
+
+# gfx950 roofs the time model prices a step against (MI355X_MICROARCH.md: dense MFMA peaks, achievable HBM copy rate)
+_PEAK_FLOPS = {"float32": 157.3e12, "float64": 78.6e12, "complex64": 157.3e12, "complex128": 78.6e12}
+_HBM_BYTES_PER_S = 6.29e12
+_LAUNCH_S = 4e-6
+
+
+def modeled_time(tree, dtype="float32"):
+    """Roofline estimate of executing ``tree`` on one MI355X: every launch of the plan the whole-tree executor
+    would issue costs ``max(flops / MFMA peak, algorithmic bytes / HBM rate) + launch``, slices repeated -- the
+    objective of the intensity-aware finders.  Fused pairs (two big-x-small steps in
+    one pass, chain2q.hip) count with the bytes they actually move, so an order that lines such pairs up is
+    cheaper than one with the same multiplication count that does not."""
+    import numpy as np
+
+    from .executor import TreeExecutor   # planning only: no device is touched
+
+    ex = TreeExecutor(tree, dtype)
+    name = np.dtype(dtype).name
+    f = 8 if np.dtype(dtype).kind == "c" else 2
+    ns = tree.nslices
+    t = 0.0
+    for inf in ex.info:
+        rep = ns if inf.sliced_dep else 1
+        t += rep * (max(f * inf.mults / _PEAK_FLOPS[name], inf.bytes / _HBM_BYTES_PER_S) + _LAUNCH_S)
+    return t
+
+
+def fused_pair_count(tree, dtype="float32"):
+    """Launches of the executor's plan that are fused pairs / triples of streaming steps."""
+    from .executor import TreeExecutor
+
+    return sum(1 for e in TreeExecutor(tree, dtype).plan if e[0] in ("chain2", "chain3"))
 
 
 def sweep_ssa_2d(Lx, Ly):
@@ -186,7 +224,7 @@ def find_path(inputs, output, size_dict, optimize="greedy"):
     if hasattr(optimize, "get_path") and hasattr(optimize, "size_dict"):
         return ContractionTree.from_any(optimize, inputs, output, size_dict)
     if isinstance(optimize, str):
-        if optimize not in ("greedy", "auto", "auto-hq", "random-greedy"):
+        if optimize not in ("greedy", "auto", "auto-hq", "random-greedy", "auto-time"):
             raise ValueError(f"unknown contraction strategy {optimize!r}")
         path_file = _cache_file(inputs, output, size_dict, optimize)
         if path_file and os.path.exists(path_file):
@@ -198,6 +236,8 @@ def find_path(inputs, output, size_dict, optimize="greedy"):
                 pass                                        # unreadable / stale entry: search again
         if optimize in ("greedy", "auto"):
             tree = ContractionTree(inputs, output, size_dict, ssa_path=greedy_ssa(inputs, output, size_dict))
+        elif optimize == "auto-time":
+            tree = random_greedy(inputs, output, size_dict, repeats=32, minimize="time")
         else:
             tree = random_greedy(inputs, output, size_dict, repeats=64 if optimize == "auto-hq" else 32)
         if path_file:
@@ -215,10 +255,11 @@ def find_path(inputs, output, size_dict, optimize="greedy"):
     return ContractionTree(inputs, output, size_dict, path=list(optimize))
 
 
-def find_slices(tree, target_slices=None, target_size=None, max_slices=1 << 20):
+def find_slices(tree, target_slices=None, target_size=None, max_slices=1 << 20, minimize="flops", dtype="float32"):
     """Greedily pick indices to slice: at every round take the index whose
-    removal gives the lowest total cost (per-slice cost x number of slices),
-    until ``target_slices`` slices / ``target_size`` max intermediate is reached."""
+    removal gives the lowest total cost (per-slice cost x number of slices; ``minimize="time"``: the lowest
+    ``modeled_time``, hoisted steps counted once), until ``target_slices`` slices / ``target_size`` max
+    intermediate is reached."""
     if target_slices is None and target_size is None:
         raise ValueError("need target_slices or target_size")
     sliced = list(tree.sliced_inds)
@@ -245,7 +286,7 @@ def find_slices(tree, target_slices=None, target_size=None, max_slices=1 << 20):
         best = None
         for ix in sorted(cands, key=repr):
             t = tree.with_slices(sliced + [ix])
-            key = (t.contraction_cost(), t.max_size())
+            key = ((t.contraction_cost() if minimize == "flops" else modeled_time(t, dtype)), t.max_size())
             if best is None or key < best[0]:
                 best = (key, ix, t)
         sliced.append(best[1])

@@ -354,3 +354,28 @@ def test_slices_argument_is_validated(emu):
 @pytest.mark.parametrize("dtype", ["float64", "float32", "complex128"])
 def test_gate_and_local_contractions(emu, dtype):
     checks.check_gate_and_local_contractions(dtype)
+
+
+def test_intensity_aware_finders(emu):
+    """``modeled_time`` prices the executor's plan against the MFMA and HBM roofs; ``optimize="auto-time"`` /
+    ``minimize="time"`` search with it instead of the multiplication count."""
+    from oracle import np_oracle as orc
+    import quimb_amd as qa
+
+    arrays, inputs = orc.tn2d_rand(5, 5, 3, seed=3, dtype="float64")
+    inputs = [tuple(t) for t in inputs]
+    size = {ix: 3 for t in inputs for ix in t}
+    by_flops = qa.find_path(inputs, (), size, "random-greedy")
+    by_time = qa.find_path(inputs, (), size, "auto-time")
+    assert qa.modeled_time(by_time, "float64") <= qa.modeled_time(by_flops, "float64") * 1.0001
+    assert by_flops.contraction_cost() <= by_time.contraction_cost() * 1.0001
+    want = orc.oracle_array_contract(arrays, inputs, ()).item()
+    assert qa.TreeExecutor(by_time, "float64")(arrays).to_numpy().item() == pytest.approx(want, rel=1e-10)
+    sl = qa.find_slices(by_time, target_slices=9, minimize="time", dtype="float64")
+    assert sl.nslices >= 9
+    assert qa.TreeExecutor(sl, "float64")(arrays).to_numpy().item() == pytest.approx(want, rel=1e-10)
+    # the headline network: the site-by-site sweep is 40 fused pairs, HBM-bound: 12-20 ms by the model
+    _, big = orc.tn2d_rand(10, 10, 2, seed=1)
+    big = [tuple(t) for t in big]
+    sweep = qa.ContractionTree(big, (), {ix: 6 for t in big for ix in t}, path=qa.sweep_path_2d(10, 10))
+    assert qa.fused_pair_count(sweep) == 40 and 0.010 < qa.modeled_time(sweep) < 0.022
