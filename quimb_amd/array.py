@@ -253,11 +253,15 @@ class Array:
         return self._binary(other, "sub", reflected=True)
 
     def __truediv__(self, other):
-        if isinstance(other, Array) and other.size == 1:
-            other = other.item()
-        if isinstance(other, numbers.Number):
-            return self._scaled(1.0 / other)
-        return NotImplemented
+        """Elementwise TRUE division (scalar, array, broadcasting): ``x / c`` is computed as x / c, not x * (1 / c)."""
+        if self.dtype.kind not in "fc":
+            return self.astype("float64") / other
+        return self._binary(other, "div")
+
+    def __rtruediv__(self, other):
+        if self.dtype.kind not in "fc":
+            return other / self.astype("float64")
+        return self._binary(other, "div", reflected=True)
 
     def __abs__(self):
         from . import ops
@@ -273,8 +277,12 @@ class Array:
     def __pow__(self, p):
         if self.size == 1 and isinstance(p, numbers.Number):
             return Array.from_numpy(np.asarray(self.item() ** p).reshape(self.shape), dev=self._dev)
-        if isinstance(p, numbers.Integral) and p == 2:
-            return self * self
+        if isinstance(p, numbers.Integral):
+            from . import ops
+
+            if p >= 0:
+                return ops.power(self, int(p))
+            return 1.0 / ops.power(self, int(-p))
         return NotImplemented
 
     def __matmul__(self, other):

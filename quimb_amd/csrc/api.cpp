@@ -683,7 +683,7 @@ extern "C" int qamd_reduce_sum(void* out, const void* x, int32_t ndk, const int6
 
 extern "C" int qamd_binary(void* out, const void* x, const int64_t* xs, const void* y, const int64_t* ys,
                            int32_t ndim, const int64_t* shape, int32_t op, int32_t dtype, void* stream) {
-  if (ndim < 0 || ndim > QAMD_MAX_NDIM || dtype < 0 || dtype > 3 || op < 0 || op > 2) return QAMD_EINVAL;
+  if (ndim < 0 || ndim > QAMD_MAX_NDIM || dtype < 0 || dtype > 3 || op < 0 || op > 3) return QAMD_EINVAL;   // 0 add, 1 mul, 2 sub, 3 true division
   // fuse adjacent dims where both operands allow it
   struct D3 { int64_t n, sa, sb; };
   std::vector<D3> v;

@@ -232,6 +232,17 @@ __device__ __forceinline__ float sub(float a, float b) { return a - b; }
 __device__ __forceinline__ double sub(double a, double b) { return a - b; }
 __device__ __forceinline__ c64 sub(c64 a, c64 b) { return c64{a.re - b.re, a.im - b.im}; }
 __device__ __forceinline__ c128 sub(c128 a, c128 b) { return c128{a.re - b.re, a.im - b.im}; }
+// true division (op 3 of the binary kernel): IEEE a / b, not a * (1 / b)
+__device__ __forceinline__ float div_(float a, float b) { return a / b; }
+__device__ __forceinline__ double div_(double a, double b) { return a / b; }
+__device__ __forceinline__ c64 div_(c64 a, c64 b) {
+  const float d = b.re * b.re + b.im * b.im;
+  return c64{(a.re * b.re + a.im * b.im) / d, (a.im * b.re - a.re * b.im) / d};
+}
+__device__ __forceinline__ c128 div_(c128 a, c128 b) {
+  const double d = b.re * b.re + b.im * b.im;
+  return c128{(a.re * b.re + a.im * b.im) / d, (a.im * b.re - a.re * b.im) / d};
+}
 __device__ __forceinline__ float mul(float a, float b) { return a * b; }
 __device__ __forceinline__ double mul(double a, double b) { return a * b; }
 __device__ __forceinline__ c64 mul(c64 a, c64 b) {
@@ -295,7 +306,7 @@ __global__ __launch_bounds__(256) void binary_kernel(T* __restrict__ out, const 
       idx = q;
     }
     T va = a[oa], vb = b[ob];
-    out[i] = p.op == 0 ? add(va, vb) : (p.op == 1 ? mul(va, vb) : sub(va, vb));
+    out[i] = p.op == 0 ? add(va, vb) : (p.op == 1 ? mul(va, vb) : (p.op == 2 ? sub(va, vb) : div_(va, vb)));
   }
 }
 

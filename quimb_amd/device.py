@@ -324,7 +324,7 @@ class HipDevice:
         _lib.check(
             self.lib.qamd_binary(
                 out.data_ptr(), a.data_ptr(), _i64arr(a_strides), b.data_ptr(), _i64arr(b_strides),
-                len(shape), _i64arr(shape), {"add": 0, "mul": 1, "sub": 2}[op], dtype_code(dtype), self.stream(),
+                len(shape), _i64arr(shape), {"add": 0, "mul": 1, "sub": 2, "div": 3}[op], dtype_code(dtype), self.stream(),
             ),
             "qamd_binary",
         )

@@ -113,10 +113,22 @@ class DMRG2:
 
     # ---- schedules --------------------------------------------------------------------------------------
     def _set_seq(self, bond_dims, cutoffs):
-        bds = (bond_dims,) if isinstance(bond_dims, (int, np.integer)) else tuple(bond_dims)
-        cts = (cutoffs,) if isinstance(cutoffs, float) else tuple(cutoffs)
+        self._set_bond_dim_seq(bond_dims)
+        self._set_cutoff_seq(cutoffs)
+
+    # the two schedules are independent, as in the reference (tn1d/dmrg.py:596-603): passing one to ``solve`` leaves
+    # the other where it is (a scalar of either kind -- int, float, numpy scalar -- is a one-element schedule)
+    def _set_bond_dim_seq(self, bond_dims):
+        import numbers
+
+        bds = (bond_dims,) if isinstance(bond_dims, numbers.Real) else tuple(bond_dims)
         self._bond_dim0 = int(bds[0])
         self._bond_dims = itertools.chain(bds, itertools.repeat(bds[-1]))
+
+    def _set_cutoff_seq(self, cutoffs):
+        import numbers
+
+        cts = (cutoffs,) if isinstance(cutoffs, numbers.Real) else tuple(cutoffs)
         self._cutoffs = itertools.chain(cts, itertools.repeat(cts[-1]))
 
     @property
@@ -238,9 +250,10 @@ class DMRG2:
     def solve(self, tol=1e-4, bond_dims=None, cutoffs=None, sweep_sequence=None, max_sweeps=10, verbosity=0):
         """Sweep until the energy changes by less than ``tol`` between sweeps (absolute, dmrg.py:1024-1028) or
         ``max_sweeps`` is reached; returns whether it converged."""
-        if bond_dims is not None or cutoffs is not None:
-            self._set_seq(bond_dims if bond_dims is not None else self._bond_dim0,
-                          cutoffs if cutoffs is not None else 1e-9)
+        if bond_dims is not None:
+            self._set_bond_dim_seq(bond_dims)
+        if cutoffs is not None:
+            self._set_cutoff_seq(cutoffs)
         seq = sweep_sequence or self.opts["default_sweep_sequence"]
         previous = "0"
         for k in range(max_sweeps):

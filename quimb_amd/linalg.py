@@ -78,7 +78,15 @@ def svd_via_eig(x, max_bond=-1):
     w, v = eigh(g)                                    # ascending; the spectrum (min(m, n) numbers) goes to the host
     wh = w.to_numpy().astype(np.float64)[::-1]
     k = len(wh) if max_bond is None or max_bond < 0 else min(int(max_bond), len(wh))
-    sh = np.sqrt(np.clip(wh[:k], 0.0, None))
+    # rank-revealing: directions with s <= 4 sqrt(eps) * s_max (zero, noise-level or clipped-negative eigenvalues) carry no vector this
+    # route can normalise -- keeping them would hand back "orthogonal" factors that are not (a rank-1 6x5 input
+    # gave |U^T U - I| = 1).  They are dropped, as a rank-revealing SVD would; at least one direction stays.
+    s_all = np.sqrt(np.clip(wh, 0.0, None))
+    eps = np.finfo(np.dtype(w.dtype.name if hasattr(w.dtype, "name") else w.dtype)).eps
+    # (through the Gram matrix the noise floor of an eigenvalue is eps * s_max^2, i.e. sqrt(eps) * s_max for s)
+    keep = int(np.count_nonzero(s_all > 4.0 * np.sqrt(eps) * float(s_all[0]))) if s_all.size and s_all[0] > 0 else 1
+    k = max(1, min(k, keep))
+    sh = s_all[:k]
     V = v[:, ::-1][:, :k] if k < len(wh) else v[:, ::-1]          # columns by descending eigenvalue
     sinv = np.where(sh > 0, 1.0 / np.where(sh > 0, sh, 1.0), 0.0)
     S = Array.from_numpy(sh.astype(w.dtype), dev=x._dev)

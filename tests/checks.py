@@ -1458,3 +1458,40 @@ def check_linop_full_chi(chi=512, dtype="float64"):
         want = ref(x)
         assert_close(A.matvec(x), want, dtype)
         assert_close((Ag @ qa.asarray(x)).to_numpy(), want, dtype)
+
+
+def check_advice_low_items():
+    """Array / Array, scalar / Array, integer powers (true division, elementwise); svd_via_eig on a rank-deficient
+    matrix returns isometric factors (fewer columns); DMRG2.solve updates only the schedule it is given."""
+    import itertools
+
+    import quimb_amd as qa
+    from quimb_amd import linalg
+
+    rng = np.random.default_rng(4)
+    a, b = rng.uniform(0.5, 2.0, (3, 4)), rng.uniform(0.5, 2.0, (3, 4))
+    A, B = qa.asarray(a), qa.asarray(b)
+    np.testing.assert_array_equal((A / B).to_numpy(), a / b)
+    np.testing.assert_array_equal((A / 3.0).to_numpy(), a / 3.0)                    # true division, not x * (1/3)
+    np.testing.assert_array_equal((2.0 / A).to_numpy(), 2.0 / a)
+    np.testing.assert_array_equal((A / b[0]).to_numpy(), a / b[0])                    # broadcasting, numpy divisor
+    np.testing.assert_allclose((A ** 3).to_numpy(), a**3, rtol=1e-14)
+    np.testing.assert_allclose((A ** -2).to_numpy(), a**-2.0, rtol=1e-14)
+    np.testing.assert_array_equal(qa.divide(A, B).to_numpy(), a / b)
+    c = a + 1j * b
+    np.testing.assert_allclose((qa.asarray(c) / qa.asarray(b + 1j * a)).to_numpy(), c / (b + 1j * a), rtol=1e-14)
+    # rank-1 6 x 5 matrix through the Gram route: one direction, isometric factors, exact product
+    x = np.outer(rng.standard_normal(6), rng.standard_normal(5))
+    U, s, VH = linalg.svd_via_eig(qa.asarray(x))
+    U, s, VH = U.to_numpy(), s.to_numpy(), VH.to_numpy()
+    assert s.shape == (1,) and U.shape == (6, 1) and VH.shape == (1, 5)
+    np.testing.assert_allclose(U.T @ U, np.eye(1), atol=1e-12)
+    np.testing.assert_allclose(VH @ VH.T, np.eye(1), atol=1e-12)
+    np.testing.assert_allclose((U * s) @ VH, x, atol=1e-12)
+    # schedules
+    d = qa.DMRG2(qa.mpo_ham_heis(4), bond_dims=[4, 8, 16], cutoffs=1e-8)
+    d.solve(max_sweeps=1, cutoffs=0)                                                   # an int cutoff is a scalar
+    assert list(itertools.islice(d._bond_dims, 3)) == [8, 16, 16]                     # the ramp went on, not back to 4
+    assert next(d._cutoffs) == 0
+    d.solve(max_sweeps=1, bond_dims=6)
+    assert next(d._bond_dims) == 6 and next(d._cutoffs) == 0                          # the cutoff schedule is untouched

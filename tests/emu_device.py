@@ -145,7 +145,7 @@ class EmuDevice:
         oa = _offsets([(d, s) for d, s in zip(shape, a_strides)], 1)
         ob = _offsets([(d, s) for d, s in zip(shape, b_strides)], 1)
         va, vb = a[oa], b[ob]
-        out[: oa.size] = va + vb if op == "add" else (va * vb if op == "mul" else va - vb)
+        out[: oa.size] = {"add": np.add, "mul": np.multiply, "sub": np.subtract, "div": np.true_divide}[op](va, vb)
 
     def scale(self, x, n, factor, dtype):
         f = complex(factor)

@@ -490,3 +490,7 @@ def test_gate_and_local_contractions(hip, dtype):
 def test_linop_chi512_parity(hip):
     """The chi = 512 TNLinearOperator of BASELINE config #5 (timed since round 1) is now also CHECKED."""
     checks.check_linop_full_chi(512, "float64")
+
+
+def test_advice_round1_low_items(hip):
+    checks.check_advice_low_items()

@@ -379,3 +379,7 @@ def test_intensity_aware_finders(emu):
     big = [tuple(t) for t in big]
     sweep = qa.ContractionTree(big, (), {ix: 6 for t in big for ix in t}, path=qa.sweep_path_2d(10, 10))
     assert qa.fused_pair_count(sweep) == 40 and 0.010 < qa.modeled_time(sweep) < 0.022
+
+
+def test_advice_round1_low_items(emu):
+    checks.check_advice_low_items()
