@@ -214,7 +214,14 @@ class Array:
         if isinstance(other, numbers.Number):
             if op == "mul":
                 return self._scaled(other)
-            other = Array.full((), other, np.result_type(self.dtype, type(other)) if not isinstance(other, numbers.Integral) else self.dtype, self._dev)
+            # a scalar never widens the array's precision (float32 / numpy.float64(2) stays float32, as x * 2.0
+            # always has here); a complex scalar makes a real array complex at ITS precision
+            sdt = self.dtype
+            if isinstance(other, numbers.Complex) and not isinstance(other, numbers.Real) and sdt.kind != "c":
+                sdt = np.dtype("complex64") if sdt == np.dtype("float32") else np.dtype("complex128")
+            if sdt.kind not in "fc":
+                sdt = np.result_type(sdt, type(other)) if not isinstance(other, numbers.Integral) else sdt
+            other = Array.full((), other, sdt, self._dev)
         if isinstance(other, np.ndarray):
             other = Array.from_numpy(other, dev=self._dev)
         if not isinstance(other, Array):
