@@ -764,6 +764,19 @@ static bool chain2_uses_quad(const qamd_chain2_plan* p, const void* C) {
   return (e && e[0] == '2') || M / 64 >= 4096;
 }
 
+// the two-waves-per-SIMD variant of it (chain2h.hip: 32-m chunks, v pairs / x pairs in the lane halves): opt-in
+// with QAMD_CHAIN2H=1 while it is being measured against chain2q
+static bool chain2_uses_half(const qamd_chain2_plan* p, const void* C) {
+  const char* e = getenv("QAMD_CHAIN2H");
+  if (!(e && e[0] == '1')) return false;
+  if (!chain2_uses_registers(p, C) || !qamd_chain2h_supported(p->dtype, p->D)) return false;
+  if (p->nm < 1 || p->dim_m[p->nm - 1] % 32) return false;
+  int64_t M = 1;
+  for (int i = 0; i < p->nm; ++i) M *= p->dim_m[i];
+  const char* q = getenv("QAMD_CHAIN2Q");
+  return (q && q[0] == '2') || M / 32 >= 8192;
+}
+
 // chunks per workgroup of the fused-pair kernels: the largest divisor of the innermost m group's chunk count
 // that still leaves ~12 workgroups per CU; ``sc``: the opt-in super-chunk variant (QAMD_C2R_SC=1: pairs of
 // adjacent chunks per wave, whole-line loads -- measured equal to the default, 0.762 vs 0.764 ms per pair)
@@ -800,6 +813,11 @@ extern "C" int qamd_chain2_describe(const qamd_chain2_plan* p, char* buf, int32_
   if (!ch) return QAMD_EUNSUPPORTED;
   const bool variant = (p->flags & (QAMD_CHAIN2_K1_SINGLE | QAMD_CHAIN2_NO_N2OUT)) != 0;
   if (variant && !chain2_uses_registers(p, nullptr)) return QAMD_EUNSUPPORTED;
+  if (chain2_uses_half(p, nullptr)) {
+    snprintf(buf, buflen, "chain2h_kernel<%d, %d, %d>", p->D, (p->flags & QAMD_CHAIN2_K1_SINGLE) ? 1 : 2,
+             (p->flags & QAMD_CHAIN2_NO_N2OUT) ? 0 : 1);
+    return QAMD_OK;
+  }
   if (chain2_uses_quad(p, nullptr)) {
     snprintf(buf, buflen, "chain2q_kernel<%d, %d, %d>", p->D, (p->flags & QAMD_CHAIN2_K1_SINGLE) ? 1 : 2,
              (p->flags & QAMD_CHAIN2_NO_N2OUT) ? 0 : 1);
@@ -855,6 +873,13 @@ extern "C" int qamd_contract_chain2(const qamd_chain2_plan* p, const void* A, co
     const int64_t N2 = (no_n2out ? 1 : p->D) * (int64_t)p->D;
     a.w1s[0] = k1_single ? DD : (int64_t)p->D * DD; a.w1s[1] = DD; a.w1s[2] = p->D; a.w1s[3] = 1;
     a.w2s[0] = (int64_t)p->D * N2; a.w2s[1] = N2; a.w2s[2] = p->D; a.w2s[3] = 1;
+  }
+  if (chain2_uses_half(p, C)) {
+    a.chunks = (uint32_t)(M / 32);
+    a.chunks_per_block = 0;
+    a.grid = std::min<uint32_t>((a.chunks + 7) / 8, 256);   // persistent: one workgroup (8 waves, 2 per SIMD) per CU
+    return qamd_chain2h_launch(p->D, k1_single, no_n2out, &a, A, W1p, W2p, C, offK1_dev, offCo_dev, scale_a, scale_1,
+                               scale_2, absmax_out, stream);
   }
   if (chain2_uses_quad(p, C)) {
     a.chunks = (uint32_t)(M / 64);

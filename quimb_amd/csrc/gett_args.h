@@ -107,6 +107,10 @@ int qamd_chain2q_supported(int dtype, int D);
 int qamd_chain2q_launch(int D, int k1_single, int no_n2out, const Chain2Args* a, const void* A, const void* W1p,
                         const void* W2p, void* C, const void* offK1, const void* offCo, const void* scale_a,
                         const void* scale_1, const void* scale_2, void* absmax_out, void* stream);
+int qamd_chain2h_supported(int dtype, int D);
+int qamd_chain2h_launch(int D, int k1_single, int no_n2out, const Chain2Args* a, const void* A, const void* W1p,
+                        const void* W2p, void* C, const void* offK1, const void* offCo, const void* scale_a,
+                        const void* scale_1, const void* scale_2, void* absmax_out, void* stream);
 int qamd_chain3_supported(int dtype, int D);
 int qamd_chain3_launch(int D, int nw, const Chain3Args* a, const void* A, const void* W1p, const void* W2p,
                        const void* W3p, void* C, const void* offK1, const void* offCo, const void* scale_a,

@@ -200,7 +200,7 @@ class HipDevice:
         to address them); ``ep`` = (slots_a, slots_w1, slots_w2, slots_out) or None."""
         # the kernel choice (and with it the W addressing mode) follows these switches at call time
         key = ("chain2", c2, dtype_code(dtype), os.environ.get("QAMD_CHAIN2R"), os.environ.get("QAMD_C2R_SC"),
-               os.environ.get("QAMD_CHAIN2Q"))
+               os.environ.get("QAMD_CHAIN2Q"), os.environ.get("QAMD_CHAIN2H"))
         ent = self._pairs.get(key)
         if ent is None:
             pl = _lib.Chain2PlanStruct()
@@ -217,7 +217,7 @@ class HipDevice:
             buf = C.create_string_buffer(128)
             _lib.check(self.lib.qamd_chain2_describe(C.byref(pl), buf, 128), "qamd_chain2_describe")
             name = buf.value.decode()
-            if name.startswith(("chain2r", "chain2q")):
+            if name.startswith(("chain2r", "chain2q", "chain2h")):
                 # the register kernel reads the small tensors in place: no packed copies, no permute launches
                 pl.flags |= 8  # QAMD_CHAIN2_W_STRIDED
                 s1, s2 = list(c2.w1_pack.strides), list(c2.w2_pack.strides)

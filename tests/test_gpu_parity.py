@@ -218,6 +218,22 @@ def test_fused_pairs_quad(hip, Lx, Ly, D):
     finally:
         del os.environ["QAMD_CHAIN2Q"]
     assert mr.to_numpy().item() * 10.0**er == pytest.approx(want, rel=1e-6)
+    if D == 6:   # the opt-in two-waves-per-SIMD variant (chain2h.hip: 32-m chunks, v / x pairs in the lane halves)
+        os.environ["QAMD_CHAIN2H"] = "1"
+        os.environ["QAMD_CHAIN2Q"] = "2"
+        os.environ["QAMD_REGROUP"] = "0"
+        try:
+            exh = qa.TreeExecutor(tree, "float32")
+            hip.profile = []
+            mh, eh = exh(arrays, strip_exponent=True)
+            names_h = {n for (_, _, n, _, _, _) in hip.profile}
+        finally:
+            hip.profile = None
+            for k in ("QAMD_CHAIN2H", "QAMD_CHAIN2Q", "QAMD_REGROUP"):
+                del os.environ[k]
+        for variant in ("chain2h_kernel<6, 2, 1>", "chain2h_kernel<6, 1, 1>", "chain2h_kernel<6, 2, 0>"):
+            assert variant in names_h, names_h
+        assert mh.to_numpy().item() * 10.0**eh == pytest.approx(want, rel=1e-6)
 
 
 @pytest.mark.parametrize("dtype", ["complex64", "complex128"])
