@@ -140,6 +140,11 @@ int qamd_contract_pair_ex(const qamd_pair_plan* plan, const void* A, const void*
  * out [k1][x*D + y] and [y*D + v][n2_out*D + n2_in].  C: the innermost m group has
  * stride D*D and is followed by the contiguous block [x][n2_in]; n2_out at element
  * offset offCo_dev[n2_out].  scale_* / absmax_out: slots as described for the epilogue struct above; any may be NULL.
+ *
+ * Which kernel runs is decided inside (qamd_chain2_describe names it): chain2q (fp32, D = 6 / 4, innermost m group a
+ * multiple of 64, >= 4096 chunks: v_mfma_f32_4x4x1_16b, one wave per SIMD), chain2h (opt-in QAMD_CHAIN2H=1: the same
+ * on 32-m half chunks, two waves per SIMD), chain2r (fp32, D <= 6: v_mfma_f32_16x16x4, 16-m chunks) or chain2
+ * (LDS tile; fp64, D = 7).  QAMD_CHAIN2Q=0 / QAMD_CHAIN2R=0 step down that list.
  */
 #define QAMD_CHAIN2_C_ALIGNED16 1
 /* row-start shape: k1 is ONE index of size D (offK1_dev has D entries, W1p is [D][D*D]) */
@@ -219,7 +224,8 @@ int qamd_reduce_sum(void* out, const void* x, int32_t ndim_keep, const int64_t* 
                     const int64_t* strides_keep, int32_t ndim_red, const int64_t* shape_red,
                     const int64_t* strides_red, int32_t dtype, void* stream);
 
-/* out (C-contiguous, shape) = a[view] (op) b[view];  op: 0 add, 1 mul, 2 sub. */
+/* out (C-contiguous, shape) = a[view] (op) b[view];  op: 0 add, 1 mul, 2 sub, 3 true division
+ * (do("divide") / Tensor.__truediv__ with an array divisor, tensor_core.py:3813). */
 int qamd_binary(void* out, const void* a, const int64_t* a_strides, const void* b,
                 const int64_t* b_strides, int32_t ndim, const int64_t* shape, int32_t op,
                 int32_t dtype, void* stream);
