@@ -92,7 +92,6 @@ __global__ __launch_bounds__(512, 2) void chain2h_kernel(const Chain2Args p, con
   constexpr int NH = K1D == 2 ? D : 1;
   constexpr int NT1 = DD / 4;                    // stage-1 row tiles (rows = (x, y))
   constexpr int NPV = D / 2;                     // v pairs
-  constexpr int ROWS = NPV * K1;                 // A row PAIRS of one chunk, consumed in the order (p, k1)
   constexpr int NGRP = NPV * NH;                 // row groups (p, h) of D rows (u)
   constexpr int RGRP = (NGRP % 6 == 0 && NGRP > 6) ? 6 : NGRP;   // row groups in the ring
   constexpr int RING = RGRP * D;
