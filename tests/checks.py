@@ -1495,3 +1495,22 @@ def check_advice_low_items():
     assert next(d._cutoffs) == 0
     d.solve(max_sweeps=1, bond_dims=6)
     assert next(d._bond_dims) == 6 and next(d._cutoffs) == 0                          # the cutoff schedule is untouched
+
+
+def check_two_sided_small(Lx, Ly, D, k, dtype="float32"):
+    """The branch decomposition on whatever device is installed (one rank: both half sweeps, every slice) against
+    the oracle evaluated on the SAME site-by-site sweep path (never the oracle's default path: on a 2D lattice it
+    builds terabyte-sized intermediates)."""
+    from oracle import np_oracle as orc
+    from quimb_amd.twosided import TwoSidedContraction
+
+    arrays, inputs = orc.tn2d_rand(Lx, Ly, D, seed=19, dtype=dtype)
+    size = {ix: D for t in inputs for ix in t}
+    tree = qa.ContractionTree(inputs, (), size, path=qa.sweep_path_2d(Lx, Ly))
+    assert tree.max_size() <= 6**9                                     # bounded memory, by construction
+    want = orc.oracle_array_contract([a.astype(np.float64) for a in arrays], inputs, (), path=tree.get_path()).item()
+    plan = TwoSidedContraction(inputs, size, Lx, Ly, dtype, sliced_cols=k)
+    m, e = plan(arrays, strip_exponent=True)
+    rel = 1e-6 if np.dtype(dtype) == np.dtype("float32") else 1e-10
+    assert abs(m * 10.0**e - want) <= rel * abs(want), (m, e, want)
+    assert abs(plan(arrays) - want) <= rel * abs(want)

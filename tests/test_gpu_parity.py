@@ -510,3 +510,21 @@ def test_linop_chi512_parity(hip):
 
 def test_advice_round1_low_items(hip):
     checks.check_advice_low_items()
+
+
+def test_two_sided_full_size(hip):
+    """The branch decomposition on the device at the headline size against the stored fp64 oracle value (what
+    ``bench.py --gpus N`` contracts; one rank running both half sweeps).  Small shapes and sliced cut bonds are
+    covered on the CPU interpreter (tests/test_host_emu.py) and, across ranks, by the gloo tests."""
+    import json
+    import os
+
+    from oracle import np_oracle as orc
+    from quimb_amd.twosided import TwoSidedContraction
+
+    ref = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "full_size_oracle.json")))["7"]
+    arrays, inputs = orc.tn2d_rand(10, 10, 6, seed=7, dtype="float32")
+    size = {ix: 6 for t in inputs for ix in t}
+    for k in (0,):
+        m, e = TwoSidedContraction(inputs, size, 10, 10, "float32", sliced_cols=k)(arrays, strip_exponent=True)
+        assert m == ref["sign"] and abs(e - ref["log10_abs"]) < np.log10(1.0 + 1e-6), (k, m, e)

@@ -383,3 +383,8 @@ def test_intensity_aware_finders(emu):
 
 def test_advice_round1_low_items(emu):
     checks.check_advice_low_items()
+
+
+@pytest.mark.parametrize("Lx,Ly,D,k", [(4, 6, 4, 0), (4, 6, 4, 2), (5, 5, 3, 1)])
+def test_two_sided_small_shapes(emu, Lx, Ly, D, k):
+    checks.check_two_sided_small(Lx, Ly, D, k, "float64")
