@@ -188,9 +188,8 @@ class TwoSidedContraction:
         per_rank = []
         for branch, slices in layout:
             halves = [self.top, self.bottom] if branch == "both" else [self.top if branch == "top" else self.bottom]
-            per_rank.append(sum(h.hoisted_mults() + h.slab_mults(slices) for h in halves)
-                            + (prod(self.size[ix] for ix in self.top.xs) if branch != "top" and slices else 0) * 0)
-        join = prod(self.size[ix] for ix in self.top.xs)
+            per_rank.append(sum(h.hoisted_mults() + h.slab_mults(slices) for h in halves))
+        join = prod(self.size[ix] for ix in self.top.xs)      # the dot products of all slices together
         hoisted = sum((self.top if b == "top" else self.bottom).hoisted_mults() for b, _ in layout if b != "both")
         if any(b == "both" for b, _ in layout):
             hoisted = self.top.hoisted_mults() + self.bottom.hoisted_mults()
