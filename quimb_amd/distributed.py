@@ -150,12 +150,16 @@ def contract_two_sided(plan, arrays, strip_exponent=False, group=None, stats=Non
         return torch.from_numpy(np.ascontiguousarray(x.to_numpy()).reshape(-1).copy())
 
     pairs = []
+    sent = []      # every slab handed over stays referenced until the job is over (the transport may still read it)
     if branch == "top":
         for s, T, eT in half.slabs(arrays, U, mine):
             dst = owner_bot[s]
-            dist.send(as_tensor(T).contiguous(), dst=dst if group is None else dist.get_global_rank(group, dst), group=group)
-            dist.send(torch.tensor([eT + eU], dtype=torch.float64, device=as_tensor(T).device),
-                      dst=dst if group is None else dist.get_global_rank(group, dst), group=group)
+            gdst = dst if group is None else dist.get_global_rank(group, dst)
+            payload = as_tensor(T).contiguous()
+            expo = torch.tensor([eT + eU], dtype=torch.float64, device=payload.device)
+            sent.append((T, payload, expo))
+            dist.send(payload, dst=gdst, group=group)
+            dist.send(expo, dst=gdst, group=group)
     else:
         from .array import Array
 
@@ -182,4 +186,5 @@ def contract_two_sided(plan, arrays, strip_exponent=False, group=None, stats=Non
     gathered = [torch.empty_like(mine_t) for _ in range(world)]
     dist.all_gather(gathered, mine_t, group=group)
     allp = [(float(g[0]), float(g[1])) for g in (x.cpu() for x in gathered) if float(g[1]) > -1e299]
+    del sent       # the all-gather's read-back above is behind every hand-off of this rank
     return combine_pairs(allp, strip_exponent=strip_exponent)
