@@ -508,7 +508,7 @@ static int64_t largest_divisor_le(int64_t n, int64_t limit) {
   return 1;
 }
 
-static bool plan_permute_stream(const std::vector<Dim>& d0, int64_t src_offset, PermArgs& a) {
+static bool plan_permute_stream(const std::vector<Dim>& d0, int64_t src_offset, int64_t cap, PermArgs& a) {
   std::vector<Dim> pool = d0, tile;
   int64_t span_s = 0, span_d = 0;
   for (const Dim& x : pool) { span_s += (x.n - 1) * std::llabs(x.ss); span_d += (x.n - 1) * x.sd; }
@@ -550,12 +550,13 @@ static bool plan_permute_stream(const std::vector<Dim>& d0, int64_t src_offset, 
       if (idx < 0 || !take((size_t)idx, std::min<int64_t>(cap / vol, std::max<int64_t>(2, 4 * want / run)))) return;
     }
   };
-  grow(true, 32, 4096);            // a source run of >= 32 elements ...
-  grow(false, 32, 4096);           // ... and a destination run of >= 32
-  for (int round = 0; round < 8 && vol < 2048; ++round) {       // then lengthen both, in turn
+  // ``cap``: elements per tile (4096; 2048 for 16-byte elements, whose padded tile must stay inside 64 KB of LDS)
+  grow(true, 32, cap);             // a source run of >= 32 elements ...
+  grow(false, 32, cap);            // ... and a destination run of >= 32
+  for (int round = 0; round < 8 && vol < cap / 2; ++round) {    // then lengthen both, in turn
     const int64_t before = vol;
-    grow(true, 2 * run_len(true), 4096);
-    if (vol < 2048) grow(false, 2 * run_len(false), 4096);
+    grow(true, 2 * run_len(true), cap);
+    if (vol < cap / 2) grow(false, 2 * run_len(false), cap);
     if (vol == before) break;
   }
   if (vol < 512 || run_len(true) < 8) return false;
@@ -597,7 +598,7 @@ extern "C" int qamd_permute(void* dst, const void* src, int32_t ndim, const int6
     // the z-looping, offset-caching kernel first (QAMD_PERMUTE_STREAM=0 keeps the tile-per-workgroup one)
     const char* e = getenv("QAMD_PERMUTE_STREAM");
     PermArgs ps;
-    if (!(e && e[0] == '0') && plan_permute_stream(d, src_offset, ps)) {
+    if (!(e && e[0] == '0') && plan_permute_stream(d, src_offset, kEsize[dtype] == 16 ? 2048 : 4096, ps)) {
       int rc = qamd_permute_stream_launch(kEsize[dtype], dst, src, &ps, stream);
       if (rc != -2) return rc;
     }

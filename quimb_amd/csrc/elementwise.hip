@@ -538,6 +538,7 @@ extern "C" int qamd_permute_stream_launch(int esize, void* dst, const void* src,
   const int total = (int)p->X;
   if (total > 4096) return -2;
   const size_t lds = (size_t)(total + total / std::max<uint32_t>(p->dim_x[p->nx - 1], 1) + 2) * esize;
+  if (lds > 64 * 1024) return -2;      // (the planner keeps tiles inside 64 KB; anything else goes to permute_kernel)
 #define QAMD_PS(T, E) QAMD_LAUNCH((permute_stream_kernel<T, E>), dim3((uint32_t)grid), dim3(256), lds, st, (T*)dst, (const T*)src, *p)
   const int ept = (total + 255) / 256;
   switch (esize) {
