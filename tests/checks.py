@@ -1514,3 +1514,37 @@ def check_two_sided_small(Lx, Ly, D, k, dtype="float32"):
     rel = 1e-6 if np.dtype(dtype) == np.dtype("float32") else 1e-10
     assert abs(m * 10.0**e - want) <= rel * abs(want), (m, e, want)
     assert abs(plan(arrays) - want) <= rel * abs(want)
+
+
+def check_golden_local(rtol=1e-12):
+    """``Tensor.gate`` / ``contract_between`` / ``contract_ind`` / ``TensorNetwork.trace`` of the mirrors against the
+    REAL quimb's results on the same data (tests/golden/local.npz, made by make_golden_local.py): data, index
+    order, tags, tensor count."""
+    import json
+    import os
+
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "local.npz"))
+    T = qa.Tensor
+    t = T(qa.asarray(g["gate_x"]), ("a", "b", "c"), tags={"T"})
+    for key, ind, transpose, preserve, inds in json.loads(str(g["gate_cases"])):
+        out = t.gate(qa.asarray(g[key + "_G"]), ind, transpose=bool(transpose), preserve_inds=bool(preserve))
+        assert list(out.inds) == inds and out.tags == ("T",), key
+        np.testing.assert_allclose(out.data.to_numpy(), g[key + "_data"], rtol=rtol, atol=rtol)
+    spec = json.loads(str(g["ring_spec"]))
+    mk = lambda: qa.TensorNetwork([T(qa.asarray(g[f"ring_{i}"]), tuple(inds), tags=tg) for i, (tg, inds) in enumerate(spec)])
+    tn = mk()
+    tn.contract_between("A", "B")
+    tab = next(x for x in tn if "A" in x.tags)
+    assert len(tn) == int(g["between_ntensors"]) and sorted(tab.tags) == json.loads(str(g["between_tags"]))
+    assert set(tab.inds) == set(json.loads(str(g["between_inds"])))
+    np.testing.assert_allclose(tab.transpose(*json.loads(str(g["between_inds"]))).data.to_numpy(), g["between_data"],
+                               rtol=rtol, atol=rtol)
+    tn = mk()
+    tn.contract_ind("l")
+    tcl = next(x for x in tn if "C" in x.tags)
+    assert sorted(tcl.tags) == json.loads(str(g["ind_tags"])) and set(tcl.inds) == set(json.loads(str(g["ind_inds"])))
+    np.testing.assert_allclose(tcl.transpose(*json.loads(str(g["ind_inds"]))).data.to_numpy(), g["ind_data"],
+                               rtol=rtol, atol=rtol)
+    np.testing.assert_allclose(mk().contract().data.to_numpy(), g["ring_value"], rtol=rtol, atol=rtol)
+    op = qa.TensorNetwork([T(qa.asarray(g["trace_P"]), ("a", "x")), T(qa.asarray(g["trace_Q"]), ("x", "b"))])
+    assert abs(float(np.asarray(op.trace("a", "b"))) - float(g["trace_value"])) <= 1e-12 * abs(float(g["trace_value"]))

@@ -105,3 +105,13 @@ def test_circuits_host_logic_match_real_quimb(emu):
 @pytest.mark.parametrize("dtype", ["complex128", "complex64"])
 def test_circuits_hip_match_real_quimb(hip, dtype):
     checks.check_circuits(dtype)
+
+
+def test_local_ops_match_real_quimb(emu):
+    """Tensor.gate / contract_between / contract_ind / trace of the mirrors vs the REAL quimb (tests/golden/local.npz)."""
+    checks.check_golden_local()
+
+
+@pytest.mark.gpu
+def test_local_ops_hip_match_real_quimb(hip):
+    checks.check_golden_local(rtol=1e-11)
