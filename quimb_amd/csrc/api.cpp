@@ -112,6 +112,68 @@ static bool dot_rows(const qamd_pair_plan* p, const PairDims& d, DotArgs& a) {
   return true;
 }
 
+// ---- gemmk.hip eligibility and tile choice --------------------------------------------------------
+// Both operands carry their free bundle innermost in 4-element vectors, ONE K group (K % 8 == 0),
+// non-negative strides, per-lane offsets inside a tile below 4 GiB.  The operands swap roles when
+// C's stride-1 index lives in the M bundle (lanes of an MFMA result run along the B operand's index).
+static bool gemmk_operand_ok(int ng, const int64_t* dims, const int64_t* strides, int64_t sk, int64_t tile) {
+  if (ng < 1 || strides[ng - 1] != 1 || dims[ng - 1] % 4 || sk <= 0) return false;
+  int64_t span = 0;   // largest element offset inside a tile of `tile` consecutive bundle indices
+  for (int g = 0; g < ng; ++g) {
+    if (strides[g] < 0) return false;
+    if (g < ng - 1 && strides[g] % 4) return false;
+  }
+  // offsets of a run of `tile` consecutive indices: bounded by the span of the groups it can touch
+  int64_t run = 1;
+  for (int g = ng - 1; g >= 0; --g) {
+    const int64_t touched = std::min<int64_t>(dims[g], (tile + run - 1) / run + 1);
+    span += (touched - 1) * strides[g];
+    run *= dims[g];
+    if (run >= 2 * tile) break;
+  }
+  return (span + 15 * sk + 4) * 4 < (1ll << 32);
+}
+
+static double gemmk_model(int64_t M, int64_t N, int64_t B, int ta, int tb, int64_t* tiles_out) {
+  const int64_t tiles = ((M + 64 * ta - 1) / (64 * ta)) * ((N + 64 * tb - 1) / (64 * tb)) * B;
+  const int occ = (ta * tb <= 6) ? 2 : 1;     // workgroups per CU (registers: 16 accumulators per sub-tile)
+  const int64_t rounds = (tiles + kNumCU * occ - 1) / (kNumCU * occ);
+  static const double eff[17] = {0, 0, 0, 0, 0.86, 0, 0.90, 0, 0.93, 0.95, 0, 0, 0.96, 0, 0, 0, 0.97};
+  if (tiles_out) *tiles_out = tiles;
+  return (double)rounds * occ * ta * tb / eff[ta * tb];
+}
+
+static bool gemmk_config(const qamd_pair_plan* p, const PairDims& d, int64_t align_a, int64_t align_b, int64_t align_c,
+                         int& ta, int& tb) {
+  const char* e = getenv("QAMD_GEMMK");
+  if (e && atoi(e) == 0) return false;
+  if (p->dtype != QAMD_F32 || p->nk != 1 || p->a_kcontig || p->b_kcontig || p->vec_a < 4 || p->vec_b < 4) return false;
+  if (d.K % 8 || d.K < 64 || d.M < 128 || d.N < 128 || d.M % 4 || d.N % 4) return false;
+  if ((align_a % 16) || (align_b % 16) || (align_c % 4)) return false;
+  if (!gemmk_operand_ok(p->nm, p->dim_m, p->sa_m, p->sa_k[0], 256) ||
+      !gemmk_operand_ok(p->nn, p->dim_n, p->sb_n, p->sb_k[0], 256))
+    return false;
+  for (int i = 0; i < p->nb; ++i)
+    if (p->sa_b[i] % 4 || p->sb_b[i] % 4) return false;
+  const bool swap = !p->c_ncontig;
+  const int64_t M = swap ? d.N : d.M, N = swap ? d.M : d.N;
+  const char* te = getenv("QAMD_GEMMK_TILE");   // e.g. 43: pin (ta, tb)
+  double best = 0;
+  ta = tb = 0;
+  for (int a = 2; a <= 4; ++a)
+    for (int b = 2; b <= 4; ++b) {
+      if (te && atoi(te) != 10 * a + b) continue;
+      int64_t tiles = 0;
+      const double t = gemmk_model(M, N, d.B, a, b, &tiles);
+      if (!ta || t < best) { best = t; ta = a; tb = b; }
+    }
+  if (!ta) return false;
+  int64_t tiles = 0;
+  gemmk_model(M, N, d.B, ta, tb, &tiles);
+  // under-filled grids keep the split-K kernels
+  return tiles >= 96 || (te != nullptr);
+}
+
 extern "C" int qamd_pair_plan_finalize(qamd_pair_plan* p, int64_t align_a, int64_t align_b, int64_t align_c) {
   PairDims d;
   int rc = pair_dims(p, d);
@@ -199,6 +261,16 @@ extern "C" int qamd_pair_plan_finalize(qamd_pair_plan* p, int64_t align_a, int64
     }
     if (p->kernel == -1) p->kernel = 0;  // caller forces the tiled kernel
     else p->kernel = kern;
+    // kernel 5 (gemmk.hip): GEMM-shaped, both operands "k-outer" (free bundle stride-1), fp32
+    if (p->kernel == 0 && kern == 0 && p->tile_cfg < 0) {
+      int ta = 0, tb = 0;
+      if (gemmk_config(p, d, align_a, align_b, align_c, ta, tb)) {
+        p->kernel = 5;
+        p->tile_cfg = 16 * ta + tb;
+        p->split_k = 1;
+        return QAMD_OK;
+      }
+    }
   }
   if (p->kernel == 4) {
     // one slab of partial sums per workgroup; every workgroup streams >= 2 x 256 16-byte vectors per row
@@ -374,6 +446,52 @@ static int launch_stream(const qamd_pair_plan* p, const PairDims& d, const void*
                             ep ? ep->scale_b : nullptr, ep ? ep->absmax_out : nullptr, stream);
 }
 
+static int launch_gemmk(const qamd_pair_plan* p, const PairDims& d, const void* A, const void* B, void* C,
+                        const qamd_epilogue* ep, void* stream) {
+  const int ta = p->tile_cfg / 16, tb = p->tile_cfg % 16;
+  if (ta < 2 || ta > 4 || tb < 2 || tb > 4 || p->dtype != QAMD_F32 || p->nk != 1 || !A || !B || !C) return QAMD_EINVAL;
+  if (((uintptr_t)A & 15) || ((uintptr_t)B & 15)) return QAMD_EINVAL;
+  const bool swap = !p->c_ncontig;
+  GettArgs a;
+  memset(&a, 0, sizeof(a));
+  a.nb = p->nb;
+  for (int i = 0; i < p->nb; ++i) {
+    a.dim_b[i] = (uint32_t)p->dim_b[i];
+    a.sa_b[i] = swap ? p->sb_b[i] : p->sa_b[i];
+    a.sb_b[i] = swap ? p->sa_b[i] : p->sb_b[i];
+    a.sc_b[i] = p->sc_b[i];
+  }
+  // kernel roles: "m" = rows of the MFMA result, "n" = its lanes (C's contiguous side)
+  const int nm = swap ? p->nn : p->nm, nn = swap ? p->nm : p->nn;
+  const int64_t* dm = swap ? p->dim_n : p->dim_m;  const int64_t* dn = swap ? p->dim_m : p->dim_n;
+  const int64_t* sam = swap ? p->sb_n : p->sa_m;   const int64_t* sbn = swap ? p->sa_m : p->sb_n;
+  const int64_t* scm = swap ? p->sc_n : p->sc_m;   const int64_t* scn = swap ? p->sc_m : p->sc_n;
+  a.nm = nm; a.nn = nn; a.nk = 1;
+  for (int i = 0; i < nm; ++i) { a.dim_m[i] = (uint32_t)dm[i]; a.sa_m[i] = sam[i]; a.sc_m[i] = scm[i]; }
+  for (int i = 0; i < nn; ++i) { a.dim_n[i] = (uint32_t)dn[i]; a.sb_n[i] = sbn[i]; a.sc_n[i] = scn[i]; }
+  a.B = (uint32_t)d.B; a.M = (uint32_t)(swap ? d.N : d.M); a.N = (uint32_t)(swap ? d.M : d.N); a.K = (uint32_t)d.K;
+  a.sa_k0 = swap ? p->sb_k[0] : p->sa_k[0];
+  a.sb_k0 = swap ? p->sa_k[0] : p->sb_k[0];
+  a.tiles_m = (uint32_t)((a.M + 64 * ta - 1) / (64 * ta));
+  a.tiles_n = (uint32_t)((a.N + 64 * tb - 1) / (64 * tb));
+  a.split_k = 1;
+  // vector stores along n: the innermost n group is stride-1 in C, a multiple of the vector, everything else aligned
+  {
+    int v = 1;
+    if (nn >= 1 && scn[nn - 1] == 1) {
+      std::vector<int64_t> others;
+      for (int i = 0; i < p->nb; ++i) others.push_back(p->sc_b[i]);
+      for (int i = 0; i < nm; ++i) others.push_back(scm[i]);
+      for (int i = 0; i + 1 < nn; ++i) others.push_back(scn[i]);
+      v = pick_vec(dn[nn - 1], (int64_t)((uintptr_t)C & 15) ? 4 : 16, 4, others);
+    }
+    a.vec_c = v;
+  }
+  const void* sa = ep ? (swap ? ep->scale_b : ep->scale_a) : nullptr;
+  const void* sb = ep ? (swap ? ep->scale_a : ep->scale_b) : nullptr;
+  return qamd_gemmk_launch(ta, tb, &a, swap ? B : A, swap ? A : B, C, sa, sb, ep ? ep->absmax_out : nullptr, stream);
+}
+
 extern "C" int qamd_contract_pair_ex(const qamd_pair_plan* p, const void* A, const void* B, void* C,
                                      const void* ktab, void* ws, int64_t ws_bytes, const qamd_epilogue* ep,
                                      void* stream) {
@@ -381,6 +499,7 @@ extern "C" int qamd_contract_pair_ex(const qamd_pair_plan* p, const void* A, con
   int rc = pair_dims(p, d);
   if (rc) return rc;
   if (p->dtype != QAMD_F32 && p->dtype != QAMD_F64) return QAMD_EUNSUPPORTED;
+  if (p->kernel == 5) return launch_gemmk(p, d, A, B, C, ep, stream);
   if (p->tile_cfg < 0 || p->tile_cfg >= kNumTileCfg || p->split_k < 1) return QAMD_EINVAL;
   if (!A || !B || !C || !ktab) return QAMD_EINVAL;
   if (p->kernel == 1 || p->kernel == 2) return launch_stream(p, d, A, B, C, ktab, ep, stream);
@@ -716,6 +835,11 @@ extern "C" int qamd_pair_describe(const qamd_pair_plan* p, char* buf, int32_t bu
   const char* T = p->dtype == QAMD_F32 ? "float" : (p->dtype == QAMD_F64 ? "double" : "?");
   if (p->kernel == 4) {
     snprintf(buf, buflen, "dotm_kernel<%s, %d>", T, (int)std::max(d.M, d.N));
+    return QAMD_OK;
+  }
+  if (p->kernel == 5) {
+    const int ta = p->tile_cfg / 16, tb = p->tile_cfg % 16;
+    snprintf(buf, buflen, "gemmk_kernel<%d, %d, 3, %d>", ta, tb, ta * tb <= 6 ? 2 : 1);
     return QAMD_OK;
   }
   if (p->kernel == 1 || p->kernel == 2) {

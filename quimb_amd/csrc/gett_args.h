@@ -18,6 +18,11 @@ struct GettArgs {
   uint32_t tiles_m, tiles_n, split_k;
   int32_t vec_a, vec_b, a_kcontig, b_kcontig;
   int64_t slab_stride;  // elements between split-K slabs
+  int64_t sa_k0, sb_k0; // gemmk.hip: strides of the single K group
+  int32_t vec_c;        // gemmk.hip: elements of C that are contiguous and aligned along n (1, 2, 4)
+  int32_t tail_first;   // gemmk.hip: first tile of the k-split tail (>= tiles: no tail)
+  int32_t tail_split;   // gemmk.hip: k parts per tail tile
+  int32_t pad_;
 };
 
 // "big tensor x small tensor" streaming kernel (stream.hip)
@@ -87,6 +92,8 @@ int qamd_gett_launch(int dtype, int cfg, const GettArgs* a, int swap, const void
                      void* stream);
 int qamd_gettf_launch(int dtype, int bn, const GettArgs* a, int swap, const void* A, const void* B, void* C,
                       const void* ktab, const void* scale_a, const void* scale_b, void* absmax_out, void* stream);
+int qamd_gemmk_launch(int ta, int tb, const GettArgs* a, const void* A, const void* B, void* C,
+                      const void* scale_a, const void* scale_b, void* absmax_out, void* stream);
 int qamd_dotm_launch(int dtype, const DotArgs* a, const void* R, const void* v, void* slab, void* C,
                      const void* scale_a, const void* scale_b, void* absmax_out, void* stream);
 int qamd_stream_launch(int dtype, int V, const StreamArgs* a, const void* A, const void* B, void* C,

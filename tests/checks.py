@@ -497,6 +497,51 @@ def check_fast_tiles(dtype, seed=12):
         assert_close(got.to_numpy(), want, dtype)
 
 
+GEMMK_CASES = [
+    # GEMM-shaped, both operands "k-outer" (free bundle innermost), fp32 -> gemmk_kernel (gemmk.hip)
+    ("km,kn->mn", dict(m=260, k=72, n=132)),           # ragged edge tiles on both sides, K % 16 == 8 (leading half tile)
+    ("km,kn->nm", dict(m=384, k=64, n=200)),           # C m-contiguous: operand roles swap
+    ("kab,kcd->acbd", dict(k=80, a=12, b=16, c=10, d=20)),   # two groups per bundle, C interleaves them
+    ("bkm,bkn->bmn", dict(b=3, k=64, m=128, n=192)),   # batch bundle
+    ("km,kn->mn", dict(m=640, k=136, n=576)),          # half tile + 8 full tiles, several workgroup tiles
+    ("xkm,kn->xmn", dict(x=2, k=96, m=132, n=128)),    # M = (x, m): x is an outer M group with its own stride
+    ("km,kn->mn", dict(m=128, k=64, n=128)),           # exactly one 128 x 128 tile, no third k-tile
+    ("km,kn->mn", dict(m=216, k=216, n=216)),          # powers of 6
+]
+
+
+def check_gemmk(seed=21, tiles=(None,)):
+    """``tiles``: values of QAMD_GEMMK_TILE to pin (None = the planner's choice); the caller clears the plan cache."""
+    import os
+
+    rng = np.random.default_rng(seed)
+    for tile in tiles:
+        if tile is None:
+            os.environ.pop("QAMD_GEMMK_TILE", None)
+        else:
+            os.environ["QAMD_GEMMK_TILE"] = str(tile)
+        dev = qa.default_device()
+        if hasattr(dev, "_pairs"):
+            dev._pairs.clear()
+        try:
+            for eq, dims in GEMMK_CASES:
+                lhs, out = eq.split("->")
+                ai, bi = lhs.split(",")
+                a = rand(rng, [dims[c] for c in ai], "float32")
+                b = rand(rng, [dims[c] for c in bi], "float32")
+                want = np.einsum(eq, a.astype(np.float64), b.astype(np.float64))
+                got = qa.einsum(eq, qa.asarray(a), qa.asarray(b))
+                # fp32 k-ordered fma chain: error <= ~1e-7 * sum |a b| (SURVEY 8c); sum |a b| <= K * 1 * 1 here
+                kk = np.prod([dims[c] for c in set(ai) & set(bi) - set(out)])
+                assert_close(got.to_numpy(), want, "float32", scale=None)
+                err = np.max(np.abs(got.to_numpy().astype(np.float64) - want))
+                assert err <= 2e-7 * kk * 0.5625, (eq, tile, err)
+        finally:
+            os.environ.pop("QAMD_GEMMK_TILE", None)
+            if hasattr(dev, "_pairs"):
+                dev._pairs.clear()
+
+
 # ---------------------------------------------------------------------------
 # golden vectors generated by the real quimb (tests/golden/make_golden.py)
 # ---------------------------------------------------------------------------

@@ -72,6 +72,20 @@ def test_fast_tiles(hip, dtype):
     assert any(s > 1 for s in splits), splits
 
 
+def test_gemmk(hip):
+    """k-outer MFMA GETT (gemmk.hip): ragged edges, half k-tile, swapped roles, tensor addressing, batch --
+    with the planner's tile and with every workgroup tile pinned."""
+    hip.profile = []
+    try:
+        checks.check_gemmk(tiles=(None, 44, 43, 34, 33, 42, 24, 32, 23, 22))
+        names = [n for (_, _, n, _, _, _) in hip.profile]
+    finally:
+        hip.profile = None
+    pinned = [n for n in names[len(checks.GEMMK_CASES):]]
+    assert all(n.startswith("gemmk_kernel") for n in pinned), pinned
+    assert {n for n in pinned} >= {f"gemmk_kernel<{a}, {b}, 3, {2 if a * b <= 6 else 1}>" for a in (2, 3, 4) for b in (2, 3, 4)}
+
+
 @pytest.mark.parametrize("Lx,Ly,D", [(6, 6, 4), (8, 8, 2), (5, 8, 4), (3, 8, 6), (3, 9, 6)])
 def test_fused_triples(hip, Lx, Ly, D):
     """Three adjacent interior site absorptions in ONE launch (chain3 kernel, chunk state exchanged through
