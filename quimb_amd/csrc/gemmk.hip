@@ -191,67 +191,101 @@ __global__ __launch_bounds__(256, MINW) void gemmk_kernel(const GettArgs p, cons
   const int aoff = kh * BM + wm * (32 * TA);
   const int boff = BK * BM + kh * BN + wn * (32 * TB);
 
-  int st = 0;
+  // ---- main loop, software-pipelined over k-steps AND k-tiles --------------------------------------
+  // tile t (stage t % NS) is requested two tiles ahead; its ONE barrier sits inside tile t - 1, three
+  // k-steps before the end, between two MFMAs: every wave has then finished reading tile t - 2 (whose stage
+  // the request for tile t + 1 may overwrite) and has waited for its own pieces of tile t.  The fragments of
+  // k-step s + 1 -- of the next tile's first step at the end of a tile -- are read while step s's
+  // MFMAs run, so neither LDS latency nor the barrier ever drains the matrix pipe.
+  const int ntiles = nfull + (lead_half ? 1 : 0);
   if (lead_half) {
     // the 8 leading k rows: only the pieces that hold rows 0..7 (piece < 2 T), straight into stage 0
     float* sa = stages;
     float* sb = sa + BK * BM;
 #pragma unroll
     for (int q = 0; q < TA; ++q)
-      if (wave + 4 * q < 2 * TA)
-        kglds(baseA + offA[q], sa + 256 * (wave + 4 * q));
+      if (wave + 4 * q < 2 * TA) kglds(baseA + offA[q], sa + 256 * (wave + 4 * q));
 #pragma unroll
     for (int q = 0; q < TB; ++q)
-      if (wave + 4 * q < 2 * TB)
-        kglds(baseB + offB[q], sb + 256 * (wave + 4 * q));
+      if (wave + 4 * q < 2 * TB) kglds(baseB + offB[q], sb + 256 * (wave + 4 * q));
     baseA += stepA / 2;
     baseB += stepB / 2;
-    if (nfull > 0) QK_ISSUE(1);
-    if (nfull > 0) { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(TA + TB) : "memory"); }
-    else { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-    __builtin_amdgcn_s_barrier();
-    if (nfull > 1) QK_ISSUE(2);
-    const float* As = stages + aoff;
-    const float* Bs = stages + boff;
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      float a[TA], b[TB];
-      kfrag<TA>(a, As + 2 * s * BM, l31);
-      kfrag<TB>(b, Bs + 2 * s * BN, l31);
-#pragma unroll
-      for (int i = 0; i < TA; ++i)
-#pragma unroll
-        for (int j = 0; j < TB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
-    }
-    st = 1;
   } else {
     QK_ISSUE(0);
-    if (nfull > 1) QK_ISSUE(1);
   }
+  // (the launcher guarantees >= 3 tiles: tiles 1 and 2 exist)
+  QK_ISSUE(1);
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(TA + TB) : "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
 
-  // invariant at the top of iteration kt: tiles kt and kt + 1 (if it exists) are in flight
-  for (int kt = 0; kt < nfull; ++kt) {
-    if (kt + 1 < nfull) { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(TA + TB) : "memory"); }
-    else { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-    __builtin_amdgcn_s_barrier();
-    if (kt + 2 < nfull) {
-      int st2 = st + 2; st2 = st2 >= NS ? st2 - NS : st2;
-      QK_ISSUE(st2);
-    }
-    const float* As = stages + st * STAGE + aoff;
-    const float* Bs = stages + st * STAGE + boff;
-#pragma unroll
-    for (int s = 0; s < 8; ++s) {
-      float a[TA], b[TB];
-      kfrag<TA>(a, As + 2 * s * BM, l31);
-      kfrag<TB>(b, Bs + 2 * s * BN, l31);
-#pragma unroll
-      for (int i = 0; i < TA; ++i)
-#pragma unroll
-        for (int j = 0; j < TB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
-    }
-    st = st + 1 >= NS ? 0 : st + 1;
+  float fa[2][TA], fb[2][TB];
+  kfrag<TA>(fa[0], stages + aoff, l31);
+  kfrag<TB>(fb[0], stages + boff, l31);
+
+  // one piece of the next request (q < TA: A pieces, else B pieces) into stage st2_
+#define QK_PIECE(q_, st2_)                                                                                    \
+  do {                                                                                                        \
+    if ((q_) < TA) kglds(baseA + offA[(q_) < TA ? (q_) : 0], stages + (st2_) * STAGE + 256 * (wave + 4 * (q_))); \
+    else kglds(baseB + offB[(q_) < TA ? 0 : (q_) - TA], stages + (st2_) * STAGE + BK * BM + 256 * (wave + 4 * ((q_) - TA))); \
+  } while (0)
+
+#define QK_TILE(NSTEPS_)                                                                                      \
+  do {                                                                                                        \
+    const float* As_ = stages + st * STAGE + aoff;                                                            \
+    const float* Bs_ = stages + st * STAGE + boff;                                                            \
+    const int stn_ = st + 1 >= NS ? 0 : st + 1;                                                               \
+    const int st2_ = stn_ + 1 >= NS ? 0 : stn_ + 1;                                                           \
+    _Pragma("unroll") for (int s = 0; s < NSTEPS_; ++s) {                                                    \
+      const bool sync_ = (s == NSTEPS_ - 3);                                                                  \
+      if (sync_) {                                                                                            \
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                      \
+        __builtin_amdgcn_s_barrier();                                                                         \
+        asm volatile("" ::: "memory");                                                                        \
+      }                                                                                                       \
+      /* one MFMA first: the wait for THIS step's fragments (read a whole step ago) then precedes the    */ \
+      /* next step's reads instead of covering them                                                     */ \
+      __builtin_amdgcn_sched_barrier(0);                                                                      \
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[s & 1][0], fb[s & 1][0], acc[0][0], 0, 0, 0);       \
+      __builtin_amdgcn_sched_barrier(0);                                                                      \
+      if (s + 1 < NSTEPS_) {                                                                                  \
+        kfrag<TA>(fa[(s + 1) & 1], As_ + 2 * (s + 1) * BM, l31);                                              \
+        kfrag<TB>(fb[(s + 1) & 1], Bs_ + 2 * (s + 1) * BN, l31);                                              \
+      } else {                                                                                                \
+        kfrag<TA>(fa[0], stages + stn_ * STAGE + aoff, l31);                                                  \
+        kfrag<TB>(fb[0], stages + stn_ * STAGE + boff, l31);                                                  \
+      }                                                                                                       \
+      __builtin_amdgcn_sched_barrier(0);                                                                      \
+      _Pragma("unroll") for (int i = 0; i < TA; ++i) _Pragma("unroll") for (int j = 0; j < TB; ++j)          \
+          if (i + j > 0) {                                                                                    \
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[s & 1][i], fb[s & 1][j], acc[i][j], 0, 0, 0); \
+            /* the request for tile t + 2, one piece behind each of the MFMAs that follow the barrier     */ \
+            if (sync_ && i * TB + j - 1 < TA + TB) {                                                          \
+              __builtin_amdgcn_sched_barrier(0);                                                              \
+              QK_PIECE(i * TB + j - 1, st2_);                                                                 \
+              __builtin_amdgcn_sched_barrier(0);                                                              \
+            }                                                                                                 \
+          }                                                                                                   \
+      if (sync_) {                                                                                            \
+        /* the base never leaves the last tile: past it the request re-reads those rows (a stage nobody reads again) */ \
+        baseA += (t + 3 < ntiles) ? stepA : 0;                                                                \
+        baseB += (t + 3 < ntiles) ? stepB : 0;                                                                \
+      }                                                                                                       \
+      __builtin_amdgcn_sched_barrier(0);                                                                      \
+    }                                                                                                         \
+    st = stn_;                                                                                                \
+  } while (0)
+
+  int st = 0;
+  int t = 0;
+  if (lead_half) {
+    QK_TILE(4);
+    t = 1;
   }
+  for (; t < ntiles; ++t) QK_TILE(8);
+#undef QK_TILE
+#undef QK_PIECE
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
   // ---- epilogue ---------------------------------------------------------------------------------
   float* Cb = C + boffC;
@@ -328,6 +362,7 @@ using namespace qamdk;
 extern "C" int qamd_gemmk_launch(int ta, int tb, const GettArgs* a, const void* A, const void* B, void* C,
                                  const void* scale_a, const void* scale_b, void* absmax_out, void* stream) {
   hipStream_t st = (hipStream_t)stream;
+  if (a->K < 48 || a->K % 8 || a->M < 4 || a->N < 4 || a->M % 4 || a->N % 4) return -2;
 #define QK_CASE(TA_, TB_, MINW_) \
   if (ta == TA_ && tb == TB_) return launch_one<TA_, TB_, 3, MINW_>(*a, A, B, C, scale_a, scale_b, absmax_out, st);
   QK_CASE(4, 4, 1) QK_CASE(4, 3, 1) QK_CASE(3, 4, 1) QK_CASE(3, 3, 1)

@@ -531,11 +531,10 @@ def check_gemmk(seed=21, tiles=(None,)):
                 b = rand(rng, [dims[c] for c in bi], "float32")
                 want = np.einsum(eq, a.astype(np.float64), b.astype(np.float64))
                 got = qa.einsum(eq, qa.asarray(a), qa.asarray(b))
-                # fp32 k-ordered fma chain: error <= ~1e-7 * sum |a b|; sum |a b| <= K * 1 * 1 here
-                kk = np.prod([dims[c] for c in set(ai) & set(bi) - set(out)])
-                assert_close(got.to_numpy(), want, "float32", scale=None)
+                # fp32 k-ordered fma chain: error ~1e-7 * sum_k |a b| per element; 4e-7 is the hard cap
+                bound = 4e-7 * np.max(np.einsum(eq, np.abs(a).astype(np.float64), np.abs(b).astype(np.float64)))
                 err = np.max(np.abs(got.to_numpy().astype(np.float64) - want))
-                assert err <= 2e-7 * kk * 0.5625, (eq, tile, err)
+                assert err <= bound, (eq, tile, err, bound)
         finally:
             os.environ.pop("QAMD_GEMMK_TILE", None)
             if hasattr(dev, "_pairs"):
