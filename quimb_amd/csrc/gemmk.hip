@@ -267,6 +267,8 @@ __global__ __launch_bounds__(256, MINW) void gemmk_kernel(const GettArgs p, cons
             }                                                                                                 \
           }                                                                                                   \
       if (sync_) {                                                                                            \
+        /* (2 x 2 sub-tiles: one piece more than there are MFMAs to put them behind) */                     \
+        _Pragma("unroll") for (int q = TA * TB - 1; q < TA + TB; ++q) QK_PIECE(q, st2_);                     \
         /* the base never leaves the last tile: past it the request re-reads those rows (a stage nobody reads again) */ \
         baseA += (t + 3 < ntiles) ? stepA : 0;                                                                \
         baseB += (t + 3 < ntiles) ? stepB : 0;                                                                \

@@ -531,8 +531,10 @@ def check_gemmk(seed=21, tiles=(None,)):
                 b = rand(rng, [dims[c] for c in bi], "float32")
                 want = np.einsum(eq, a.astype(np.float64), b.astype(np.float64))
                 got = qa.einsum(eq, qa.asarray(a), qa.asarray(b))
-                # fp32 k-ordered fma chain: error ~1e-7 * sum_k |a b| per element; 4e-7 is the hard cap
-                bound = 4e-7 * np.max(np.einsum(eq, np.abs(a).astype(np.float64), np.abs(b).astype(np.float64)))
+                # fp32 k-ordered fma chain, one rounding (<= 2^-24 relative) per partial sum: the error of an element is a
+                # random walk of K such roundings, ~sqrt(K) 2^-24 sum_k |a b|; 2 x that for the max over ~1e5 elements
+                kk = int(np.prod([dims[c] for c in set(ai) & set(bi) - set(out)]))
+                bound = 2 * np.sqrt(kk) * 2.0**-24 * np.max(np.einsum(eq, np.abs(a).astype(np.float64), np.abs(b).astype(np.float64)))
                 err = np.max(np.abs(got.to_numpy().astype(np.float64) - want))
                 assert err <= bound, (eq, tile, err, bound)
         finally:
