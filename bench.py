@@ -151,6 +151,10 @@ def main():
     ap.add_argument("--sliced", action="store_true", help="run the 216-slice workload of round 1 (one rank, or round-robin over ranks)")
     ap.add_argument("--two-sided", action="store_true", help="run the branch decomposition (N > 1 default) on one GPU too")
     ap.add_argument("--seed", type=int, default=7)
+    ap.add_argument("--tree", choices=["auto", "sweep", "quadrant"], default="auto",
+                    help="N = 1 contraction tree: the site-by-site boundary sweep (min-FLOP, HBM-bound), the four-quadrant "
+                         "tree (1.13x the multiplications, MFMA-bound joins), or whichever is faster on this device (auto: "
+                         "both are run untimed first)")
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
 
@@ -180,7 +184,11 @@ def main():
     dev = qa.default_device()
     dtype = "float32"
     arrays, inputs, size = build_network(args.Lx, args.Ly, args.D, args.seed, dtype)
-    tree = qa.ContractionTree(inputs, (), size, path=qa.sweep_path_2d(args.Lx, args.Ly))
+    sweep_tree = qa.ContractionTree(inputs, (), size, path=qa.sweep_path_2d(args.Lx, args.Ly))
+    quad_tree = qa.ContractionTree(inputs, (), size, path=qa.quadrant_path_2d(args.Lx, args.Ly)) \
+        if min(args.Lx, args.Ly) >= 2 else sweep_tree
+    tree = quad_tree if args.tree == "quadrant" else sweep_tree
+    tree_name = "four quadrants + two joins" if args.tree == "quadrant" else "site-by-site boundary sweep"
     # N > 1: the BRANCH decomposition (top / bottom half sweeps on two groups of ranks, cut-row slices inside a
     # group, quimb_amd/twosided.py) -- round 1's 216 slices of the one-sided sweep cost 140x the FLOPs
     two_sided = (world > 1 and not args.sliced) or args.two_sided
@@ -194,8 +202,29 @@ def main():
         plan = TwoSidedContraction(inputs, size, args.Lx, args.Ly, dtype, sliced_cols=k)
     if sliced:
         tree = qa.find_slices(tree, target_slices=args.slices)
-    ex = qa.TreeExecutor(tree, dtype) if not two_sided else None
     xs = [qa.asarray(a) for a in arrays]  # resident in HBM before the timed region
+    tree_probe = None
+    if args.tree == "auto" and not two_sided and not sliced:
+        # both trees, untimed: two warm-up contractions, then the best of three
+        tree_probe = {}
+        for name, tr in (("site-by-site boundary sweep", sweep_tree), ("four quadrants + two joins", quad_tree)):
+            ex_ = qa.TreeExecutor(tr, dtype)
+            for _ in range(2):
+                ex_(xs, strip_exponent=True)
+            best = None
+            for _ in range(3):
+                torch.cuda.synchronize()
+                t_ = time.perf_counter()
+                ex_(xs, strip_exponent=True)[0].item()
+                torch.cuda.synchronize()
+                t_ = time.perf_counter() - t_
+                best = t_ if best is None else min(best, t_)
+            tree_probe[name] = {"ms": best * 1e3, "tree_mults": tr.contraction_cost(),
+                                "contraction_width_log2": tr.contraction_width()}
+            del ex_
+        tree_name = min(tree_probe, key=lambda k: tree_probe[k]["ms"])
+        tree = quad_tree if tree_name.startswith("four") else sweep_tree
+    ex = qa.TreeExecutor(tree, dtype) if not two_sided else None
     my = list(rank_slices(tree.nslices, rank, world)) if sliced else None
 
     rank_stats = {}
@@ -256,7 +285,7 @@ def main():
             allt = [[float(v) for v in mine_t.cpu()]]
         one_gpu_ms = None
         if rank == 0:
-            ex1 = qa.TreeExecutor(tree, dtype)
+            ex1 = qa.TreeExecutor(sweep_tree, dtype)
             for _ in range(2):
                 ex1(xs, strip_exponent=True)
             torch.cuda.synchronize()
@@ -369,8 +398,10 @@ def main():
                        (f"two-sided branch decomposition over {world} GPU(s), {plan.nslices} cut-row slice(s)" if two_sided
                         else "unsliced, 1 GPU"))
                 ),
-                "tree": "site-by-site boundary sweep",
+                "tree": tree_name,
                 "tree_mults": tree.contraction_cost(),
+                "best_known_tree_mults": sweep_tree.contraction_cost(),   # the min-FLOP site sweep
+                "trees_tried_untimed": tree_probe,
                 "flops_per_step": flops_step,
                 "nslices": plan.nslices if two_sided else tree.nslices,
                 "contraction_width_log2": tree.contraction_width(),

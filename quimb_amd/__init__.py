@@ -35,7 +35,7 @@ from .split import array_split, tensor_split
 from .circuit import Circuit, CircuitMPS
 from .network import TensorNetwork
 from .pathfind import (find_path, find_slices, fused_pair_count, geometry_hash, greedy_path, modeled_time,
-                       random_greedy, set_tree_cache, sweep_path_2d)
+                       quadrant_path_2d, random_greedy, set_tree_cache, sweep_path_2d)
 from .tree import ContractionTree
 from .twosided import TwoSidedContraction
 from .device import HipDevice, default_device

@@ -8,6 +8,7 @@ part of this build, so the executor ships its own finders:
 * ``greedy_path``      -- size-difference greedy (the classic opt_einsum rule)
 * ``random_greedy``    -- Boltzmann-perturbed greedy restarts, keep the cheapest
 * ``sweep_path_2d``    -- row-by-row, site-by-site boundary sweep of an Lx x Ly grid
+* ``quadrant_path_2d`` -- four corner sweeps + two GEMM-shaped joins + a dot product (MFMA-bound, shardable)
 * ``find_slices``      -- greedy choice of sliced indices (what cotengra's
                           SliceFinder does) so that the slices can be sharded
 * ``modeled_time``     -- roofline time of the executor's plan for a tree; ``minimize="time"`` /
@@ -181,6 +182,50 @@ def sweep_ssa_2d(Lx, Ly):
 
 def sweep_path_2d(Lx, Ly):
     return ssa_to_linear(sweep_ssa_2d(Lx, Ly), Lx * Ly)
+
+
+def quadrant_ssa_2d(Lx, Ly, rx=None, cy=None):
+    """SSA path for a row-major Lx x Ly grid that contracts the four QUADRANTS (rows < rx / >= rx, columns < cy /
+    >= cy, default the middle) site by site from their outer corners, joins the two upper and the two lower
+    quadrants over the bonds they share and closes with the product of the two halves:
+
+        T = TL . TR,   B = BL . BR,   Z = T . B
+
+    On the 10 x 10 D = 6 lattice that is 9.84e11 multiplications (1.13 x the site sweep's 8.72e11) with a largest
+    intermediate of 6^10 elements (242 MB instead of 1.45 GB), and ~96 % of them sit in the two joins -- plain
+    7776^3 matrix products, MFMA-bound (AI ~1300 flop/B) where every step of the sweep is HBM-bound, and
+    shardable by rows / columns of T and B with no redundancy (quimb_amd/quadrants.py).  The reference analogue is
+    the tree cotengra finds for ``TensorNetwork.contraction_tree`` (quimb/tensor/tensor_core.py:9004-9014) and the
+    closing product of a two-sided boundary contraction (quimb/tensor/tn2d/core.py:2493-2498)."""
+    rx = Lx // 2 if rx is None else rx
+    cy = Ly // 2 if cy is None else cy
+    if not (0 < rx < Lx and 0 < cy < Ly):
+        raise ValueError("the cut must leave four non-empty quadrants")
+    nxt = [Lx * Ly]
+    ssa = []
+    sid = lambda r, c: r * Ly + c
+
+    def sweep(sites):
+        cur = sites[0]
+        for s_ in sites[1:]:
+            ssa.append((cur, s_))
+            cur = nxt[0]
+            nxt[0] += 1
+        return cur
+
+    tl = sweep([sid(r, c) for r in range(rx) for c in range(cy)])
+    tr = sweep([sid(r, c) for r in range(rx) for c in range(Ly - 1, cy - 1, -1)])
+    bl = sweep([sid(r, c) for r in range(Lx - 1, rx - 1, -1) for c in range(cy)])
+    br = sweep([sid(r, c) for r in range(Lx - 1, rx - 1, -1) for c in range(Ly - 1, cy - 1, -1)])
+    for pair in ((tl, tr), (bl, br)):
+        ssa.append(pair)
+        nxt[0] += 1
+    ssa.append((nxt[0] - 2, nxt[0] - 1))
+    return ssa
+
+
+def quadrant_path_2d(Lx, Ly, rx=None, cy=None):
+    return ssa_to_linear(quadrant_ssa_2d(Lx, Ly, rx, cy), Lx * Ly)
 
 
 def geometry_hash(inputs, output, size_dict, extra=""):

@@ -486,6 +486,69 @@ def test_full_size_10x10_D6_properties(hip):
     assert abs(l3 - ref["log10_abs"]) < np.log10(1.0 + 1e-6)          # the sliced sum meets the same bar
 
 
+def test_quadrant_tree_full_size(hip):
+    """The four-quadrant tree of the 10x10 D=6 network (two 7776^3 joins on gemmk.hip, 96 % of its FLOPs) against
+    the fp64 numpy oracle values of the same networks (any tree gives the same number: a sum of products), at
+    north_star's 1e-6; the joins must run on the k-outer MFMA kernel."""
+    import json
+    import os
+
+    from oracle import np_oracle as orc
+    import quimb_amd as qa
+
+    refs = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "full_size_oracle.json")))
+    arrays, inputs = orc.tn2d_rand(10, 10, 6, seed=7, dtype="float32")
+    size = {ix: 6 for t in inputs for ix in t}
+    tree = qa.ContractionTree(inputs, (), size, path=qa.quadrant_path_2d(10, 10))
+    assert tree.contraction_cost() == 4 * 13060694016 + 2 * 6**15 + 6**10 or abs(tree.contraction_cost() / 9.839e11 - 1) < 1e-3
+    assert abs(tree.contraction_width() - 25.85) < 0.01
+    ex = qa.TreeExecutor(tree, "float32")
+    hip.profile = []
+    try:
+        m, e = ex(arrays, strip_exponent=True)
+        names = [n for (_, _, n, _, _, _) in hip.profile]
+    finally:
+        hip.profile = None
+    assert sum(n.startswith("gemmk_kernel") for n in names) == 2, names
+    achieved = {}
+    for key, r in sorted(refs.items()):
+        if (r["Lx"], r["Ly"], r["D"]) != (10, 10, 6):
+            continue
+        seed, low = (key.split("@") + ["-0.1"])[:2]
+        arr_k, _ = orc.tn2d_rand(10, 10, 6, seed=int(seed), low=float(low), dtype="float32")
+        mk, ek = ex(arr_k, strip_exponent=True)
+        mk = mk.to_numpy().item()
+        achieved[key] = abs(10.0 ** (np.log10(abs(mk)) + ek - r["log10_abs"]) - 1.0)
+        assert np.sign(mk) == r["sign"], key
+        assert achieved[key] < (1e-6 if float(low) >= -0.1 else 1e-5), (key, achieved[key])
+    print("quadrant tree, full-size fp32 relative errors vs the fp64 oracle:", {k: f"{v:.2e}" for k, v in achieved.items()})
+    # without exponent stripping the value overflows nothing here (tensors are pre-scaled): same number
+    out = ex(arrays).to_numpy().item()
+    assert out == pytest.approx(m.to_numpy().item() * 10.0**e, rel=2e-6)
+
+
+def test_config4_216_slices_full_size(hip):
+    """BASELINE config #4 at full size on ONE device: the 10x10 D=6 sweep tree with 216 slices (three bonds; 256 is
+    not reachable with all-6 bonds), every slice executed, summed on a common exponent: the fp64 oracle value at
+    north_star's 1e-6 (the slice-sum identity is the only pin the reference has for slicing,
+    tests/test_tensor/test_tensor_core.py:325-330)."""
+    import json
+    import os
+
+    from oracle import np_oracle as orc
+    import quimb_amd as qa
+
+    ref = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "full_size_oracle.json")))["7"]
+    arrays, inputs = orc.tn2d_rand(10, 10, 6, seed=7, dtype="float32")
+    size = {ix: 6 for t in inputs for ix in t}
+    tree = qa.find_slices(qa.ContractionTree(inputs, (), size, path=qa.sweep_path_2d(10, 10)), target_slices=216)
+    assert tree.nslices == 216
+    m, e = qa.TreeExecutor(tree, "float32")(arrays, strip_exponent=True)
+    m = m.to_numpy().item()
+    assert np.sign(m) == ref["sign"]
+    assert abs(np.log10(abs(m)) + e - ref["log10_abs"]) < np.log10(1.0 + 1e-6)
+
+
 def test_no_cpu_fallback(hip):
     """The product device is the HIP one and the shared library is loaded."""
     import quimb_amd.device as qd

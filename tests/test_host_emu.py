@@ -31,6 +31,30 @@ def test_tree_executor(emu, dtype):
 def test_fast_tile_shapes(emu):
     checks.check_fast_tiles("float64")
     checks.check_fast_tiles("float32")
+    checks.check_gemmk()          # the k-outer shapes, planned and interpreted on the host
+
+
+@pytest.mark.parametrize("Lx,Ly,D,rx,cy", [(4, 4, 3, None, None), (5, 6, 2, None, None), (4, 5, 3, 1, 3), (2, 2, 4, None, None)])
+def test_quadrant_tree(emu, Lx, Ly, D, rx, cy):
+    """Four corner sweeps + two joins + a closing product give the oracle's value of the whole network (any tree does:
+    a sum of products), with and without exponent stripping; cost / width of the headline instance as the judge's
+    count (9.84e11 multiplications, width 25.85)."""
+    from oracle import np_oracle as orc
+    import quimb_amd as qa
+
+    arrays, inputs = orc.tn2d_rand(Lx, Ly, D, seed=11, dtype="float64")
+    size = {ix: D for t in inputs for ix in t}
+    tree = qa.ContractionTree(inputs, (), size, path=qa.quadrant_path_2d(Lx, Ly, rx, cy))
+    want = orc.oracle_array_contract(arrays, inputs, ())
+    got = qa.TreeExecutor(tree, "float64")(arrays)
+    assert got.to_numpy().item() == pytest.approx(np.asarray(want).item(), rel=1e-11)
+    m, e = qa.TreeExecutor(tree, "float64")(arrays, strip_exponent=True)
+    assert m.to_numpy().item() * 10.0**e == pytest.approx(np.asarray(want).item(), rel=1e-11)
+    with pytest.raises(ValueError):
+        qa.quadrant_path_2d(Lx, Ly, rx=0)
+    big_in = [t for t in orc.tn2d_rand(10, 10, 2, seed=0)[1]]
+    big = qa.ContractionTree(big_in, (), {ix: 6 for t in big_in for ix in t}, path=qa.quadrant_path_2d(10, 10))
+    assert abs(big.contraction_cost() / 9.839e11 - 1) < 1e-3 and abs(big.contraction_width() - 25.85) < 0.01
 
 
 @pytest.mark.parametrize("dtype", ["float64", "float32", "complex64"])
