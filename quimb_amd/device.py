@@ -120,6 +120,15 @@ class HipDevice:
     def synchronize(self):
         self.torch.cuda.synchronize(self.tdev)
 
+    def lane_streams(self, n):
+        """[current stream, side stream 1, ...]: the HIP streams the tree executor runs independent branches on."""
+        pool = getattr(self, "_lane_pool", None)
+        if pool is None:
+            pool = self._lane_pool = []
+        while len(pool) < n - 1:
+            pool.append(self.torch.cuda.Stream(device=self.tdev))
+        return [self.torch.cuda.current_stream(self.tdev)] + pool[: n - 1]
+
     def _workspace(self, nbytes):
         if nbytes <= 0:
             return None, 0

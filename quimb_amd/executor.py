@@ -110,6 +110,7 @@ class TreeExecutor:
         self.layout = layout
         self.dep = dep
         self._fuse_pairs(size)
+        self._assign_lanes()
         if len(tree.remaining) != 1:
             raise ValueError("contraction path does not reduce the network to a single tensor")
         (self.root,) = tree.remaining
@@ -176,6 +177,48 @@ class TreeExecutor:
                 i += 1
         self.plan, self.info = new_plan, new_info
 
+    @staticmethod
+    def _entry_io(entry):
+        """(operand ssa ids, result ssa id) of a plan entry"""
+        k = entry[0]
+        if k == "single":
+            return (entry[1],), entry[2]
+        if k == "chain2":
+            return (entry[1], entry[2], entry[3]), entry[4]
+        if k == "chain3":
+            return (entry[1], entry[2], entry[3], entry[4]), entry[5]
+        return (entry[1], entry[2]), entry[3]
+
+    def _assign_lanes(self, max_lanes=8, min_steps=4):
+        """Independent branches of the tree run concurrently: every plan entry gets a LANE (a HIP stream at run
+        time).  Walking down from the root, the heaviest operand sub-tree of a step stays on the step's lane, every
+        other operand sub-tree of at least ``min_steps`` launches opens a lane of its own and joins back (one event)
+        right before the step that consumes it.  A chain -- a boundary sweep -- is one lane; the four corner sweeps of
+        ``quadrant_path_2d`` are four, so their many small, latency-bound launches overlap."""
+        n = len(self.plan)
+        prod = {}
+        for i, e in enumerate(self.plan):
+            prod[self._entry_io(e)[1]] = i
+        weight, count, kids = [0] * n, [1] * n, [()] * n
+        for i, e in enumerate(self.plan):
+            ch = tuple(prod[o] for o in self._entry_io(e)[0] if o in prod)
+            kids[i] = ch
+            weight[i] = self.info[i].bytes + sum(weight[c] for c in ch)
+            count[i] = 1 + sum(count[c] for c in ch)
+        lane = [0] * n
+        nxt = 1
+        for i in range(n - 1, -1, -1):          # parents follow their operands in plan order
+            ch = sorted(kids[i], key=lambda c: -weight[c])
+            for rank, c in enumerate(ch):
+                if rank > 0 and count[c] >= min_steps and nxt < max_lanes:
+                    lane[c] = nxt
+                    nxt += 1
+                else:
+                    lane[c] = lane[i]
+        self.lanes = lane
+        self.nlanes = nxt
+        self._producer = prod
+
     # ---- accounting -------------------------------------------------------------
     def flops(self, per_slice=False, hoist=True):
         """Floating-point operations actually executed (2 per real multiply-add,
@@ -210,7 +253,16 @@ class TreeExecutor:
             key[ax] = vals[ix]
         return x[tuple(key)]
 
-    def _run_core(self, inputs, exponent, cache, only_independent=False):
+    def _run_core(self, inputs, exponent, cache, only_independent=False, lanes=False):
+        dev = inputs[0]._dev
+        home = dev.torch.cuda.current_stream(dev.tdev) if hasattr(dev, "torch") else None
+        try:
+            return self._run_core_impl(inputs, exponent, cache, only_independent, lanes)
+        finally:
+            if home is not None:
+                dev.torch.cuda.set_stream(home)      # lanes switch the current stream: always hand the caller's back
+
+    def _run_core_impl(self, inputs, exponent, cache, only_independent=False, lanes=False):
         """Evaluate the tree for one slice.  ``cache`` maps ssa id -> Array for
         slice-independent intermediates (filled on first use).
 
@@ -225,6 +277,13 @@ class TreeExecutor:
             nid = len(inputs) + len(self.tree.steps)
             slots = dev.new_slots(nid, self.dtype)
             has_scale = set()
+        # branch concurrency (unsliced runs on the HIP device): lane -> stream; lane 0 is the caller's stream
+        streams = None
+        if lanes and self.nlanes > 1 and hasattr(dev, "lane_streams") and os.environ.get("QAMD_LANES", "1") != "0":
+            streams = dev.lane_streams(self.nlanes)
+            for st_ in streams[1:]:
+                st_.wait_stream(streams[0])       # inputs / slots are ready on the caller's stream
+        keep_alive = []   # buffers handed from one lane to another stay allocated until every launch is queued
         uses = {}
         def operands(entry):
             if entry[0] == "single":
@@ -238,7 +297,15 @@ class TreeExecutor:
         for entry in self.plan:
             for s in operands(entry):
                 uses[s] = uses.get(s, 0) + 1
-        for entry in self.plan:
+        for pi, entry in enumerate(self.plan):
+            if streams is not None:
+                mine = streams[self.lanes[pi]]
+                for o in self._entry_io(entry)[0]:
+                    pj = self._producer.get(o)
+                    if pj is not None and self.lanes[pj] != self.lanes[pi]:
+                        mine.wait_stream(streams[self.lanes[pj]])     # the join: one event
+                        keep_alive.append(live[o])
+                dev.torch.cuda.set_stream(mine)
             if entry[0] == "single":
                 _, a, res, src, out = entry
                 independent = not self.dep[res]
@@ -327,6 +394,8 @@ class TreeExecutor:
                 uses[s] -= 1
                 if uses[s] == 0:
                     live.pop(s, None)
+        if streams is not None:
+            dev.torch.cuda.set_stream(streams[0])
         out = live.get(self.root)
         if exponent is not None and out is not None:
             if self.root in has_scale:
@@ -389,12 +458,14 @@ class TreeExecutor:
             ent["g"].replay()
         return acc.copy(), dev.read_exponent(acc_exp)
 
-    def __call__(self, arrays, strip_exponent=False, slices=None, hoist=True):
+    def __call__(self, arrays, strip_exponent=False, slices=None, hoist=True, defer_exponent=False):
         """Contract.  ``slices``: iterable of slice numbers to evaluate (default
         all); the partial sum over exactly those slices is returned, which is what
         a rank of the multi-GPU driver needs before the RCCL reduce.
 
-        Returns an ``Array`` (or ``(Array, exponent)`` if ``strip_exponent``)."""
+        Returns an ``Array`` (or ``(Array, exponent)`` if ``strip_exponent``).  ``defer_exponent`` (unsliced trees):
+        the exponent comes back as the device-resident accumulator instead of a float, so the call does not
+        synchronise with the device -- ``dev.read_exponent(e)`` reads it later."""
         tree = self.tree
         if len(arrays) != len(tree.inputs):
             raise ValueError(f"expected {len(tree.inputs)} arrays, got {len(arrays)}")
@@ -421,9 +492,9 @@ class TreeExecutor:
             return (out, 0.0) if strip_exponent else out
         if nsl == 1:
             exponent = dev.new_exponent() if strip_exponent else None
-            out = self._run_core(xs, exponent, None)
+            out = self._run_core(xs, exponent, None, lanes=True)
             if strip_exponent:
-                return out, dev.read_exponent(exponent)
+                return (out, exponent) if defer_exponent else (out, dev.read_exponent(exponent))
             return out
 
         todo = range(nsl) if slices is None else list(slices)
@@ -499,7 +570,7 @@ class GraphedContraction:
         s.wait_stream(torch.cuda.current_stream(dev.tdev))
         with torch.cuda.stream(s):
             for _ in range(2):
-                executor._run_core(self.inputs, dev.new_exponent() if strip_exponent else None, None)
+                executor._run_core(self.inputs, dev.new_exponent() if strip_exponent else None, None, lanes=True)
         torch.cuda.current_stream(dev.tdev).wait_stream(s)
         torch.cuda.synchronize(dev.tdev)
         self._graph = torch.cuda.CUDAGraph()
@@ -507,7 +578,7 @@ class GraphedContraction:
         with torch.cuda.graph(self._graph, capture_error_mode="thread_local"):
             if strip_exponent:
                 self._exponent.zero_()
-            self.output = executor._run_core(self.inputs, self._exponent, None)
+            self.output = executor._run_core(self.inputs, self._exponent, None, lanes=True)
 
     def update(self, i, array):
         """Overwrite static input ``i`` in place (device-to-device or host-to-device copy)."""
