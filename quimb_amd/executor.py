@@ -191,32 +191,43 @@ class TreeExecutor:
 
     def _assign_lanes(self, max_lanes=8, min_steps=4):
         """Independent branches of the tree run concurrently: every plan entry gets a LANE (a HIP stream at run
-        time).  Walking down from the root, the heaviest operand sub-tree of a step stays on the step's lane, every
-        other operand sub-tree of at least ``min_steps`` launches opens a lane of its own and joins back (one event)
-        right before the step that consumes it.  A chain -- a boundary sweep -- is one lane; the four corner sweeps of
-        ``quadrant_path_2d`` are four, so their many small, latency-bound launches overlap."""
+        time).  A step with ONE sizeable operand sub-tree continues that sub-tree's chain on the same lane (a
+        boundary sweep is one lane).  A JOIN -- two or more operand sub-trees of at least ``min_steps`` launches --
+        stays on its parent's lane (the root's is lane 0, the caller's stream) and every chain below it opens a lane
+        of its own, joining back with one event right before the join; joins below joins stay on the same lane, so
+        the big GEMM-shaped joins of ``quadrant_path_2d`` run one after the other on lane 0 while its four corner
+        sweeps -- many small, latency-bound launches -- overlap on lanes 1..4."""
         n = len(self.plan)
         prod = {}
         for i, e in enumerate(self.plan):
             prod[self._entry_io(e)[1]] = i
-        weight, count, kids = [0] * n, [1] * n, [()] * n
+        count, kids = [1] * n, [()] * n
         for i, e in enumerate(self.plan):
             ch = tuple(prod[o] for o in self._entry_io(e)[0] if o in prod)
             kids[i] = ch
-            weight[i] = self.info[i].bytes + sum(weight[c] for c in ch)
             count[i] = 1 + sum(count[c] for c in ch)
         lane = [0] * n
-        nxt = 1
-        for i in range(n - 1, -1, -1):          # parents follow their operands in plan order
-            ch = sorted(kids[i], key=lambda c: -weight[c])
-            for rank, c in enumerate(ch):
-                if rank > 0 and count[c] >= min_steps and nxt < max_lanes:
-                    lane[c] = nxt
-                    nxt += 1
-                else:
-                    lane[c] = lane[i]
+        nxt = [1]
+        big_kids = lambda i: [c for c in kids[i] if count[c] >= min_steps]
+        stack = [(n - 1, 0)] if n else []
+        while stack:
+            i, ln = stack.pop()
+            lane[i] = ln
+            big = big_kids(i)
+            for c in kids[i]:
+                if c not in big:
+                    stack.append((c, ln))
+            if len(big) >= 2:
+                for c in big:
+                    if len(big_kids(c)) >= 2 or nxt[0] >= max_lanes:
+                        stack.append((c, ln))          # a join below a join / out of lanes: same lane
+                    else:
+                        stack.append((c, nxt[0]))
+                        nxt[0] += 1
+            elif big:
+                stack.append((big[0], ln))
         self.lanes = lane
-        self.nlanes = nxt
+        self.nlanes = nxt[0]
         self._producer = prod
 
     # ---- accounting -------------------------------------------------------------

@@ -249,12 +249,19 @@ def plan_pair(a_inds, a_shape, b_inds, b_shape, out_inds, out_fixed=True, death=
         # run -- the streaming kernel's ideal operand -- and because every operand is
         # already death-ordered the surviving M indices keep their relative order, so
         # they fuse on both the load and the store side.  Stable: ties keep the big
-        # operand's order, then the small operand's.
+        # operand's order, then the small operand's -- except in the group that dies NEXT
+        # (the consumer's contraction bundle, the outermost block): a new index joins it at
+        # its OUTER end, so that the surviving indices behind it stay one contiguous run in
+        # the operand and in the result (open legs of a corner sweep, all contracted by one
+        # later join: [h_new, h_old..., spectators..., d_new] instead of a run split in two).
         dmap = dict(death) if death else {}
         big = 1 << 60
         kset = set(kk)
         cand = [ix for ix in va.inds if ix not in kset] + list(nn)
-        oi = tuple(sorted(cand, key=lambda ix: dmap.get(ix, big)))
+        first = min((dmap.get(ix, big) for ix in cand), default=big)
+        nset = set(nn)
+        oi = tuple(sorted(cand, key=lambda ix: (dmap.get(ix, big),
+                                                0 if (dmap.get(ix, big) == first and first < big and ix in nset) else 1)))
     oshape = tuple(size[ix] for ix in oi)
     sc = dict(zip(oi, contig_strides(oshape)))
 
