@@ -91,6 +91,8 @@ class HipDevice:
         #: set to a list to collect (spec, dtype, tile_cfg, split_k, start_event, end_event)
         #: per qamd_contract_pair launch (HIP events on the launch stream)
         self.profile = None
+        #: launches below this many multiplications are not bracketed by events when ``profile`` is a list
+        self.profile_min_mults = 0
         self.force_tile_cfg = int(os.environ.get("QAMD_TILE_CFG", "-1"))
         self.force_split_k = int(os.environ.get("QAMD_SPLIT_K", "0"))
         #: 0 = auto (streaming kernel where eligible), -1 = always the tiled GETT kernel
@@ -188,6 +190,8 @@ class HipDevice:
             e.absmax_out = ep[2].data_ptr() if ep[2] is not None else None
             epp = C.byref(e)
         prof = self.profile
+        if prof is not None and getattr(spec, "mults", self.profile_min_mults) < self.profile_min_mults:
+            prof = None      # an event pair costs a small launch ~10 us of queue time: only the launches that matter
         if prof is not None:
             e0 = self.torch.cuda.Event(enable_timing=True)
             e1 = self.torch.cuda.Event(enable_timing=True)
@@ -253,6 +257,8 @@ class HipDevice:
         if ep is not None:
             sa, s1, s2, so = (ptr(t) for t in ep)
         prof = self.profile
+        if prof is not None and c2.mults < self.profile_min_mults:
+            prof = None
         if prof is not None:
             e0 = self.torch.cuda.Event(enable_timing=True)
             e1 = self.torch.cuda.Event(enable_timing=True)

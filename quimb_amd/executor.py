@@ -208,6 +208,7 @@ class TreeExecutor:
             count[i] = 1 + sum(count[c] for c in ch)
         lane = [0] * n
         nxt = [1]
+        home_taken = [False]
         big_kids = lambda i: [c for c in kids[i] if count[c] >= min_steps]
         stack = [(n - 1, 0)] if n else []
         while stack:
@@ -221,6 +222,9 @@ class TreeExecutor:
                 for c in big:
                     if len(big_kids(c)) >= 2 or nxt[0] >= max_lanes:
                         stack.append((c, ln))          # a join below a join / out of lanes: same lane
+                    elif ln == 0 and not home_taken[0]:
+                        home_taken[0] = True           # ONE chain runs ahead of the joins on the caller's stream:
+                        stack.append((c, 0))           # four corner sweeps = four streams = the default HW queues
                     else:
                         stack.append((c, nxt[0]))
                         nxt[0] += 1
