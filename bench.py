@@ -4,18 +4,21 @@ amplitude (single-layer 10x10 D=6 tensor network, fp32), MI355X.
 
     python bench.py --gpus N --steps K --warmup W
 
-* N == 1 (BASELINE.json configs[2]): one step = one exact contraction of the
-  whole network (site-by-site boundary sweep tree, 1.745e12 FLOP), inputs
-  resident in HBM, result read back as an 8-byte (mantissa, exponent).
-* N  > 1 (configs[3]): the same network with 216 slices (three bonds of size 6;
-  256 is not reachable with all-6 bonds) sharded round-robin over the ranks, one
-  RCCL all-reduce of the scalar at the join; strong scaling (total slices fixed).
-  ``--sliced`` runs that workload on one GPU too.
+* N == 1 (BASELINE.json configs[2]): one step = one exact contraction of the whole network, inputs resident in HBM,
+  the (mantissa, exponent) pair read back after the timed region.  Tree: the faster of the site-by-site boundary
+  sweep (8.72e11 multiplications, HBM-bound) and the four-quadrant tree (9.84e11, two 7776^3 MFMA-bound joins) --
+  both run untimed first, ``config`` names the one timed and quotes both multiplication counts.
+* N  > 1 (configs[3]): the four-quadrant tree with the cut bonds range-sliced over the ranks (halves of 1 / 2 / 3
+  bonds at N = 2 / 4 / 8: rank (i, j) of a P x Q grid contracts block (i, j) of the two joins), nothing exchanged on
+  the data path, ONE RCCL all-gather of (mantissa, exponent) pairs at the join; strong scaling: ``value`` = the
+  one-rank tree's FLOPs / max-over-ranks time.  (256 slices are not reachable with all-6 bonds; ``--sliced`` keeps
+  round 1's 216 single-value slices of the sweep, ``--two-sided`` round 2's branch decomposition.)
+* N == 1 also reports: ``secondary`` (BASELINE configs #2 and #5: circuit amplitude, DMRG2 matvec / local update),
+  ``scaling_projection`` (the busiest rank's share of the N = 2 / 4 / 8 jobs timed on this one GPU) and
+  ``cpu_baseline``.
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with the extra
-``roofline`` (dominant kernel, HIP events on the launch stream) and
-``cpu_baseline`` (numpy/OpenBLAS port of the same sweep on a bounded sample)
-objects.
+Prints ONE JSON line on rank 0 (contract in the task statement) with the extra ``roofline`` (dominant kernel, HIP
+events on the launch stream) and ``cpu_baseline`` (numpy/OpenBLAS port of the sweep on a bounded sample) objects.
 """
 
 import argparse
@@ -85,11 +88,11 @@ def _result_with_parity(res, args):
     return out
 
 
-def cpu_baseline(D, Ly, seed, rows=4, repeats=3):
+def cpu_baseline(D, Ly, seed, rows=3, repeats=5):
     """quimb's numpy path restated (oracle/np_oracle.py: per step tensordot through OpenBLAS, strip_exponent) on a
     BOUNDED sample of the same workload: the top ``rows`` rows of the same 10-wide network, same site-by-site
-    sweep (rows = 4: two full-size interior rows, 0.44 of the 1.74 TFLOP; the whole network takes ~9 minutes on the
-    host).  The BLAS thread count is swept on the 3-row sample first (threadpoolctl; the default of one thread
+    sweep (rows = 3: one full-size interior row between a first and a last row; the whole network takes ~9 minutes on
+    the host: ``full_network_seconds`` quotes the recorded fp64 run of tests/golden/make_full_size_oracle.py).  The BLAS thread count is swept on the 2-row sample first (threadpoolctl; the default of one thread
     per core oversubscribes the skinny 6^9 x 36 x 36 products), then the sample is timed ``repeats`` times after
     one warm-up at the best count and the MEDIAN is reported, with the thread count next to the core count."""
     from oracle import np_oracle as orc
@@ -117,7 +120,7 @@ def cpu_baseline(D, Ly, seed, rows=4, repeats=3):
             orc.oracle_array_contract(arrays, inputs, (), path=tree.get_path(), strip_exponent=True)
         return time.perf_counter() - t0
 
-    small = sample(3)
+    small = sample(2)
     sweep = {}
     for th in sorted({min(cores, t) for t in (16, 32, 64, cores)}):
         sweep[th] = run(small, th)
@@ -135,8 +138,32 @@ def cpu_baseline(D, Ly, seed, rows=4, repeats=3):
         "sample": f"{rows}x{Ly} D={D} fp32 top-rows sweep of the same network ({big[3]:.3e} of the headline's FLOP), numpy "
                   f"tensordot / OpenBLAS, median of {repeats} after one warm-up: {med:.2f} s (all: "
                   f"{', '.join(f'{t:.2f}' for t in times)})",
-        "thread_sweep_3row_seconds": {str(k): round(v, 2) for k, v in sweep.items()},
+        "thread_sweep_2row_seconds": {str(k): round(v, 2) for k, v in sweep.items()},
+        **_full_network_record(seed),
     }
+
+
+def _full_network_record(seed):
+    """The anchor of the bounded sample: the WHOLE network through the oracle, recorded once (fp64, same tree)."""
+    path = os.path.join(ROOT, "tests", "golden", "full_size_oracle.json")
+    try:
+        r = json.load(open(path)).get(str(seed))
+    except (OSError, ValueError):
+        r = None
+    if not r or "seconds" not in r:
+        return {}
+    return {"full_network_seconds": r["seconds"],
+            "full_network_note": "whole 10x10 D=6 network, fp64 numpy oracle, same sweep tree, 8 host cores of the build "
+                                 "container (tests/golden/make_full_size_oracle.py, recorded with the golden value)"}
+
+
+def _time_steps(fn, n, sync):
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        r = fn()
+    sync()
+    return (time.perf_counter() - t0) / n, r
 
 
 def main():
@@ -148,14 +175,17 @@ def main():
     ap.add_argument("--Ly", type=int, default=10)
     ap.add_argument("--D", type=int, default=6)
     ap.add_argument("--slices", type=int, default=216)
-    ap.add_argument("--sliced", action="store_true", help="run the 216-slice workload of round 1 (one rank, or round-robin over ranks)")
-    ap.add_argument("--two-sided", action="store_true", help="run the branch decomposition (N > 1 default) on one GPU too")
+    ap.add_argument("--sliced", action="store_true", help="round 1's workload: 216 single-value slices of the sweep (one rank, or round-robin over ranks)")
+    ap.add_argument("--two-sided", action="store_true", help="round 2's branch decomposition (top / bottom half sweeps on two rank groups)")
     ap.add_argument("--seed", type=int, default=7)
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the configs #2 / #5 numbers and the scaling projection (N = 1)")
     ap.add_argument("--tree", choices=["auto", "sweep", "quadrant"], default="auto",
                     help="N = 1 contraction tree: the site-by-site boundary sweep (min-FLOP, HBM-bound), the four-quadrant "
                          "tree (1.13x the multiplications, MFMA-bound joins), or whichever is faster on this device (auto: "
                          "both are run untimed first)")
-    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--emulate-world", type=int, default=0,
+                    help="one GPU times ONE rank's share (the busiest) of a job over this many ranks -- no collective")
     args = ap.parse_args()
 
     import torch
@@ -180,6 +210,7 @@ def main():
 
     import quimb_amd as qa
     from quimb_amd.distributed import contract_sliced, rank_slices
+    from quimb_amd.quadrants import QuadrantRank, QuadrantSharding, contract_quadrants
 
     dev = qa.default_device()
     dtype = "float32"
@@ -187,52 +218,67 @@ def main():
     sweep_tree = qa.ContractionTree(inputs, (), size, path=qa.sweep_path_2d(args.Lx, args.Ly))
     quad_tree = qa.ContractionTree(inputs, (), size, path=qa.quadrant_path_2d(args.Lx, args.Ly)) \
         if min(args.Lx, args.Ly) >= 2 else sweep_tree
+    sync = lambda: torch.cuda.synchronize()
+
+    emulate = args.emulate_world if (world == 1 and args.emulate_world > 1) else 0
+    if args.sliced:
+        mode = "sliced"
+    elif args.two_sided:
+        mode = "two_sided"
+    elif world > 1 or emulate:
+        mode = "quadrants"
+    else:
+        mode = "single"
+
     tree = quad_tree if args.tree == "quadrant" else sweep_tree
     tree_name = "four quadrants + two joins" if args.tree == "quadrant" else "site-by-site boundary sweep"
-    # N > 1: the BRANCH decomposition (top / bottom half sweeps on two groups of ranks, cut-row slices inside a
-    # group, quimb_amd/twosided.py) -- round 1's 216 slices of the one-sided sweep cost 140x the FLOPs
-    two_sided = (world > 1 and not args.sliced) or args.two_sided
-    sliced = args.sliced and not two_sided
-    plan = None
-    if two_sided:
+    plan = sharding = qrank = None
+    tree_probe = None
+    xs = [qa.asarray(a) for a in arrays]  # resident in HBM before the timed region
+    if mode == "two_sided":
         from quimb_amd.distributed import contract_two_sided, sliced_cols_for_world, two_sided_layout
         from quimb_amd.twosided import TwoSidedContraction
 
-        k = sliced_cols_for_world([args.D] * args.Ly, world)
-        plan = TwoSidedContraction(inputs, size, args.Lx, args.Ly, dtype, sliced_cols=k)
-    if sliced:
-        tree = qa.find_slices(tree, target_slices=args.slices)
-    xs = [qa.asarray(a) for a in arrays]  # resident in HBM before the timed region
-    tree_probe = None
-    if args.tree == "auto" and not two_sided and not sliced:
+        plan = TwoSidedContraction(inputs, size, args.Lx, args.Ly, dtype, sliced_cols=sliced_cols_for_world([args.D] * args.Ly, world))
+    elif mode == "sliced":
+        tree = qa.find_slices(sweep_tree, target_slices=args.slices)
+        tree_name = "site-by-site boundary sweep"
+    elif mode == "quadrants":
+        # every rank: the same tree on ITS block of the joins (cut bonds range-sliced); the sharded copies of the site
+        # tensors next to the cut are made once, before the timed region (inputs resident in HBM, as at N = 1)
+        w_ = emulate or world
+        sharding = QuadrantSharding(inputs, size, args.Lx, args.Ly, w_)
+        rep0 = sharding.cost_report()
+        r_ = int(np.argmax(rep0["per_rank_mults"])) if emulate else rank
+        qrank = QuadrantRank(sharding, r_, dtype)
+        xs = sharding.shard(xs, r_)
+        tree, tree_name = quad_tree, "four quadrants + two joins"
+    elif args.tree == "auto":
         # both trees, untimed: two warm-up contractions, then the best of three
         tree_probe = {}
         for name, tr in (("site-by-site boundary sweep", sweep_tree), ("four quadrants + two joins", quad_tree)):
             ex_ = qa.TreeExecutor(tr, dtype)
             for _ in range(2):
                 ex_(xs, strip_exponent=True)
-            best = None
-            for _ in range(3):
-                torch.cuda.synchronize()
-                t_ = time.perf_counter()
-                ex_(xs, strip_exponent=True)[0].item()
-                torch.cuda.synchronize()
-                t_ = time.perf_counter() - t_
-                best = t_ if best is None else min(best, t_)
+            best = min(_time_steps(lambda: ex_(xs, strip_exponent=True)[0].item(), 1, sync)[0] for _ in range(3))
             tree_probe[name] = {"ms": best * 1e3, "tree_mults": tr.contraction_cost(),
                                 "contraction_width_log2": tr.contraction_width()}
             del ex_
         tree_name = min(tree_probe, key=lambda k: tree_probe[k]["ms"])
         tree = quad_tree if tree_name.startswith("four") else sweep_tree
-    ex = qa.TreeExecutor(tree, dtype) if not two_sided else None
-    my = list(rank_slices(tree.nslices, rank, world)) if sliced else None
+    ex = qa.TreeExecutor(tree, dtype) if mode in ("single", "sliced") else (qrank.executor if qrank else None)
+    my = list(rank_slices(tree.nslices, rank, world)) if mode == "sliced" else None
 
     rank_stats = {}
 
     def step():
-        if two_sided:
+        if mode == "two_sided":
             return contract_two_sided(plan, xs, strip_exponent=True, stats=rank_stats)
-        if sliced:
+        if mode == "quadrants":
+            if emulate:
+                return qrank(xs, defer=True)                     # one rank's share, no collective
+            return contract_quadrants(qrank, xs, strip_exponent=True)     # ... + the one all-gather
+        if mode == "sliced":
             if world > 1:
                 # this rank's slices, then ONE all-reduce of the (mantissa, exponent) pair at the join -- the
                 # library routine the gloo tests exercise (tests/test_distributed_gloo.py), RCCL here
@@ -257,12 +303,12 @@ def main():
     for _ in range(args.warmup):
         res = step()
     fence()
-    # N = 1 (unsliced): per-kernel HIP events are recorded inside the timed region.  Sliced runs replay one
-    # recorded hipGraph per slice, which hides the individual launches from the host: their kernel timings
-    # come from ONE extra, untimed, launch-by-launch pass after the timed region.
-    if rank == 0 and not sliced and not two_sided:
-        # HIP events around the launches that can be the dominant kernel only (>= 1e9 multiplications): an event pair
-        # around each of the ~60 tiny first-row launches costs them ~10 us of queue time apiece
+    # Per-kernel HIP events are recorded inside the timed region (launch-by-launch modes) around the launches that can
+    # be the dominant kernel only (>= 1e9 multiplications): an event pair around each of the ~60 tiny first-row
+    # launches costs them ~10 us of queue time apiece.  Sliced runs replay one recorded hipGraph per slice, which
+    # hides the launches from the host: their kernel timings come from ONE extra, untimed, launch-by-launch pass.
+    graphed = mode in ("sliced", "two_sided")
+    if rank == 0 and not graphed:
         dev.profile_min_mults = 10**9
         dev.profile = []
     t0 = time.perf_counter()
@@ -272,7 +318,7 @@ def main():
     dt = time.perf_counter() - t0
     res = materialize(res)
     prof, dev.profile = dev.profile, None
-    if sliced or two_sided:
+    if graphed:
         os.environ["QAMD_SLICE_GRAPH"] = "0"
         if rank == 0:
             dev.profile = []
@@ -281,41 +327,36 @@ def main():
         prof, dev.profile = dev.profile, None
         del os.environ["QAMD_SLICE_GRAPH"]
     scaling_report = None
-    if two_sided:
-        # honest strong-scaling context: what the ranks executed, how evenly, and the one-GPU unsliced time
-        layout = two_sided_layout(plan.nslices, world)
-        rep = plan.cost_report(layout)
-        mine_t = torch.tensor([rank_stats.get("hoist_s", 0.0), rank_stats.get("compute_s", 0.0)], dtype=torch.float64,
-                              device="cpu" if backend == "gloo" else dev.tdev)
+    if mode == "quadrants":
+        # what the ranks executed and how evenly: every rank's own time for its share without the collective
+        t_loc, _ = _time_steps(lambda: qrank(xs, defer=True), 3, sync)
+        mine_t = torch.tensor([t_loc], dtype=torch.float64, device="cpu" if backend == "gloo" else dev.tdev)
         if world > 1:
             allt = [torch.empty_like(mine_t) for _ in range(world)]
             dist.all_gather(allt, mine_t)
-            allt = [[float(v) for v in t.cpu()] for t in allt]
+            allt = [float(t.cpu()[0]) for t in allt]
         else:
-            allt = [[float(v) for v in mine_t.cpu()]]
-        one_gpu_ms = None
-        if rank == 0:
-            ex1 = qa.TreeExecutor(sweep_tree, dtype)
-            for _ in range(2):
-                ex1(xs, strip_exponent=True)
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for _ in range(3):
-                ex1(xs, strip_exponent=True)[0].item()
-            torch.cuda.synchronize()
-            one_gpu_ms = (time.perf_counter() - t1) / 3 * 1e3
-        if world > 1:
-            dist.barrier()
+            allt = [t_loc]
+        rep = sharding.cost_report()
+        scaling_report = {
+            "decomposition": f"four-quadrant tree, cut bonds range-sliced: rank (i, j) of a {rep['grid'][0]} x {rep['grid'][1]} grid "
+                             f"contracts block (i, j) of the two joins ({rep['sliced_bonds']} bond(s) in {rep['parts_per_bond']} "
+                             f"ranges), no data-path collective, one all-gather of (mantissa, exponent) pairs",
+            "flops_useful": 2 * rep["one_rank_mults"], "flops_executed_all_ranks": 2 * rep["executed_mults"],
+            "flop_inflation": rep["inflation"], "busiest_rank_fraction_of_one_rank_flops": rep["busiest_rank_fraction"],
+            "ideal_speedup_from_flops": rep["ideal_speedup_vs_one_rank"],
+            "per_rank_ms_without_collective": [1e3 * t for t in allt],
+        }
+        if emulate:
+            scaling_report["emulated"] = f"ONE GPU timed the busiest rank's share of a {emulate}-rank job; no collective ran"
+    elif mode == "two_sided":
+        layout = two_sided_layout(plan.nslices, world)
+        rep = plan.cost_report(layout)
         scaling_report = {
             "decomposition": f"two-sided: top / bottom half sweeps on {world // 2 or 1} + {world - world // 2} ranks, "
-                             f"{plan.nslices} cut-row slice(s) in contiguous blocks per group, point-to-point hand-off of the "
-                             f"cut boundary, one all-gather",
+                             f"{plan.nslices} cut-row slice(s) per group, point-to-point hand-off, one all-gather",
             "flops_useful": 2 * rep["useful_mults"], "flops_executed_all_ranks": 2 * rep["executed_mults"],
-            "slice_flop_inflation": rep["inflation"],
-            "hoisted_fraction_of_executed": rep["hoisted_mults_all_ranks"] / rep["executed_mults"],
             "ideal_speedup_from_flops": rep["ideal_speedup_vs_one_rank"],
-            "per_rank_hoist_ms": [1e3 * a for a, _ in allt], "per_rank_compute_ms": [1e3 * b for _, b in allt],
-            "unsliced_one_sided_1gpu_ms_on_rank0": one_gpu_ms,
         }
     tt = torch.tensor([dt], dtype=torch.float64, device=dev.tdev)
     if world > 1:
@@ -323,9 +364,14 @@ def main():
     dt = float(tt.cpu()[0])
 
     if rank == 0:
-        # whole job: FLOPs of the tree executed (all slices, hoisted steps once); for the branch decomposition the
-        # USEFUL count -- the one-sided sweep's -- so that values at different N compare as time to solution
-        flops_step = 2 * plan.one_sided_mults if two_sided else ex.flops()
+        # whole job: FLOPs of the tree executed (all slices, hoisted steps once); for the sharded decompositions the
+        # USEFUL count -- the one-rank tree's -- so that values at different N compare as time to solution
+        if mode == "two_sided":
+            flops_step = 2 * plan.one_sided_mults
+        elif mode == "quadrants":
+            flops_step = 2 * quad_tree.contraction_cost()
+        else:
+            flops_step = ex.flops()
         ms = dt / args.steps * 1e3
         value = flops_step / (dt / args.steps) / 1e12
         # ---- dominant kernel from HIP-event timings over the timed region ------
@@ -383,11 +429,53 @@ def main():
             roof["tflops"] = flops_launch / avg / 1e12
             roof["avg_launch_ms"] = avg * 1e3
             roof["launches_timed"] = cnt
-            roof["timed_in"] = "one untimed launch-by-launch pass after the timed region (the timed region replays hipGraphs)" if sliced else ("rank 0's launches of one untimed pass after the timed region" if two_sided else "the timed region")
-            roof["share_of_step_time"] = tsum / (dt / args.steps * (1 if (sliced or two_sided) else args.steps))
+            roof["timed_in"] = ("one untimed launch-by-launch pass after the timed region (the timed region replays hipGraphs)"
+                                if graphed else "the timed region (HIP events on the launch stream, launches >= 1e9 multiplications)")
+            roof["share_of_step_time"] = tsum / (dt / args.steps * (1 if graphed else args.steps))
             roof["algorithmic_bytes_per_launch"] = bytes_launch
             roof["flops_per_launch"] = flops_launch
-        cpu = None if (args.no_cpu or world > 1) else cpu_baseline(args.D, args.Ly, args.seed)   # N=1 only
+        # ---- N = 1 extras (after the timed region): other BASELINE configs, what one rank of N = 2 / 4 / 8 costs -------
+        secondary = projection = None
+        if mode == "single" and not args.no_secondary and (args.Lx, args.Ly) == (10, 10):
+            sys.path.insert(0, os.path.join(ROOT, "scripts"))
+            try:
+                import secondary as _sec
+
+                secondary = _sec.measure(qa, sync)
+            except Exception as err:
+                secondary = {"error": f"{type(err).__name__}: {err}"}
+            projection = {"note": "ONE GPU timing the busiest rank's share of an N-rank job (same code path as --gpus N minus "
+                                  "the 16-byte all-gather); the driver's SCALE run is the measurement, this is its preview",
+                          "one_gpu_ms": ms}
+            for w_ in (2, 4, 8):
+                try:
+                    sh_ = QuadrantSharding(inputs, size, args.Lx, args.Ly, w_)
+                    rep_ = sh_.cost_report()
+                    r_ = int(np.argmax(rep_["per_rank_mults"]))
+                    qr_ = QuadrantRank(sh_, r_, dtype)
+                    loc_ = sh_.shard([qa.asarray(a) for a in arrays], r_)
+                    for _ in range(2):
+                        qr_(loc_, defer=True)
+                    t_, _ = _time_steps(lambda: qr_(loc_, defer=True), 5, sync)
+                    projection[str(w_)] = {"grid": rep_["grid"], "busiest_rank_ms": t_ * 1e3, "speedup_vs_one_gpu": ms / (t_ * 1e3),
+                                           "busiest_rank_fraction_of_flops": rep_["busiest_rank_fraction"]}
+                    del qr_, loc_
+                except Exception as err:
+                    projection[str(w_)] = {"error": f"{type(err).__name__}: {err}"}
+        cpu = None if (args.no_cpu or world > 1 or emulate) else cpu_baseline(args.D, args.Ly, args.seed)   # N=1 only
+        nsl = plan.nslices if mode == "two_sided" else tree.nslices
+        if mode == "single":
+            workload, par = "unsliced, 1 GPU", "single"
+        elif mode == "sliced":
+            workload, par = f"{tree.nslices} single-value slices over {world} GPU(s), one all-reduce", f"slices{world}"
+        elif mode == "two_sided":
+            workload, par = f"two-sided branch decomposition over {world} GPU(s), {plan.nslices} cut-row slice(s)", f"branches2xslices{max(world // 2, 1)}"
+        else:
+            g_ = sharding.cost_report()["grid"]
+            workload = (f"BASELINE config #4's role (the same network sharded over sliced indices; 256 slices are not reachable with "
+                        f"all-6 bonds): {emulate or world} range-slices of the cut bonds = blocks of a {g_[0]} x {g_[1]} grid over the two "
+                        f"joins, one all-gather" + (f" -- EMULATED: one GPU runs the busiest rank's share" if emulate else ""))
+            par = f"blocks{g_[0]}x{g_[1]}"
         out = {
             "metric": "contracted-FLOP/s on PEPS amplitude",
             "value": value,
@@ -402,30 +490,27 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": (
-                    f"{args.Lx}x{args.Ly} D={args.D} PEPS amplitude (single-layer TN), exact, "
-                    + (f"{tree.nslices} slices over {world} GPU(s), one all-reduce" if sliced else
-                       (f"two-sided branch decomposition over {world} GPU(s), {plan.nslices} cut-row slice(s)" if two_sided
-                        else "unsliced, 1 GPU"))
-                ),
+                "workload": f"{args.Lx}x{args.Ly} D={args.D} PEPS amplitude (single-layer TN), exact, " + workload,
                 "tree": tree_name,
                 "tree_mults": tree.contraction_cost(),
                 "best_known_tree_mults": sweep_tree.contraction_cost(),   # the min-FLOP site sweep
                 "trees_tried_untimed": tree_probe,
                 "flops_per_step": flops_step,
-                "nslices": plan.nslices if two_sided else tree.nslices,
+                "nslices": nsl,
                 "contraction_width_log2": tree.contraction_width(),
-                "parallelism": f"slices{world}" if sliced else (f"branches2xslices{max(world // 2, 1)}" if two_sided else "single"),
+                "parallelism": par,
             },
             "pct_mfma_peak": 100.0 * value / (MFMA_F32_PEAK_TF * world),
             "result": _result_with_parity(res, args),
             "roofline": roof,
             "cpu_baseline": cpu,
         }
+        if secondary is not None:
+            out["secondary"] = secondary
+        if projection is not None:
+            out["scaling_projection"] = projection
         if scaling_report is not None:
             out["strong_scaling_report"] = scaling_report
-            if scaling_report["unsliced_one_sided_1gpu_ms_on_rank0"]:
-                out["strong_scaling_report"]["time_vs_unsliced_1gpu"] = ms / scaling_report["unsliced_one_sided_1gpu_ms_on_rank0"]
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -1,0 +1,141 @@
+"""Driver-visible numbers for the BASELINE configs bench.py's headline does not cover (imported by bench.py at
+N = 1; no oracle / test code is touched -- the generators below are this file's own):
+
+  config #2  random 53-qubit depth-10 brickwork circuit, one amplitude, complex64 (reference:
+             Circuit.amplitude, quimb/tensor/circuit/exact.py:417-501): the whole 895-step tree in ONE launch
+             (microtree.hip), and 256 bitstrings sharing the gate tensors in one launch
+  config #5  DMRG2 at chi = 512, MPO bond 5, d = 2, fp64 (reference: DMRG._update_local_state_2site,
+             quimb/tensor/tn1d/dmrg.py:803-870): the effective-Hamiltonian matvec (TNLinearOperator,
+             quimb/tensor/tensor_core.py:12393-12448) and one whole local update
+             (Lanczos + split + environment update)
+"""
+import time
+
+import numpy as np
+
+
+def _timed(fn, reps, sync):
+    fn()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        out = fn()
+    sync()
+    return (time.perf_counter() - t0) / reps, out
+
+
+def brickwork_amplitude_network(n, depth, seed=0, dtype="complex64"):
+    """|0..0>, per layer a random single-qubit unitary on every qubit and a random two-qubit unitary on alternating
+    neighbour pairs, <b| for a random bitstring b: (arrays, inputs, index of the first <b| tensor)."""
+    rng = np.random.default_rng(seed)
+
+    def runitary(k):
+        q, r = np.linalg.qr(rng.normal(size=(k, k)) + 1j * rng.normal(size=(k, k)))
+        return q * (np.diag(r) / np.abs(np.diag(r)))
+
+    arrays, inputs = [], []
+    cur = [f"q{i}_0" for i in range(n)]
+    cnt = [0] * n
+    for i in range(n):
+        arrays.append(np.array([1.0, 0.0]))
+        inputs.append((cur[i],))
+    for d in range(depth):
+        for i in range(n):
+            cnt[i] += 1
+            new = f"q{i}_{cnt[i]}"
+            arrays.append(runitary(2))
+            inputs.append((new, cur[i]))
+            cur[i] = new
+        for i in range(d % 2, n - 1, 2):
+            cnt[i] += 1
+            cnt[i + 1] += 1
+            n1, n2 = f"q{i}_{cnt[i]}", f"q{i + 1}_{cnt[i + 1]}"
+            arrays.append(runitary(4).reshape(2, 2, 2, 2))
+            inputs.append((n1, n2, cur[i], cur[i + 1]))
+            cur[i], cur[i + 1] = n1, n2
+    first_bra = len(arrays)
+    bits = rng.integers(0, 2, size=n)
+    for i in range(n):
+        v = np.zeros(2)
+        v[bits[i]] = 1.0
+        arrays.append(v)
+        inputs.append((cur[i],))
+    return [a.astype(dtype) for a in arrays], inputs, first_bra
+
+
+def config2(qa, sync, nq=53, depth=10, batch=256):
+    arrays, inputs, first_bra = brickwork_amplitude_network(nq, depth)
+    tree = qa.array_contract_tree(inputs, (), shapes=[a.shape for a in arrays], optimize="greedy")
+    xs = [qa.asarray(a) for a in arrays]
+    bm = qa.MicroTree(tree, "complex64").bind(xs)
+    t_one, amp = _timed(lambda: bm(), 20, sync)
+    e0, e1 = qa.asarray(np.array([1, 0], "complex64")), qa.asarray(np.array([0, 1], "complex64"))
+    bits = np.random.default_rng(5).integers(0, 2, size=(batch, nq))
+    sel = {first_bra + q: ((e0, e1), bits[:, q]) for q in range(nq)}
+    t_b, _ = _timed(lambda: bm.batch(sel), 5, sync)
+    # the same amplitude launch by launch (TreeExecutor): the parity cross-check of the one-launch walk
+    ref = qa.TreeExecutor(tree, "complex64")(xs).to_numpy().item()
+    got = amp.to_numpy().item()
+    return {
+        "config": f"BASELINE #2: {nq}-qubit depth-{depth} brickwork circuit amplitude, complex64, exact",
+        "kernel": "microtree_kernel (one workgroup walks the whole tree)",
+        "steps": len(tree.steps), "contraction_width_log2": tree.contraction_width(),
+        "amplitude_ms": t_one * 1e3, "us_per_step": t_one / len(tree.steps) * 1e6,
+        "batch": batch, "batch_ms": t_b * 1e3, "us_per_amplitude_in_batch": t_b / batch * 1e6,
+        "rel_diff_vs_launch_by_launch": abs(got - ref) / max(abs(ref), 1e-300),
+    }
+
+
+def config5(qa, sync, chi=512, d=2, w=5, nmv=12):
+    rng = np.random.default_rng(23)
+    r = lambda *s: rng.uniform(-0.5, 1.0, size=s)
+    L, R, W1, W2 = r(chi, w, chi), r(chi, w, chi), r(w, w, d, d), r(w, w, d, d)
+    L = (L + L.transpose(2, 1, 0)) / 2
+    R = (R + R.transpose(2, 1, 0)) / 2
+    W1 = (W1 + W1.transpose(0, 1, 3, 2)) / 2
+    W2 = (W2 + W2.transpose(0, 1, 3, 2)) / 2
+    tensors = [(L, ("a", "p", "A")), (W1, ("p", "q", "s1", "S1")), (W2, ("q", "r", "s2", "S2")), (R, ("b", "r", "B"))]
+    A = qa.TNLinearOperator(tensors, ("a", "s1", "s2", "b"), ("A", "S1", "S2", "B"), optimize="random-greedy", graph=True)
+    v0 = qa.asarray(np.random.default_rng(1).standard_normal(chi * d * d * chi))
+    t_mv, _ = _timed(lambda: A @ v0, 20, sync)
+    fl_mv = A._expr(0).tree.total_flops("float64")
+    names = []
+    ex = A._expr(0).executor
+    dev = v0._dev
+    if hasattr(dev, "describe_pair"):
+        for e in ex.plan:
+            if e[0] == "pair" and e[4].kind == "gett":
+                try:
+                    names.append(dev.describe_pair(dev.compile_pair(e[4].spec, np.dtype("float64"))))
+                except Exception:
+                    pass
+    t_eig, (e0, vec) = _timed(lambda: qa.eigh_lanczos(A, k=1, which="SA", v0=v0, ncv=nmv, tol=1e-14, maxiter=nmv), 3, sync)
+    x = vec.reshape(chi * d, d * chi)
+    t_split, (U, S, Vh) = _timed(lambda: qa.linalg.svd_via_eig(x), 3, sync)
+    Asite = qa.asarray(np.ascontiguousarray(U.reshape(chi, d, d * chi).to_numpy()[:, :, :chi]))
+    Ld, W1d = qa.asarray(L), qa.asarray(W1)
+    inputs = [("a", "w", "b"), ("a", "s", "A"), ("w", "W", "s", "t"), ("b", "t", "B")]
+    expr = qa.array_contract_expression(inputs, ("A", "W", "B"), shapes=[(chi, w, chi), (chi, d, chi), (w, w, d, d), (chi, d, chi)],
+                                        optimize="random-greedy", dtype="float64")
+    t_env, _ = _timed(lambda: expr(Ld, Asite, W1d, Asite), 5, sync)
+    fl_env = expr.tree.total_flops("float64")
+    return {
+        "config": f"BASELINE #5: DMRG2 local update at chi={chi}, MPO bond {w}, d={d}, fp64",
+        "matvec_ms": t_mv * 1e3, "matvec_flop": fl_mv, "matvec_tflops_f64": fl_mv / t_mv / 1e12,
+        "matvec_frac_of_f64_mfma_peak_78.6": fl_mv / t_mv / 78.6e12,
+        "matvec_kernels": sorted(set(names)),
+        "lanczos_matvecs": nmv, "lanczos_ms": t_eig * 1e3,
+        "split_svd_via_eig_ms": t_split * 1e3,
+        "environment_update_ms": t_env * 1e3, "environment_update_tflops_f64": fl_env / t_env / 1e12,
+        "local_update_ms": (t_eig + t_split + t_env) * 1e3,
+    }
+
+
+def measure(qa, sync):
+    out = {}
+    for name, fn in (("config2_circuit_amplitude", config2), ("config5_dmrg_local_update", config5)):
+        try:
+            out[name] = fn(qa, sync)
+        except Exception as err:      # a secondary number must never take the headline line down with it
+            out[name] = {"error": f"{type(err).__name__}: {err}"}
+    return out
