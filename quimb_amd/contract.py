@@ -114,7 +114,7 @@ def _size_dict(inputs, shapes):
     return size
 
 
-def array_contract_tree(inputs, output=None, size_dict=None, shapes=None, optimize=None, slicing=None, **_):
+def array_contract_tree(inputs, output=None, size_dict=None, shapes=None, optimize=None, slicing=None, dtype=None, **_):
     """Find (or adopt) a contraction tree. ``slicing``: dict passed to
     ``find_slices`` (``target_slices`` / ``target_size``)."""
     inputs = tuple(tuple(t) for t in inputs)
@@ -124,7 +124,7 @@ def array_contract_tree(inputs, output=None, size_dict=None, shapes=None, optimi
         size_dict = _size_dict(inputs, shapes)
     if optimize is None:
         optimize = get_contract_strategy()
-    tree = find_path(inputs, tuple(output), size_dict, optimize)
+    tree = find_path(inputs, tuple(output), size_dict, optimize, dtype=dtype or "float32")
     if slicing:
         tree = find_slices(tree, **slicing)
     return tree
@@ -239,7 +239,11 @@ def contract_with_implementation(tree, arrays, implementation):
         if len(con) == 2:
             la, lb = ops_inds
             shared = [ix for ix in la if ix in lb]
-            plain = (len(set(la)) == len(la) and len(set(lb)) == len(lb) and not any(ix in out for ix in shared))
+            # tensordot keeps EVERY unshared index: an index carried by one operand only that the step sums away
+            # (not in ``out``) needs the einsum form
+            free = [ix for ix in la if ix not in shared] + [ix for ix in lb if ix not in shared]
+            plain = (len(set(la)) == len(la) and len(set(lb)) == len(lb) and not any(ix in out for ix in shared)
+                     and set(free) == set(out))
             if plain:
                 axes = ([la.index(ix) for ix in shared], [lb.index(ix) for ix in shared])
                 x = tensordot(xs[0], xs[1], axes)

@@ -47,17 +47,23 @@ def contract_sliced(executor, arrays, strip_exponent=False, group=None, rank=Non
     if strip_exponent and n <= (1 << 16):
         # ONE collective: every rank contributes (mantissa block, exponent) -- 8 (n + 1) bytes, 16 for an
         # amplitude -- and adds the gathered blocks up on the common (max) exponent itself
-        mine = torch.empty(n + 1, dtype=torch.float64, device=t.device)
-        mine[:n] = t[:n].to(torch.float64)
-        mine[n] = e if np.isfinite(e) else -1e300
+        # (complex outputs travel as interleaved (re, im) doubles: a cast to float64 would drop the imaginary part)
+        cplx = t.is_complex()
+        body = torch.view_as_real(t[:n].to(torch.complex128)).reshape(-1) if cplx else t[:n].to(torch.float64)
+        nb = body.numel()
+        mine = torch.empty(nb + 1, dtype=torch.float64, device=t.device)
+        mine[:nb] = body
+        mine[nb] = e if np.isfinite(e) else -1e300
         gathered = [torch.empty_like(mine) for _ in range(world)]
         dist.all_gather(gathered, mine, group=group)
-        g = torch.stack(gathered).cpu().numpy()
-        es = g[:, n]
+        g = torch.stack(gathered).cpu().numpy()       # world x (nb + 1) doubles: the result itself, read back once
+        es = g[:, nb]
         e_max = float(es.max())
+        blocks = g[:, :nb].reshape(world, n, 2) if cplx else g[:, :nb]
+        blocks = blocks[..., 0] + 1j * blocks[..., 1] if cplx else blocks
         if e_max <= -1e299:
-            return np.zeros(out.shape, dtype=g.dtype), 0.0
-        res = (g[:, :n] * (10.0 ** (es - e_max))[:, None]).sum(0)
+            return np.zeros(out.shape, dtype=blocks.dtype), 0.0
+        res = (blocks * (10.0 ** (es - e_max))[:, None]).sum(0)
         return res.astype(out.to_numpy().dtype if hasattr(out, "to_numpy") else res.dtype).reshape(out.shape), e_max
     if strip_exponent:
         # large outputs: a MAX of the exponents, then a SUM of the rescaled mantissas (two collectives)

@@ -68,7 +68,8 @@ def svd_via_eig(x, max_bond=-1):
     reference's ``svd_via_eig`` (quimb/tensor/decomp.py:1168, split ``method="svd:eig"``) with ``absorb=None``.
     The two Gram / back-projection products run on this library's GETT kernels, the small eigenproblem on
     rocSOLVER ``syevd``: 23 ms instead of 260 ms (``gesvd``) for the 1024 x 1024 fp64 two-site tensor of a
-    chi = 512 DMRG step.  Singular values below ~sqrt(eps) * s_max lose relative accuracy (squared condition)."""
+    chi = 512 DMRG step.  Singular values below ~sqrt(eps) * s_max lose relative accuracy (squared condition); only
+    directions below the Gram matrix's noise floor (eigenvalue <= eps * s_max^2) are dropped."""
     from . import ops
 
     x = x if isinstance(x, Array) else Array.from_numpy(np.asarray(x))
@@ -78,13 +79,15 @@ def svd_via_eig(x, max_bond=-1):
     w, v = eigh(g)                                    # ascending; the spectrum (min(m, n) numbers) goes to the host
     wh = w.to_numpy().astype(np.float64)[::-1]
     k = len(wh) if max_bond is None or max_bond < 0 else min(int(max_bond), len(wh))
-    # rank-revealing: directions with s <= 4 sqrt(eps) * s_max (zero, noise-level or clipped-negative eigenvalues) carry no vector this
-    # route can normalise -- keeping them would hand back "orthogonal" factors that are not (a rank-1 6x5 input
-    # gave |U^T U - I| = 1).  They are dropped, as a rank-revealing SVD would; at least one direction stays.
+    # Only directions this route cannot normalise are dropped: eigenvalues of the Gram matrix that are zero, clipped
+    # negative, or below its noise floor eps * s_max^2 (there the eigenvector is noise and U = x V / s would hand back
+    # "orthogonal" factors that are not: a rank-1 6x5 input gave |U^T U - I| = 1).  Everything above the floor is kept
+    # -- the reference's svd_via_eig (quimb/tensor/decomp.py:1168) truncates by max_bond only -- so a full-rank input
+    # comes back with min(m, n) values; their RELATIVE accuracy degrades below ~sqrt(eps) * s_max (squared condition),
+    # which is the documented price of method "svd:eig".  At least one direction stays.
     s_all = np.sqrt(np.clip(wh, 0.0, None))
     eps = np.finfo(np.dtype(w.dtype.name if hasattr(w.dtype, "name") else w.dtype)).eps
-    # (through the Gram matrix the noise floor of an eigenvalue is eps * s_max^2, i.e. sqrt(eps) * s_max for s)
-    keep = int(np.count_nonzero(s_all > 4.0 * np.sqrt(eps) * float(s_all[0]))) if s_all.size and s_all[0] > 0 else 1
+    keep = int(np.count_nonzero(wh > eps * float(wh[0]))) if wh.size and wh[0] > 0 else 1
     k = max(1, min(k, keep))
     sh = s_all[:k]
     V = v[:, ::-1][:, :k] if k < len(wh) else v[:, ::-1]          # columns by descending eigenvalue

@@ -332,7 +332,7 @@ def power(x, p):
             return Array.full(x.shape, 1.0, x.dtype, x._dev)
         while e:                                                     # square-and-multiply on the device
             if e & 1:
-                out = base if out is None else out * base
+                out = base.copy() if out is None else out * base   # (x ** 1 is a new array, as numpy's is)
             e >>= 1
             if e:
                 base = base * base

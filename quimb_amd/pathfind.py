@@ -262,8 +262,9 @@ def _cache_file(inputs, output, size_dict, optimize):
     return os.path.join(d, f"tree-{geometry_hash(inputs, output, size_dict, optimize)}.json")
 
 
-def find_path(inputs, output, size_dict, optimize="greedy"):
-    """Resolve quimb's ``optimize=`` argument to a ``ContractionTree``."""
+def find_path(inputs, output, size_dict, optimize="greedy", dtype="float32"):
+    """Resolve quimb's ``optimize=`` argument to a ``ContractionTree``.  ``dtype`` matters to the time objective only
+    (peaks, item size, which fused kernels exist): it prices the trees of ``"auto-time"`` and keys their cache entries."""
     if isinstance(optimize, ContractionTree):
         return optimize
     if hasattr(optimize, "get_path") and hasattr(optimize, "size_dict"):
@@ -271,7 +272,10 @@ def find_path(inputs, output, size_dict, optimize="greedy"):
     if isinstance(optimize, str):
         if optimize not in ("greedy", "auto", "auto-hq", "random-greedy", "auto-time"):
             raise ValueError(f"unknown contraction strategy {optimize!r}")
-        path_file = _cache_file(inputs, output, size_dict, optimize)
+        import numpy as _np
+
+        dt_name = _np.dtype(dtype).name
+        path_file = _cache_file(inputs, output, size_dict, optimize + ("@" + dt_name if optimize == "auto-time" else ""))
         if path_file and os.path.exists(path_file):
             try:
                 with open(path_file) as f:
@@ -282,7 +286,7 @@ def find_path(inputs, output, size_dict, optimize="greedy"):
         if optimize in ("greedy", "auto"):
             tree = ContractionTree(inputs, output, size_dict, ssa_path=greedy_ssa(inputs, output, size_dict))
         elif optimize == "auto-time":
-            tree = random_greedy(inputs, output, size_dict, repeats=32, minimize="time")
+            tree = random_greedy(inputs, output, size_dict, repeats=32, minimize="time", dtype=dt_name)
         else:
             tree = random_greedy(inputs, output, size_dict, repeats=64 if optimize == "auto-hq" else 32)
         if path_file:

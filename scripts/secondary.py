@@ -112,7 +112,7 @@ def config5(qa, sync, chi=512, d=2, w=5, nmv=12):
     t_eig, (e0, vec) = _timed(lambda: qa.eigh_lanczos(A, k=1, which="SA", v0=v0, ncv=nmv, tol=1e-14, maxiter=nmv), 3, sync)
     x = vec.reshape(chi * d, d * chi)
     t_split, (U, S, Vh) = _timed(lambda: qa.linalg.svd_via_eig(x), 3, sync)
-    Asite = qa.asarray(np.ascontiguousarray(U.reshape(chi, d, d * chi).to_numpy()[:, :, :chi]))
+    Asite = qa.asarray(np.ascontiguousarray(U.to_numpy()[:, :chi].reshape(chi, d, chi)))    # keep chi columns
     Ld, W1d = qa.asarray(L), qa.asarray(W1)
     inputs = [("a", "w", "b"), ("a", "s", "A"), ("w", "W", "s", "t"), ("b", "t", "B")]
     expr = qa.array_contract_expression(inputs, ("A", "W", "B"), shapes=[(chi, w, chi), (chi, d, chi), (w, w, d, d), (chi, d, chi)],
