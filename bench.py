@@ -29,6 +29,10 @@ import time
 
 import numpy as np
 
+# four corner sweeps + the caller's stream want five hardware queues (HIP's default is four: a fifth stream would share
+# one and serialise behind it); must be set before the HIP runtime initialises
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
@@ -184,7 +188,9 @@ def main():
                     help="N = 1 contraction tree: the site-by-site boundary sweep (min-FLOP, HBM-bound), the four-quadrant "
                          "tree (1.13x the multiplications, MFMA-bound joins), or whichever is faster on this device (auto: "
                          "both are run untimed first)")
-    ap.add_argument("--inflight", type=int, default=2, help="independent contractions in flight (alternating HIP streams); 1 = one at a time")
+    ap.add_argument("--inflight", type=int, default=1, help="independent contractions in flight (alternating HIP streams); 1 = one at a time")
+    ap.add_argument("--graph", action="store_true", help="N > 1: one hipGraph replay per step instead of launch by launch (measured: no faster -- "
+                    "the host enqueues a share in 1.6 ms, the device needs 3.4 -- and the runtime maps the parallel branches of a graph onto fewer queues)")
     ap.add_argument("--emulate-world", type=int, default=0,
                     help="one GPU times ONE rank's share (the busiest) of a job over this many ranks -- no collective")
     args = ap.parse_args()
@@ -253,6 +259,8 @@ def main():
         r_ = int(np.argmax(rep0["per_rank_mults"])) if emulate else rank
         qrank = QuadrantRank(sharding, r_, dtype)
         xs = sharding.shard(xs, r_)
+        if args.graph:
+            qrank.capture(xs)
         tree, tree_name = quad_tree, "four quadrants + two joins"
     elif args.tree == "auto":
         # both trees, untimed: two warm-up contractions, then the best of three
@@ -323,7 +331,7 @@ def main():
     # be the dominant kernel only (>= 1e9 multiplications): an event pair around each of the ~60 tiny first-row
     # launches costs them ~10 us of queue time apiece.  Sliced runs replay one recorded hipGraph per slice, which
     # hides the launches from the host: their kernel timings come from ONE extra, untimed, launch-by-launch pass.
-    graphed = mode in ("sliced", "two_sided")
+    graphed = mode in ("sliced", "two_sided") or (mode == "quadrants" and args.graph)
     if rank == 0 and not graphed:
         dev.profile_min_mults = 10**9
         dev.profile = []
@@ -337,8 +345,12 @@ def main():
     if graphed:
         os.environ["QAMD_SLICE_GRAPH"] = "0"
         if rank == 0:
+            dev.profile_min_mults = 10**9
             dev.profile = []
-        step()
+        if mode == "quadrants":
+            qrank.executor(xs, strip_exponent=True)      # launch by launch, this rank alone (no collective)
+        else:
+            step()
         fence()
         prof, dev.profile = dev.profile, None
         del os.environ["QAMD_SLICE_GRAPH"]
@@ -527,7 +539,8 @@ def main():
                 "contractions_in_flight": args.inflight if pipelined else 1,
             },
             "pct_mfma_peak": 100.0 * value / (MFMA_F32_PEAK_TF * world),
-            "result": _result_with_parity(res, args),
+            "result": _result_with_parity(res, args) if not emulate else
+                      {"mantissa": res[0], "exponent_log10": res[1], "note": "ONE rank's block z_ij of the sum, not the network's value"},
             "roofline": roof,
             "cpu_baseline": cpu,
         }

@@ -299,6 +299,15 @@ class TreeExecutor:
             for st_ in streams[1:]:
                 st_.wait_stream(streams[0])       # inputs / slots are ready on the caller's stream
         keep_alive = []   # buffers handed from one lane to another stay allocated until every launch is queued
+        # QAMD_LANE_TRACE=1 (debugging aid): HIP events at the first and last launch of every lane -> self.lane_trace
+        trace = trace_at = None
+        if streams is not None and os.environ.get("QAMD_LANE_TRACE"):
+            trace = self.lane_trace = []
+            first, last = {}, {}
+            for i_, l_ in enumerate(self.lanes):
+                first.setdefault(l_, i_)
+                last[l_] = i_
+            trace_at = set(first.values()) | set(last.values()) | {i_ for i_, l_ in enumerate(self.lanes) if l_ == 0 and i_ >= len(self.lanes) - 3}
         uses = {}
         def operands(entry):
             if entry[0] == "single":
@@ -321,6 +330,10 @@ class TreeExecutor:
                         mine.wait_stream(streams[self.lanes[pj]])     # the join: one event
                         keep_alive.append(live[o])
                 dev.torch.cuda.set_stream(mine)
+                if trace is not None and pi in trace_at:
+                    ev = dev.torch.cuda.Event(enable_timing=True)
+                    ev.record()
+                    trace.append((f"lane {self.lanes[pi]} entry {pi} ({entry[0]}) start", ev))
             if entry[0] == "single":
                 _, a, res, src, out = entry
                 independent = not self.dep[res]
@@ -409,6 +422,10 @@ class TreeExecutor:
                 uses[s] -= 1
                 if uses[s] == 0:
                     live.pop(s, None)
+            if streams is not None and trace is not None and pi in trace_at:
+                ev = dev.torch.cuda.Event(enable_timing=True)
+                ev.record()
+                trace.append((f"lane {self.lanes[pi]} entry {pi} ({entry[0]}) end", ev))
         if streams is not None:
             dev.torch.cuda.set_stream(streams[0])
         out = live.get(self.root)
@@ -602,8 +619,10 @@ class GraphedContraction:
             raise ValueError("shape mismatch")
         self.inputs[i]._buf[: src.size].copy_(src._buf[: src.size])
 
-    def replay(self):
+    def replay(self, defer_exponent=False):
+        """One host call re-launches the recorded kernel sequence (independent branches as parallel graph branches).
+        ``defer_exponent``: hand back the device-resident exponent accumulator instead of reading it (no sync)."""
         self._graph.replay()
         if self.strip_exponent:
-            return self.output, self._dev.read_exponent(self._exponent)
+            return self.output, (self._exponent if defer_exponent else self._dev.read_exponent(self._exponent))
         return self.output
