@@ -585,6 +585,11 @@ def test_linop_chi512_parity(hip):
     checks.check_linop_full_chi(512, "float64")
 
 
+def test_dmrg_local_update_chi512(hip):
+    """One whole DMRG2 local update at chi = 512 (config #5): Lanczos Ritz value, split, environment update."""
+    checks.check_dmrg_local_update_full_chi(512, "float64")
+
+
 def test_advice_round1_low_items(hip):
     checks.check_advice_low_items()
 

@@ -412,3 +412,8 @@ def test_advice_round1_low_items(emu):
 @pytest.mark.parametrize("Lx,Ly,D,k", [(4, 6, 4, 0), (4, 6, 4, 2), (5, 5, 3, 1)])
 def test_two_sided_small_shapes(emu, Lx, Ly, D, k):
     checks.check_two_sided_small(Lx, Ly, D, k, "float64")
+
+
+def test_dmrg_local_update_small_chi(emu):
+    """The chi = 512 local-update check of the GPU suite, at chi = 24 on the plan interpreter."""
+    checks.check_dmrg_local_update_full_chi(24, "float64", nmv=6)
