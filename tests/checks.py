@@ -12,7 +12,10 @@ import pytest
 import quimb_amd as qa
 from oracle import np_oracle as orc
 
-#: relative tolerances (north_star: 1e-6 rel for fp32 on conditioned inputs)
+#: relative tolerances.  fp32: north_star asks 1e-6 relative to numpy on conditioned inputs; ``assert_close`` measures
+#: max |got - want| / max |want| over a whole result, and 2e-6 there is what a k-ordered fp32 fma chain meets on the
+#: mostly-positive fills of these checks with K up to 4096 and a few chained steps (round 2 used 2e-5).  The full-size
+#: lattice tests and the smoke assert 1e-6 on the VALUE of the network itself.
 RTOL = {np.dtype("float32"): 2e-6, np.dtype("float64"): 1e-12,
         np.dtype("complex64"): 2e-6, np.dtype("complex128"): 1e-12}
 
@@ -872,8 +875,10 @@ def check_random_pairs(dtype, ncases=120, seed=77):
         scale = np.einsum(eq, np.abs(x).astype(np.float64), np.abs(y).astype(np.float64))
         got = qa.einsum(eq, qa.asarray(x), qa.asarray(y)).to_numpy()
         # error budget relative to sum |a||b| (the inputs have a positive mean, so partial sums grow and the
-        # rounding error does not shrink with K): 0.1 * RTOL = 2e-6 in single, 1e-13 in double precision
-        tol = 0.1 * RTOL[np.dtype(dtype)] * np.maximum(scale, 1e-30) + 1e-30
+        # rounding error does not shrink with K): 1e-6 in single (north_star's number; SURVEY 8c: a k-ordered fp32
+        # fma chain errs by ~1e-7 sum |a b| at K <= 1024), 1e-13 in double precision -- per ELEMENT, not per max
+        budget = 1e-6 if np.dtype(dtype) in (np.dtype("float32"), np.dtype("complex64")) else 1e-13
+        tol = budget * np.maximum(scale, 1e-30) + 1e-30
         assert got.shape == want.shape, eq
         assert np.all(np.abs(got - want) <= tol), (eq, dims, float(np.max(np.abs(got - want) / tol)))
         done += 1
