@@ -527,6 +527,24 @@ def test_quadrant_tree_full_size(hip):
     assert out == pytest.approx(m.to_numpy().item() * 10.0**e, rel=2e-6)
 
 
+def test_found_tree_6x6_D6(hip):
+    """A tree FOUND by the finders (recursive bisection / the time objective), not written down, executed on the
+    device against the fp64 oracle: 6x6 D=6 fp32, with and without exponent stripping."""
+    from oracle import np_oracle as orc
+    import quimb_amd as qa
+
+    arrays, inputs = orc.tn2d_rand(6, 6, 6, seed=12, dtype="float32")
+    inputs = [tuple(t) for t in inputs]
+    size = {ix: 6 for t in inputs for ix in t}
+    want = orc.oracle_array_contract([a.astype(np.float64) for a in arrays], inputs, ()).item()
+    for strategy in ("auto-time", "bisection"):
+        tree = qa.find_path(inputs, (), size, strategy)
+        ex = qa.TreeExecutor(tree, "float32")
+        assert ex(arrays).to_numpy().item() == pytest.approx(want, rel=1e-6)
+        m, e = ex(arrays, strip_exponent=True)
+        assert m.to_numpy().item() * 10.0**e == pytest.approx(want, rel=1e-6)
+
+
 def test_config4_216_slices_full_size(hip):
     """BASELINE config #4 at full size on ONE device: the 10x10 D=6 sweep tree with 216 slices (three bonds; 256 is
     not reachable with all-6 bonds), every slice executed, summed on a common exponent: the fp64 oracle value at
