@@ -163,9 +163,12 @@ def contract_two_sided(plan, arrays, strip_exponent=False, group=None, stats=Non
             gdst = dst if group is None else dist.get_global_rank(group, dst)
             payload = as_tensor(T).contiguous()
             expo = torch.tensor([eT + eU], dtype=torch.float64, device=payload.device)
-            sent.append((T, payload, expo))
-            dist.send(payload, dst=gdst, group=group)
-            dist.send(expo, dst=gdst, group=group)
+            # non-blocking: this rank goes on to its next slab while the transfer runs; everything handed over stays
+            # referenced (``sent``) until the closing collective is behind it
+            sent.append((T, payload, expo, dist.isend(payload, dst=gdst, group=group), dist.isend(expo, dst=gdst, group=group)))
+        for item in sent:
+            item[3].wait()
+            item[4].wait()
     else:
         from .array import Array
 
@@ -174,9 +177,10 @@ def contract_two_sided(plan, arrays, strip_exponent=False, group=None, stats=Non
             gsrc = src if group is None else dist.get_global_rank(group, src)
             tb = as_tensor(B)
             recv = torch.empty_like(tb)
-            dist.recv(recv, src=gsrc, group=group)
             et = torch.zeros(1, dtype=torch.float64, device=tb.device)
-            dist.recv(et, src=gsrc, group=group)
+            works = [dist.irecv(recv, src=gsrc, group=group), dist.irecv(et, src=gsrc, group=group)]
+            for w_ in works:
+                w_.wait()
             if isinstance(B._buf, torch.Tensor):
                 T = Array(dev, recv.to(B._buf.device), B.shape, B.dtype)
             else:

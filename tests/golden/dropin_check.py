@@ -10,12 +10,21 @@ CPU tests (this script runs in the build container only: /root/reference does no
 
 Run by tests/test_dropin_reference.py in a subprocess; prints "DROPIN OK" when every check passed.
 """
+import argparse
 import os
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-sys.path.insert(0, os.path.join(HERE, "_shims"))
-sys.path.insert(0, "/root/reference")
+_ap = argparse.ArgumentParser()
+_ap.add_argument("--device", choices=["emu", "hip"], default="emu",
+                 help="emu: the numpy plan interpreter of the CPU tests; hip: the MI355X (needs a GPU AND the quimb sources)")
+_ap.add_argument("--stack", choices=["shims", "real"], default="shims",
+                 help="shims: quimb's sources from /root/reference with this repo's stand-ins for autoray / cotengra / numba / "
+                      "cytoolz; real: the INSTALLED quimb, autoray and cotengra (scripts/verify_real_stack.py)")
+ARGS = _ap.parse_args()
+if ARGS.stack == "shims":
+    sys.path.insert(0, os.path.join(HERE, "_shims"))
+    sys.path.insert(0, "/root/reference")
 sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 sys.path.insert(0, os.path.dirname(HERE))
 
@@ -25,11 +34,24 @@ import quimb.tensor as qtn  # noqa: E402
 import quimb_amd as qa  # noqa: E402
 import quimb_amd.autoray_backend as qab  # noqa: E402
 import quimb_amd.device as qd  # noqa: E402
-from emu_device import EmuDevice  # noqa: E402
 
-dev = EmuDevice()
-qd.set_default_device(dev)
+if ARGS.device == "emu":
+    from emu_device import EmuDevice  # noqa: E402
+
+    dev = EmuDevice()
+    qd.set_default_device(dev)
+else:
+    dev = qa.default_device()                      # HipDevice: raises if no GPU is visible
+    import collections
+
+    dev.calls = collections.Counter()
+    for _name in ("contract_pair", "permute"):     # the same launch counters the interpreter keeps
+        def _counted(*a, _f=getattr(dev, _name), _n=_name, **k):
+            dev.calls[_n] += 1
+            return _f(*a, **k)
+        setattr(dev, _name, _counted)
 assert qab.register() == "quimb_amd"
+print(f"stack: {ARGS.stack} (quimb from {os.path.dirname(qtn.__file__)}), device: {type(dev).__name__}")
 
 
 def host(x):

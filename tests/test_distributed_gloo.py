@@ -233,3 +233,101 @@ def test_quadrant_sharding_costs():
     for r in range(8):
         seen.add(tuple(sorted((repr(b), rng) for b, rng in sh.rank_ranges(r).items())))
     assert len(seen) == 8
+
+
+# ---------------------------------------------------------------------------------------------------------
+# RCCL itself: opt-in (QAMD_TEST_NCCL=1) on a box with >= 2 GPUs, so that the first multi-GPU bench run is not the
+# first execution of the nccl branches (the one-GPU box of the test tiers cannot run it: RCCL refuses two ranks on
+# one device)
+# ---------------------------------------------------------------------------------------------------------
+def _worker_nccl(rank, world, port, outdir):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+
+    torch.cuda.set_device(rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+    try:
+        import quimb_amd as qa
+        from oracle import np_oracle as orc
+        from quimb_amd.distributed import contract_sliced
+        from quimb_amd.quadrants import QuadrantRank, QuadrantSharding, contract_quadrants
+
+        arrays, inputs = orc.tn2d_rand(6, 6, 6, seed=4, dtype="float32")
+        size = {ix: 6 for t in inputs for ix in t}
+        sh = QuadrantSharding(inputs, size, 6, 6, world)
+        plan = QuadrantRank(sh, rank, "float32")
+        local = sh.shard([qa.asarray(a) for a in arrays], rank)
+        m, e = contract_quadrants(plan, local, strip_exponent=True)
+        tree = qa.find_slices(qa.ContractionTree(inputs, (), size, path=qa.sweep_path_2d(6, 6)), target_slices=6)
+        ms, es = contract_sliced(qa.TreeExecutor(tree, "float32"), arrays, strip_exponent=True)
+        np.save(os.path.join(outdir, f"r{rank}.npy"), np.asarray([m * 10.0**e, float(np.asarray(ms).reshape(-1)[0]) * 10.0**es]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_nccl_two_ranks_smoke(tmp_path):
+    import torch
+
+    if os.environ.get("QAMD_TEST_NCCL") != "1" or torch.cuda.device_count() < 2:
+        pytest.skip("set QAMD_TEST_NCCL=1 on a box with >= 2 GPUs")
+    import torch.multiprocessing as mp
+
+    from oracle import np_oracle as orc
+
+    port = _free_port()
+    mp.spawn(_worker_nccl, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    arrays, inputs = orc.tn2d_rand(6, 6, 6, seed=4, dtype="float64")
+    want = np.asarray(orc.oracle_array_contract(arrays, inputs, ())).item()
+    for r in range(2):
+        got = np.load(tmp_path / f"r{r}.npy")
+        assert got[0] == pytest.approx(want, rel=2e-6) and got[1] == pytest.approx(want, rel=2e-6)
+
+
+def _worker_sliced_complex(rank, world, port, outdir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+
+    import quimb_amd as qa
+    import quimb_amd.device as qd
+    from emu_device import EmuDevice
+    from oracle import np_oracle as orc
+    from quimb_amd.distributed import contract_sliced
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        qd.set_default_device(EmuDevice())
+        arrays, inputs = orc.tn2d_rand(3, 3, 3, seed=9, dtype="float64")
+        rng = np.random.default_rng(9)
+        arrays = [(a + 1j * rng.uniform(-0.5, 0.5, size=a.shape)).astype("complex128") for a in arrays]
+        size = {ix: 3 for t in inputs for ix in t}
+        st = qa.find_slices(qa.ContractionTree(inputs, (), size, path=qa.sweep_path_2d(3, 3)), target_slices=3)
+        m, e = contract_sliced(qa.TreeExecutor(st, "complex128"), arrays, strip_exponent=True)
+        np.save(os.path.join(outdir, f"r{rank}.npy"), np.asarray(m).reshape(-1)[:1] * 10.0**e)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sliced_complex_strip_exponent_gloo(tmp_path):
+    """A COMPLEX network through the one-collective join of ``contract_sliced`` (round 2 cast the gathered mantissa to
+    float64 and lost the imaginary part): real and imaginary part of the oracle's value on both ranks."""
+    import torch.multiprocessing as mp
+
+    from oracle import np_oracle as orc
+
+    port = _free_port()
+    mp.spawn(_worker_sliced_complex, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    arrays, inputs = orc.tn2d_rand(3, 3, 3, seed=9, dtype="float64")
+    rng = np.random.default_rng(9)
+    arrays = [(a + 1j * rng.uniform(-0.5, 0.5, size=a.shape)).astype("complex128") for a in arrays]
+    want = complex(np.asarray(orc.oracle_array_contract(arrays, inputs, ())).item())
+    assert abs(want.imag) > 1e-6 * abs(want)
+    for r in range(2):
+        got = complex(np.load(tmp_path / f"r{r}.npy")[0])
+        assert abs(got - want) <= 1e-10 * abs(want), (got, want)
