@@ -17,14 +17,14 @@ TAG=${1:-r01}
 OUT=$R/gpurun_out/profiles_new
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-CMD="python $R/bench.py --steps 5 --warmup 2 --no-cpu"
+CMD="python $R/bench.py --steps 5 --warmup 2 --no-cpu --no-secondary"
 pass() {  # name, rocprof args...
   n=$1; shift
   rm -rf /tmp/qprof_$n
   rocprofv3 "$@" -d /tmp/qprof_$n -o r -- $CMD > $OUT/${TAG}_bench_$n.json 2> /tmp/qprof_$n.log
   db=$(find /tmp/qprof_$n -name "r_results.db" | head -1)
   python $R/scripts/rocpd_summary.py $db --top 200 --by-grid > $OUT/${TAG}_bench_$n.txt 2>&1
-  sed -i "s#/tmp/qprof_$n#rocprofv3 $* -- bench.py --steps 5 --warmup 2#" $OUT/${TAG}_bench_$n.txt
+  sed -i "s#/tmp/qprof_$n#rocprofv3 $* -- bench.py --steps 5 --warmup 2 --no-cpu --no-secondary#" $OUT/${TAG}_bench_$n.txt
 }
 pass stats --kernel-trace --stats
 pass fetch --kernel-trace --pmc FETCH_SIZE

@@ -15,7 +15,7 @@ def short(name):
         name, grid = name.rsplit(" grid=", 1)
         grid = " grid=" + grid
     name = re.sub(r"\(.*$", "", name) + grid
-    name = name.replace("void ", "").replace("qamd::", "")
+    name = name.replace("void ", "").replace("qamd::", "").replace("qamdk::", "")
     return name[:110]
 
 
