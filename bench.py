@@ -301,7 +301,7 @@ def main():
 
     def materialize(r):
         if r is not None and hasattr(r[0], "item"):
-            return r[0].item(), dev.read_exponent(r[1]) if hasattr(r[1], "cpu") else r[1]
+            return r[0].item(), (r[1] if isinstance(r[1], float) else dev.read_exponent(r[1]))
         return r
 
     def fence():
@@ -530,7 +530,9 @@ def main():
                 "workload": f"{args.Lx}x{args.Ly} D={args.D} PEPS amplitude (single-layer TN), exact, " + workload,
                 "tree": tree_name,
                 "tree_mults": tree.contraction_cost(),
-                "best_known_tree_mults": sweep_tree.contraction_cost(),   # the min-FLOP site sweep
+                # the cheapest tree known for this network (quote it next to the executed tree's count, so that
+                # an extra-FLOP tree cannot inflate the number): the site sweep on the 10x10 lattice
+                "best_known_tree_mults": min(sweep_tree.contraction_cost(), quad_tree.contraction_cost()),
                 "trees_tried_untimed": tree_probe,
                 "flops_per_step": flops_step,
                 "nslices": nsl,

@@ -69,7 +69,7 @@ def svd_via_eig(x, max_bond=-1):
     The two Gram / back-projection products run on this library's GETT kernels, the small eigenproblem on
     rocSOLVER ``syevd``: 23 ms instead of 260 ms (``gesvd``) for the 1024 x 1024 fp64 two-site tensor of a
     chi = 512 DMRG step.  Singular values below ~sqrt(eps) * s_max lose relative accuracy (squared condition); only
-    directions below the Gram matrix's noise floor (eigenvalue <= eps * s_max^2) are dropped."""
+    directions below the Gram matrix's noise floor (eigenvalue <= 8 eps * s_max^2) are dropped."""
     from . import ops
 
     x = x if isinstance(x, Array) else Array.from_numpy(np.asarray(x))
@@ -87,7 +87,10 @@ def svd_via_eig(x, max_bond=-1):
     # which is the documented price of method "svd:eig".  At least one direction stays.
     s_all = np.sqrt(np.clip(wh, 0.0, None))
     eps = np.finfo(np.dtype(w.dtype.name if hasattr(w.dtype, "name") else w.dtype)).eps
-    keep = int(np.count_nonzero(wh > eps * float(wh[0]))) if wh.size and wh[0] > 0 else 1
+    # (floor = 8 eps s_max^2: a Hermitian eigensolver returns a zero eigenvalue as a few eps of |G| with either sign;
+    # in s that is 2.8 sqrt(eps) s_max -- 1e-3 in float32, 4e-8 in float64: callers that need more of the spectrum in
+    # single precision use method "svd", and DMRG2 / tensor_split take the rank from the returned factors)
+    keep = int(np.count_nonzero(wh > 8.0 * eps * float(wh[0]))) if wh.size and wh[0] > 0 else 1
     k = max(1, min(k, keep))
     sh = s_all[:k]
     V = v[:, ::-1][:, :k] if k < len(wh) else v[:, ::-1]          # columns by descending eigenvalue
