@@ -136,11 +136,13 @@ static bool gemmk_operand_ok(int ng, const int64_t* dims, const int64_t* strides
 
 static double gemmk_model(int64_t M, int64_t N, int64_t B, int ta, int tb, int64_t* tiles_out) {
   const int64_t tiles = ((M + 64 * ta - 1) / (64 * ta)) * ((N + 64 * tb - 1) / (64 * tb)) * B;
-  const int occ = (ta * tb <= 6) ? 2 : 1;     // workgroups per CU (registers: 16 accumulators per sub-tile)
-  const int64_t rounds = (tiles + kNumCU * occ - 1) / (kNumCU * occ);
+  // rounds of one tile per CU: two co-resident workgroups of a small tile time-share the CU's matrix pipes, so
+  // occupancy smooths the tail but does not add throughput (measured, profiles/r03_gemm_pow6.txt: 2048 x 2560 x 512
+  // runs 82 TFLOP/s on 220 tiles of 192 x 128 against 75 on 160 tiles of 128 x 256)
+  const int64_t rounds = (tiles + kNumCU - 1) / kNumCU;
   static const double eff[17] = {0, 0, 0, 0, 0.86, 0, 0.90, 0, 0.93, 0.95, 0, 0, 0.96, 0, 0, 0, 0.97};
   if (tiles_out) *tiles_out = tiles;
-  return (double)rounds * occ * ta * tb / eff[ta * tb];
+  return (double)rounds * ta * tb / eff[ta * tb];
 }
 
 static bool gemmk_config(const qamd_pair_plan* p, const PairDims& d, int64_t align_a, int64_t align_b, int64_t align_c,
