@@ -34,10 +34,12 @@ from .dmrg import DMRG2, mpo_ham_heis
 from .split import array_split, tensor_split
 from .circuit import Circuit, CircuitMPS
 from .network import TensorNetwork
-from .pathfind import (find_path, find_slices, fused_pair_count, geometry_hash, greedy_path, modeled_time,
+from .pathfind import (bisection_ssa, find_path, find_slices, fused_pair_count, geometry_hash, greedy_path, modeled_time,
                        quadrant_path_2d, random_greedy, set_tree_cache, sweep_path_2d)
 from .tree import ContractionTree
 from .twosided import TwoSidedContraction
+from . import quadrants
+from .quadrants import QuadrantRank, QuadrantSharding, contract_quadrants
 from .device import HipDevice, default_device
 
 # the class must report the top-level module for autoray's backend inference
