@@ -114,24 +114,19 @@ static bool dot_rows(const qamd_pair_plan* p, const PairDims& d, DotArgs& a) {
 
 // ---- gemmk.hip eligibility and tile choice --------------------------------------------------------
 // Both operands carry their free bundle innermost in 4-element vectors, ONE K group (K % 8 == 0),
-// non-negative strides, per-lane offsets inside a tile below 4 GiB.  The operands swap roles when
+// non-negative strides, free-bundle offsets of the whole operand below 4 GiB.  The operands swap roles when
 // C's stride-1 index lives in the M bundle (lanes of an MFMA result run along the B operand's index).
-static bool gemmk_operand_ok(int ng, const int64_t* dims, const int64_t* strides, int64_t sk, int64_t tile) {
+static bool gemmk_operand_ok(int ng, const int64_t* dims, const int64_t* strides, int64_t sk) {
   if (ng < 1 || strides[ng - 1] != 1 || dims[ng - 1] % 4 || sk <= 0) return false;
-  int64_t span = 0;   // largest element offset inside a tile of `tile` consecutive bundle indices
+  // the kernel addresses a lane's 16-byte piece as (wave-uniform 64-bit base that advances along k) + (32-bit byte
+  // offset of its free-bundle index, absolute within the operand, + up to 15 k rows): everything must stay below 4 GiB
+  int64_t span = 0;
   for (int g = 0; g < ng; ++g) {
     if (strides[g] < 0) return false;
     if (g < ng - 1 && strides[g] % 4) return false;
+    span += (dims[g] - 1) * strides[g];
   }
-  // offsets of a run of `tile` consecutive indices: bounded by the span of the groups it can touch
-  int64_t run = 1;
-  for (int g = ng - 1; g >= 0; --g) {
-    const int64_t touched = std::min<int64_t>(dims[g], (tile + run - 1) / run + 1);
-    span += (touched - 1) * strides[g];
-    run *= dims[g];
-    if (run >= 2 * tile) break;
-  }
-  return (span + 15 * sk + 4) * 4 < (1ll << 32);
+  return (span + 16 * sk + 4) * 4 < (1ll << 32);
 }
 
 static double gemmk_model(int64_t M, int64_t N, int64_t B, int ta, int tb, int64_t* tiles_out) {
@@ -152,8 +147,8 @@ static bool gemmk_config(const qamd_pair_plan* p, const PairDims& d, int64_t ali
   if (p->dtype != QAMD_F32 || p->nk != 1 || p->a_kcontig || p->b_kcontig || p->vec_a < 4 || p->vec_b < 4) return false;
   if (d.K % 8 || d.K < 64 || d.M < 128 || d.N < 128 || d.M % 4 || d.N % 4) return false;
   if ((align_a % 16) || (align_b % 16) || (align_c % 4)) return false;
-  if (!gemmk_operand_ok(p->nm, p->dim_m, p->sa_m, p->sa_k[0], 256) ||
-      !gemmk_operand_ok(p->nn, p->dim_n, p->sb_n, p->sb_k[0], 256))
+  if (!gemmk_operand_ok(p->nm, p->dim_m, p->sa_m, p->sa_k[0]) ||
+      !gemmk_operand_ok(p->nn, p->dim_n, p->sb_n, p->sb_k[0]))
     return false;
   for (int i = 0; i < p->nb; ++i)
     if (p->sa_b[i] % 4 || p->sb_b[i] % 4) return false;

@@ -329,6 +329,10 @@ class TreeExecutor:
                     if pj is not None and self.lanes[pj] != self.lanes[pi]:
                         mine.wait_stream(streams[self.lanes[pj]])     # the join: one event
                         keep_alive.append(live[o])
+                        buf_ = getattr(live[o], "_buf", None)
+                        if hasattr(buf_, "record_stream") and not dev.torch.cuda.is_current_stream_capturing():
+                            buf_.record_stream(mine)      # allocated on the producer's stream, read on this one: the
+                                                          # allocator must not hand it out again before this stream is done
                 dev.torch.cuda.set_stream(mine)
                 if trace is not None and pi in trace_at:
                     ev = dev.torch.cuda.Event(enable_timing=True)
