@@ -40,6 +40,8 @@ from .tree import ContractionTree
 from .twosided import TwoSidedContraction
 from . import quadrants
 from .quadrants import QuadrantRank, QuadrantSharding, contract_quadrants
+from . import rangeslice
+from .rangeslice import RangeSliced, RangeSlicedExecutor, contract_range_sliced, find_range_slices
 from .device import HipDevice, default_device
 
 # the class must report the top-level module for autoray's backend inference
