@@ -16,7 +16,18 @@ def pytest_configure(config):
     if not os.path.exists(so) and os.path.exists("/opt/rocm/bin/hipcc"):
         import subprocess
 
-        subprocess.run(["make", "-s", "-j8", "-C", os.path.join(ROOT, "quimb_amd", "csrc")], check=False)
+        subprocess.run(["make", "-s", "-j4", "-C", os.path.join(ROOT, "quimb_amd", "csrc")], check=False)
+
+
+def pytest_collection_modifyitems(config, items):
+    """No test of this suite may hang a run: with pytest-timeout present (it is in this image) every test gets a
+    15-minute ceiling unless the command line set its own -- a GPU test stuck in a device call ends the run with a
+    failure instead of occupying the box until an outer limit kills it."""
+    if not config.pluginmanager.hasplugin("timeout") or getattr(config.option, "timeout", None):
+        return
+    for item in items:
+        if item.get_closest_marker("timeout") is None:
+            item.add_marker(pytest.mark.timeout(900, method="thread"))
 
 
 @pytest.fixture
