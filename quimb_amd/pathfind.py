@@ -133,18 +133,27 @@ def random_greedy(inputs, output, size_dict, repeats=32, seed=0, temperature=0.3
     return best
 
 
-# gfx950 roofs the time model prices a step against (MI355X_MICROARCH.md: dense MFMA peaks, achievable HBM copy rate)
+# gfx950 roofs the time model prices a step against (MI355X_MICROARCH.md: dense MFMA peaks, achievable HBM copy rate),
+# and what this library's kernels reach of them (round-3 measurements): the k-outer MFMA kernel
+# 0.85 of the peak on GEMM-shaped fp32 joins, the older tiled kernels ~0.5; streaming / fused-pair kernels 4.9 of the
+# 6.29 TB/s a copy reaches; a launch that moves less than a few MB is latency: ~12 us on the device
 _PEAK_FLOPS = {"float32": 157.3e12, "float64": 78.6e12, "complex64": 157.3e12, "complex128": 78.6e12}
 _HBM_BYTES_PER_S = 6.29e12
-_LAUNCH_S = 4e-6
+_HBM_EFF = 0.78
+_MFMA_EFF_JOIN, _MFMA_EFF_TILED = 0.85, 0.5
+_LAUNCH_S, _SMALL_LAUNCH_S, _SMALL_BYTES = 4e-6, 12e-6, 4 << 20
 
 
 def modeled_time(tree, dtype="float32"):
-    """Roofline estimate of executing ``tree`` on one MI355X: every launch of the plan the whole-tree executor
-    would issue costs ``max(flops / MFMA peak, algorithmic bytes / HBM rate) + launch``, slices repeated -- the
-    objective of the intensity-aware finders.  Fused pairs (two big-x-small steps in
-    one pass, chain2q.hip) count with the bytes they actually move, so an order that lines such pairs up is
-    cheaper than one with the same multiplication count that does not."""
+    """Estimate of executing ``tree`` on one MI355X: every launch of the plan the whole-tree executor would issue costs
+    ``max(flops / (MFMA peak x kernel efficiency), algorithmic bytes / achieved HBM rate) + launch``, slices repeated,
+    and the lanes of the plan (independent branches on their own HIP streams, ``TreeExecutor._assign_lanes``) overlap:
+    the caller's lane runs in sequence, the side lanes cost the longest of them or their summed HBM time, whichever is
+    larger -- the objective of the intensity-aware finders.  Fused pairs (two
+    big-x-small steps in one pass, chain2q.hip) count with the bytes they actually move.  On the headline network it
+    lands within 10 % of the device: site sweep 22.6 ms (measured 20.5), four-quadrant tree 14.8 ms (measured 16.0),
+    the busiest rank's share of 2 / 4 / 8 ranks 7.6 / 3.9 / 2.2 ms (measured 9.1 / 5.4 / 3.6: the small and size-3
+    steps of a share run further below the roofs than the model's one efficiency per kernel class says)."""
     import numpy as np
 
     from .executor import TreeExecutor   # planning only: no device is touched
@@ -153,11 +162,33 @@ def modeled_time(tree, dtype="float32"):
     name = np.dtype(dtype).name
     f = 8 if np.dtype(dtype).kind == "c" else 2
     ns = tree.nslices
-    t = 0.0
-    for inf in ex.info:
+    lane_t, lane_hbm = {}, {}
+    for inf, lane in zip(ex.info, ex.lanes):
         rep = ns if inf.sliced_dep else 1
-        t += rep * (max(f * inf.mults / _PEAK_FLOPS[name], inf.bytes / _HBM_BYTES_PER_S) + _LAUNCH_S)
-    return t
+        join = name == "float32" and inf.kind == "gett" and min(inf.M, inf.N) >= 128 and inf.K >= 64
+        t_mfma = f * inf.mults / (_PEAK_FLOPS[name] * (_MFMA_EFF_JOIN if join else _MFMA_EFF_TILED))
+        t_hbm = inf.bytes / (_HBM_BYTES_PER_S * _HBM_EFF)
+        t = max(t_mfma, t_hbm) + (_SMALL_LAUNCH_S if inf.bytes < _SMALL_BYTES else _LAUNCH_S)
+        lane_t[lane] = lane_t.get(lane, 0.0) + rep * t
+        lane_hbm[lane] = lane_hbm.get(lane, 0.0) + rep * (t_hbm if t_hbm >= t_mfma else 0.0)
+    side = [l for l in lane_t if l != 0]
+    # lane 0: its own chain, then the joins; side lanes run beside lane 0's chain and share the HBM with it
+    own = lane_t.get(0, 0.0)
+    if not side:
+        return own
+    overlap = max(max(lane_t[l] for l in side), sum(lane_hbm[l] for l in side))
+    # the part of lane 0 that precedes the first join is concurrent with the side lanes: count the larger of the two
+    first_join = next((i for i, e in enumerate(ex.plan) if ex.lanes[i] == 0 and
+                       any(ex.lanes[ex._producer[o]] != 0 for o in ex._entry_io(e)[0] if o in ex._producer)), len(ex.plan))
+    pre = 0.0
+    for i, (inf, lane) in enumerate(zip(ex.info, ex.lanes)):
+        if lane == 0 and i < first_join:
+            join = name == "float32" and inf.kind == "gett" and min(inf.M, inf.N) >= 128 and inf.K >= 64
+            t_mfma = f * inf.mults / (_PEAK_FLOPS[name] * (_MFMA_EFF_JOIN if join else _MFMA_EFF_TILED))
+            t_hbm = inf.bytes / (_HBM_BYTES_PER_S * _HBM_EFF)
+            pre += (ns if inf.sliced_dep else 1) * (max(t_mfma, t_hbm) + (_SMALL_LAUNCH_S if inf.bytes < _SMALL_BYTES else _LAUNCH_S))
+    hbm_all = sum(lane_hbm[l] for l in side) + lane_hbm.get(0, 0.0) * (pre / own if own else 0.0)
+    return (own - pre) + max(pre, overlap, hbm_all)
 
 
 def fused_pair_count(tree, dtype="float32"):

@@ -398,11 +398,11 @@ def test_intensity_aware_finders(emu):
     sl = qa.find_slices(by_time, target_slices=9, minimize="time", dtype="float64")
     assert sl.nslices >= 9
     assert qa.TreeExecutor(sl, "float64")(arrays).to_numpy().item() == pytest.approx(want, rel=1e-10)
-    # the headline network: the site-by-site sweep is 40 fused pairs, HBM-bound: 12-20 ms by the model
+    # the headline network: the site-by-site sweep is 40 fused pairs, HBM-bound: ~22 ms by the model (measured 20.5)
     _, big = orc.tn2d_rand(10, 10, 2, seed=1)
     big = [tuple(t) for t in big]
     sweep = qa.ContractionTree(big, (), {ix: 6 for t in big for ix in t}, path=qa.sweep_path_2d(10, 10))
-    assert qa.fused_pair_count(sweep) == 40 and 0.010 < qa.modeled_time(sweep) < 0.022
+    assert qa.fused_pair_count(sweep) == 40 and 0.015 < qa.modeled_time(sweep) < 0.026
     # ... and the finders FIND a tree for it that beats the hand-written sweep by the model: recursive bisection with
     # reconfigured leaves arrives at four corner sweeps + two 7776^3 joins (round 2's finders: 2.3e13 / 4.4e15 mults)
     size6 = {ix: 6 for t in big for ix in t}
