@@ -115,3 +115,36 @@ def test_local_ops_match_real_quimb(emu):
 @pytest.mark.gpu
 def test_local_ops_hip_match_real_quimb(hip):
     checks.check_golden_local(rtol=1e-11)
+
+
+def test_round3_trees_match_real_quimb_values(emu):
+    """The real quimb's values of two golden lattices (``TN2D_rand(4,4,3,seed=42).contract(all)``, the 6x6 Ising
+    partition function) through the round-3 ways of contracting them: the four-quadrant tree, a tree FOUND by recursive
+    bisection / the time objective, range slices chosen by cost, and the quadrant tree sharded into rank blocks
+    (every rank's share evaluated here, summed)."""
+    import quimb_amd as qa
+    from quimb_amd.quadrants import QuadrantRank, QuadrantSharding, combine_pairs
+    from quimb_amd.rangeslice import RangeSliced, RangeSlicedExecutor, find_range_slices
+
+    for name, L in (("tn2d_rand_4x4_D3", 4), ("ising_6x6_b044", 6)):
+        g = checks.load_golden(name)
+        arrays, inputs, want = g["arrays"], [tuple(t) for t in g["inputs"]], g["value"].item()
+        size = {ix: d for t, a in zip(inputs, arrays) for ix, d in zip(t, a.shape)}
+        # quimb's builders order a site's indices by direction, not by neighbour: rebuild the row-major site order check
+        assert len(arrays) == L * L
+        quad = qa.ContractionTree(inputs, (), size, path=qa.quadrant_path_2d(L, L))
+        assert qa.TreeExecutor(quad, "float64")(arrays).to_numpy().item() == pytest.approx(want, rel=1e-11)
+        for strategy in ("bisection", "auto-time"):
+            found = qa.find_path(inputs, (), size, strategy)
+            assert qa.TreeExecutor(found, "float64")(arrays).to_numpy().item() == pytest.approx(want, rel=1e-11)
+        d_cut = min(size.values())
+        for n in (2, d_cut):
+            rse = RangeSlicedExecutor(RangeSliced(quad, find_range_slices(quad, n)), "float64")
+            assert rse(arrays).item() == pytest.approx(want, rel=1e-11)
+        for world in (2, 4) if d_cut % 2 == 0 else (3,):
+            sh = QuadrantSharding(inputs, size, L, L, world)
+            pairs = []
+            for r in range(world):
+                m, e = QuadrantRank(sh, r, "float64")(sh.shard(arrays, r))
+                pairs.append((m.to_numpy().item(), e))
+            assert combine_pairs(pairs) == pytest.approx(want, rel=1e-11)
