@@ -454,7 +454,8 @@ template <typename R>
 __global__ void strip_finish_kernel(double* __restrict__ exponent, typename Bits<R>::u* scratch) {
   if (threadIdx.x == 0 && blockIdx.x == 0) {
     R m = Bits<R>::from(scratch[0]);
-    if (m > R(0)) exponent[0] += log10((double)m);
+    // independent branches of a tree run on different HIP streams and share ONE accumulator: the add is atomic
+    if (m > R(0)) atomicAdd(exponent, log10((double)m));
     scratch[0] = 0;
   }
 }

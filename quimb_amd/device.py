@@ -55,7 +55,7 @@ def fill_plan_struct(spec: GettSpec, code: int):
 
 
 class _CompiledPair:
-    __slots__ = ("struct", "ktab", "ws_bytes")
+    __slots__ = ("struct", "ktab", "ws_bytes", "ready", "ready_stream")
 
 
 class HipDevice:
@@ -85,9 +85,6 @@ class HipDevice:
             np.dtype("int64"): torch.int64,
         }
         self._pairs = {}
-        self._ws = None
-        self._ws_retired = []   # outgrown split-K workspaces, kept alive for captured graphs (see _workspace)
-        self._scratch = torch.zeros(4, dtype=torch.float64, device=self.tdev)
         #: set to a list to collect (spec, dtype, tile_cfg, split_k, start_event, end_event)
         #: per qamd_contract_pair launch (HIP events on the launch stream)
         self.profile = None
@@ -132,18 +129,20 @@ class HipDevice:
         return [self.torch.cuda.current_stream(self.tdev)] + pool[: n - 1]
 
     def _workspace(self, nbytes):
+        """Split-K / dot workspace of ONE launch: a stream-ordered allocation from torch's caching allocator on the
+        launch stream.  The executor runs independent branches on several HIP streams (lanes), so there is no
+        device-wide workspace: two under-filled launches on different lanes must not write their partial sums into
+        the same slab.  The block goes back to its stream's pool as soon as the launch is queued (later launches on
+        that stream are ordered behind it); under stream capture it comes from the graph's private pool and lives as
+        long as the graph does."""
         if nbytes <= 0:
-            return None, 0
-        if self._ws is None or self._ws.numel() < nbytes:
-            # captured hipGraphs (TreeExecutor slice graphs, GraphedContraction, TNLinearOperator(graph=True)) bake
-            # the raw pointer of the workspace they were recorded with into their split-K nodes: a workspace that
-            # is outgrown is RETIRED, never freed, so that replaying such a graph later still writes into memory
-            # nothing else owns.  Sizes grow geometrically, so the retired list stays short.
-            if self._ws is not None:
-                self._ws_retired.append(self._ws)
-            grow = max(int(nbytes), 2 * (self._ws.numel() if self._ws is not None else 0))
-            self._ws = self.torch.empty(grow, dtype=self.torch.uint8, device=self.tdev)
-        return self._ws.data_ptr(), self._ws.numel()
+            return None, None, 0
+        ws = self.torch.empty(int(nbytes), dtype=self.torch.uint8, device=self.tdev)
+        return ws, ws.data_ptr(), ws.numel()
+
+    def _scratch(self):
+        """4 doubles of reduction scratch for one call, private to the launch stream (see ``_workspace``)."""
+        return self.torch.empty(4, dtype=self.torch.float64, device=self.tdev)
 
     # ---- pairwise contraction ---------------------------------------------
     def compile_pair(self, spec, dtype, align_a=16, align_b=16, align_c=16):
@@ -167,9 +166,24 @@ class HipDevice:
         cp = _CompiledPair()
         cp.struct = p
         cp.ktab = ktab
+        # the table is filled by a kernel on THIS stream; a launch on another lane that finds the plan in the cache
+        # waits for the event first (``_wait_plan_tables``)
+        cp.ready = self.torch.cuda.Event()
+        cp.ready.record()
+        cp.ready_stream = self.stream()
         cp.ws_bytes = int(self.lib.qamd_pair_workspace_bytes(C.byref(p)))
         self._pairs[key] = cp
         return cp
+
+    def _wait_plan_tables(self, cp):
+        """Order the current stream behind the kernel that filled ``cp.ktab`` (built on another stream)."""
+        ev = cp.ready
+        if ev is None:
+            return
+        if self.stream() != cp.ready_stream:
+            self.torch.cuda.current_stream(self.tdev).wait_event(ev)
+        if not self.torch.cuda.is_current_stream_capturing() and ev.query():
+            cp.ready = None          # the table is final: nothing to wait for any more
 
     def describe_pair(self, cp):
         buf = C.create_string_buffer(160)
@@ -181,7 +195,8 @@ class HipDevice:
         exponent-stripping epilogue (entries may be None)."""
         pa, pb, pc = a.data_ptr(), b.data_ptr(), c.data_ptr()
         cp = self.compile_pair(spec, dtype, min(pa & -pa, 16), min(pb & -pb, 16), min(pc & -pc, 16))
-        ws, wsn = self._workspace(cp.ws_bytes)
+        ws_keep, ws, wsn = self._workspace(cp.ws_bytes)
+        self._wait_plan_tables(cp)
         epp = None
         if ep is not None:
             e = _lib.Epilogue()
@@ -395,9 +410,11 @@ class HipDevice:
         return self.torch.zeros(1, dtype=self.torch.float64, device=self.tdev)
 
     def strip_exponent(self, x, n, dtype, exponent):
+        """x /= max|x|; exponent += log10(max|x|) (an atomic add: lanes share one accumulator)."""
+        scratch = self._scratch()
         _lib.check(
             self.lib.qamd_strip_exponent(
-                x.data_ptr(), int(n), dtype_code(dtype), self._scratch.data_ptr(), exponent.data_ptr(), self.stream()
+                x.data_ptr(), int(n), dtype_code(dtype), scratch.data_ptr(), exponent.data_ptr(), self.stream()
             ),
             "qamd_strip_exponent",
         )
@@ -430,11 +447,12 @@ class HipDevice:
         return float(exponent.cpu()[0])
 
     def absmax(self, x, n, dtype):
+        scratch = self._scratch()
         _lib.check(
-            self.lib.qamd_absmax(self._scratch.data_ptr() + 16, x.data_ptr(), int(n), dtype_code(dtype), self.stream()),
+            self.lib.qamd_absmax(scratch.data_ptr() + 16, x.data_ptr(), int(n), dtype_code(dtype), self.stream()),
             "qamd_absmax",
         )
-        return float(self._scratch.cpu()[2])
+        return float(scratch.cpu()[2])
 
 
     def buffer_address(self, buf):

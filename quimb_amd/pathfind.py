@@ -144,6 +144,17 @@ _MFMA_EFF_JOIN, _MFMA_EFF_TILED = 0.85, 0.5
 _LAUNCH_S, _SMALL_LAUNCH_S, _SMALL_BYTES = 4e-6, 12e-6, 4 << 20
 
 
+def _step_cost(inf, name, f, nslices):
+    """(seconds, seconds of it that are HBM time) of one launch of the executor's plan, repeated per slice where the
+    step depends on a sliced index -- the ONE place the time model prices a step."""
+    rep = nslices if inf.sliced_dep else 1
+    join = name == "float32" and inf.kind == "gett" and min(inf.M, inf.N) >= 128 and inf.K >= 64   # gemmk's domain
+    t_mfma = f * inf.mults / (_PEAK_FLOPS[name] * (_MFMA_EFF_JOIN if join else _MFMA_EFF_TILED))
+    t_hbm = inf.bytes / (_HBM_BYTES_PER_S * _HBM_EFF)
+    t = max(t_mfma, t_hbm) + (_SMALL_LAUNCH_S if inf.bytes < _SMALL_BYTES else _LAUNCH_S)
+    return rep * t, rep * (t_hbm if t_hbm >= t_mfma else 0.0)
+
+
 def modeled_time(tree, dtype="float32"):
     """Estimate of executing ``tree`` on one MI355X: every launch of the plan the whole-tree executor would issue costs
     ``max(flops / (MFMA peak x kernel efficiency), algorithmic bytes / achieved HBM rate) + launch``, slices repeated,
@@ -163,14 +174,10 @@ def modeled_time(tree, dtype="float32"):
     f = 8 if np.dtype(dtype).kind == "c" else 2
     ns = tree.nslices
     lane_t, lane_hbm = {}, {}
-    for inf, lane in zip(ex.info, ex.lanes):
-        rep = ns if inf.sliced_dep else 1
-        join = name == "float32" and inf.kind == "gett" and min(inf.M, inf.N) >= 128 and inf.K >= 64
-        t_mfma = f * inf.mults / (_PEAK_FLOPS[name] * (_MFMA_EFF_JOIN if join else _MFMA_EFF_TILED))
-        t_hbm = inf.bytes / (_HBM_BYTES_PER_S * _HBM_EFF)
-        t = max(t_mfma, t_hbm) + (_SMALL_LAUNCH_S if inf.bytes < _SMALL_BYTES else _LAUNCH_S)
-        lane_t[lane] = lane_t.get(lane, 0.0) + rep * t
-        lane_hbm[lane] = lane_hbm.get(lane, 0.0) + rep * (t_hbm if t_hbm >= t_mfma else 0.0)
+    cost = [_step_cost(inf, name, f, ns) for inf in ex.info]      # (time, HBM-bound part) per launch, slices included
+    for (t, hbm), lane in zip(cost, ex.lanes):
+        lane_t[lane] = lane_t.get(lane, 0.0) + t
+        lane_hbm[lane] = lane_hbm.get(lane, 0.0) + hbm
     side = [l for l in lane_t if l != 0]
     # lane 0: its own chain, then the joins; side lanes run beside lane 0's chain and share the HBM with it
     own = lane_t.get(0, 0.0)
@@ -180,13 +187,7 @@ def modeled_time(tree, dtype="float32"):
     # the part of lane 0 that precedes the first join is concurrent with the side lanes: count the larger of the two
     first_join = next((i for i, e in enumerate(ex.plan) if ex.lanes[i] == 0 and
                        any(ex.lanes[ex._producer[o]] != 0 for o in ex._entry_io(e)[0] if o in ex._producer)), len(ex.plan))
-    pre = 0.0
-    for i, (inf, lane) in enumerate(zip(ex.info, ex.lanes)):
-        if lane == 0 and i < first_join:
-            join = name == "float32" and inf.kind == "gett" and min(inf.M, inf.N) >= 128 and inf.K >= 64
-            t_mfma = f * inf.mults / (_PEAK_FLOPS[name] * (_MFMA_EFF_JOIN if join else _MFMA_EFF_TILED))
-            t_hbm = inf.bytes / (_HBM_BYTES_PER_S * _HBM_EFF)
-            pre += (ns if inf.sliced_dep else 1) * (max(t_mfma, t_hbm) + (_SMALL_LAUNCH_S if inf.bytes < _SMALL_BYTES else _LAUNCH_S))
+    pre = sum(cost[i][0] for i, lane in enumerate(ex.lanes) if lane == 0 and i < first_join)
     hbm_all = sum(lane_hbm[l] for l in side) + lane_hbm.get(0, 0.0) * (pre / own if own else 0.0)
     return (own - pre) + max(pre, overlap, hbm_all)
 
@@ -285,6 +286,11 @@ def set_tree_cache(directory):
     _TREE_CACHE_DIR[0] = os.fspath(directory) if directory else None
 
 
+#: bump when the candidate set / objective of a named strategy changes (r2: "auto-hq" gained recursive bisection;
+#: r3: one per-step cost helper in the time model)
+_FINDER_REV = 3
+
+
 def _cache_file(inputs, output, size_dict, optimize):
     d = _TREE_CACHE_DIR[0]
     if d is None:
@@ -307,7 +313,9 @@ def find_path(inputs, output, size_dict, optimize="greedy", dtype="float32"):
         import numpy as _np
 
         dt_name = _np.dtype(dtype).name
-        path_file = _cache_file(inputs, output, size_dict, optimize + ("@" + dt_name if optimize == "auto-time" else ""))
+        # the finder's revision is part of the key: entries written by an older candidate set are searched again
+        path_file = _cache_file(inputs, output, size_dict,
+                                f"{optimize}#r{_FINDER_REV}" + ("@" + dt_name if optimize == "auto-time" else ""))
         if path_file and os.path.exists(path_file):
             try:
                 with open(path_file) as f:

@@ -178,7 +178,8 @@ class QuadrantRank:
 
     def __call__(self, local_arrays, defer=False):
         """(mantissa Array, exponent) of this rank's z_ij; ``defer``: the exponent stays on the device."""
-        if self._graph is not None and self._graph_key == tuple(id(a) for a in local_arrays):
+        key = self._graph_key
+        if self._graph is not None and len(key) == len(local_arrays) and all(a is b for a, b in zip(key, local_arrays)):
             return self._graph.replay(defer_exponent=defer)
         return self.executor(local_arrays, strip_exponent=True, defer_exponent=defer)
 
@@ -188,7 +189,7 @@ class QuadrantRank:
         at 8 ranks a share is ~3 ms of device time, less than Python needs to enqueue it.  HIP device only; refresh a
         changed input with ``plan.update(i, array)``."""
         self._graph = self.executor.graph(local_arrays, strip_exponent=True)
-        self._graph_key = tuple(id(a) for a in local_arrays)
+        self._graph_key = tuple(local_arrays)    # the objects themselves: an id() can be reused once they are freed
         return self
 
     def update(self, i, array):
@@ -208,16 +209,24 @@ def contract_quadrants(rank_plan, local_arrays, strip_exponent=False, group=None
     buf = m._buf
     if isinstance(buf, torch.Tensor) and isinstance(e, torch.Tensor):
         # device resident: the pair is assembled on the device, nothing is read back before the collective
-        mine = torch.cat([buf[:1].to(torch.float64), e.to(torch.float64).reshape(1)])
+        head = buf[:1]
+        if head.is_complex():
+            reim = torch.view_as_real(head).reshape(2).to(torch.float64)
+        else:
+            reim = torch.cat([head.to(torch.float64), torch.zeros(1, dtype=torch.float64, device=head.device)])
+        mine = torch.cat([reim, e.to(torch.float64).reshape(1)])       # (re, im, exponent)
         if world > 1 and dist.get_backend(group) == "gloo" and mine.is_cuda:
             mine = mine.cpu()      # gloo moves host memory (CPU tests / several ranks on one GPU as a debugging aid)
     else:
         ev = dev.read_exponent(e) if hasattr(e, "cpu") or not isinstance(e, float) else e
-        mine = torch.tensor([float(np.asarray(m.to_numpy()).reshape(-1)[0]), ev], dtype=torch.float64)
+        m0 = complex(np.asarray(m.to_numpy()).reshape(-1)[0])
+        mine = torch.tensor([m0.real, m0.imag, ev], dtype=torch.float64)
     if world > 1:
         gathered = [torch.empty_like(mine) for _ in range(world)]
         dist.all_gather(gathered, mine, group=group)          # THE collective of the job
-        pairs = torch.stack(gathered).cpu().numpy()
+        trip = torch.stack(gathered).cpu().numpy()
     else:
-        pairs = mine.cpu().numpy().reshape(1, 2)
-    return combine_pairs([(float(a), float(b)) for a, b in pairs], strip_exponent=strip_exponent)
+        trip = mine.cpu().numpy().reshape(1, 3)
+    cplx = np.dtype(m.dtype).kind == "c"
+    return combine_pairs([((complex(a, b) if cplx else float(a)), float(c)) for a, b, c in trip],
+                         strip_exponent=strip_exponent)

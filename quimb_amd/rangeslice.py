@@ -191,11 +191,15 @@ def contract_range_sliced(rse, arrays, strip_exponent=False, group=None):
         m, e = rse(arrays, slices=mine, strip_exponent=True) if mine else (0.0, float("-inf"))
         if world == 1:
             return m, e
-        t = torch.tensor([m, e if np.isfinite(e) else -1e300], dtype=torch.float64, device=cdev)
+        # (re, im, exponent): a complex mantissa travels as two doubles
+        mc = complex(m)
+        t = torch.tensor([mc.real, mc.imag, e if np.isfinite(e) else -1e300], dtype=torch.float64, device=cdev)
         gathered = [torch.empty_like(t) for _ in range(world)]
         dist.all_gather(gathered, t, group=group)
-        pairs = torch.stack(gathered).cpu().numpy()
-        return combine_pairs([(float(a), float(b)) for a, b in pairs if b > -1e299], strip_exponent=True)
+        trip = torch.stack(gathered).cpu().numpy()
+        cplx = np.dtype(rse.dtype).kind == "c"
+        return combine_pairs([((complex(a, b) if cplx else float(a)), float(c)) for a, b, c in trip if c > -1e299],
+                             strip_exponent=True)
     part = np.ascontiguousarray(rse(arrays, slices=mine))
     if world == 1:
         return part

@@ -1678,3 +1678,110 @@ def check_golden_local(rtol=1e-12):
     np.testing.assert_allclose(mk().contract().data.to_numpy(), g["ring_value"], rtol=rtol, atol=rtol)
     op = qa.TensorNetwork([T(qa.asarray(g["trace_P"]), ("a", "x")), T(qa.asarray(g["trace_Q"]), ("x", "b"))])
     assert abs(float(np.asarray(op.trace("a", "b"))) - float(g["trace_value"])) <= 1e-12 * abs(float(g["trace_value"]))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# round 4: the N > 1 WORKLOAD on one device (every rank's share in turn), complex strip_exponent across lanes
+# ---------------------------------------------------------------------------------------------------------------------
+def _profiled_names(dev, fn):
+    """Run ``fn()`` with the device's launch profile on (HIP device only) and return (result, kernel names)."""
+    if not hasattr(dev, "profile"):
+        return fn(), None
+    dev.profile = []
+    try:
+        out = fn()
+        names = [rec[2] for rec in dev.profile]
+    finally:
+        dev.profile = None
+    return out, names
+
+
+def check_sharded_quadrants(Lx, Ly, D, world, dtype, seed, want_log10=None, want_sign=None, rel=None):
+    """What ``bench.py --gpus world`` contracts, every rank's share evaluated in turn on THIS device: rank r runs the
+    quadrant tree on the network range-sliced along its cut-bond ranges (``QuadrantSharding.shard``), the
+    (mantissa, exponent) pairs are summed as the all-gather's consumer does (``combine_pairs``).  The reference's only
+    pin for slicing is exactly this identity -- sum over slices == the whole contraction
+    (tests/test_tensor/test_tensor_core.py:325-330).  ``want_log10`` / ``want_sign``: the fp64 oracle value of the whole
+    network (computed here when omitted).  Returns {rank: kernel names} on the HIP device."""
+    from quimb_amd.quadrants import QuadrantRank, QuadrantSharding, combine_pairs
+
+    arrays, inputs = orc.tn2d_rand(Lx, Ly, D, seed=seed, dtype=dtype)
+    inputs = [tuple(t) for t in inputs]
+    size = {ix: D for t in inputs for ix in t}
+    if want_log10 is None:
+        wm, we = orc.oracle_array_contract([a.astype(np.float64) for a in arrays], inputs, (), strip_exponent=True)
+        want_sign, want_log10 = float(np.sign(wm.item())), math.log10(abs(wm.item())) + we
+    rel = RTOL[np.dtype(dtype)] if rel is None else rel
+    sh = QuadrantSharding(inputs, size, Lx, Ly, world)
+    assert sh.P * sh.Q == world
+    dev = qa.default_device()
+    pairs, names = [], {}
+    for r in range(world):
+        plan = QuadrantRank(sh, r, dtype)
+        local = sh.shard(arrays, r)
+        (m, e), names[r] = _profiled_names(dev, lambda: plan(local))
+        pairs.append((m.to_numpy().item(), float(e)))
+    m, e = combine_pairs(pairs, strip_exponent=True)
+    assert np.sign(m) == want_sign
+    got_log10 = math.log10(abs(m)) + e
+    assert abs(got_log10 - want_log10) < math.log10(1.0 + rel), (world, 10.0 ** (got_log10 - want_log10) - 1.0)
+    # every rank's share is a proper part: no rank's pair alone is the answer
+    if world > 1:
+        assert all(abs(math.log10(abs(pm)) + pe - want_log10) > 1e-3 for pm, pe in pairs if pm != 0)
+    return names
+
+
+def check_range_sliced_found_tree(L, D, dtype, seed, nslices=(2, 3, 6)):
+    """``RangeSlicedExecutor`` on a tree the finders FOUND (recursive bisection): the range slices of the bonds the
+    cost model picks sum to the oracle's value of the whole network, with and without exponent stripping."""
+    from quimb_amd.rangeslice import RangeSliced, RangeSlicedExecutor, find_range_slices
+
+    arrays, inputs = orc.tn2d_rand(L, L, D, seed=seed, dtype=dtype)
+    inputs = [tuple(t) for t in inputs]
+    size = {ix: D for t in inputs for ix in t}
+    want = orc.oracle_array_contract([a.astype(np.float64) for a in arrays], inputs, ()).item()
+    tree = qa.find_path(inputs, (), size, "bisection")
+    rel = RTOL[np.dtype(dtype)]
+    for n in nslices:
+        rs = RangeSliced(tree, find_range_slices(tree, n))
+        assert rs.nslices == n
+        rse = RangeSlicedExecutor(rs, dtype)
+        assert np.asarray(rse(arrays)).item() == pytest.approx(want, rel=rel)
+        m, e = rse(arrays, strip_exponent=True)
+        assert m * 10.0**e == pytest.approx(want, rel=rel)
+        # a subset of the slices is a proper partial sum (what one rank of several holds before the collective)
+        part = np.asarray(rse(arrays, slices=[0])).item() + np.asarray(rse(arrays, slices=range(1, n))).item()
+        assert part == pytest.approx(want, rel=rel)
+
+
+def check_complex_strip_exponent_lanes(dtype, L=6, D=3, seed=5):
+    """complex pair steps under ``strip_exponent`` take the un-fused path (absmax -> scale ->
+    exponent += log10) and the executor runs independent branches on several HIP streams -- the reduction scratch and
+    the accumulator must not be shared unprotected between lanes.  A quadrant tree (four branches) in a complex dtype
+    against the oracle, several times over (a race shows up as run-to-run differences), plus the same through a
+    captured graph."""
+    arrays, inputs = orc.tn2d_rand(L, L, D, seed=seed, dtype="float64")
+    rng = np.random.default_rng(seed)
+    arrays = [(a + 1j * rng.uniform(-0.5, 0.5, size=a.shape)).astype(dtype) for a in arrays]
+    inputs = [tuple(t) for t in inputs]
+    size = {ix: D for t in inputs for ix in t}
+    tree = qa.ContractionTree(inputs, (), size, path=qa.quadrant_path_2d(L, L))
+    ex = qa.TreeExecutor(tree, dtype)
+    assert ex.nlanes >= 4, ex.nlanes
+    wm, we = orc.oracle_array_contract([a.astype(np.complex128) for a in arrays], inputs, (), path=tree.get_path(),
+                                       strip_exponent=True)
+    want = complex(wm.item()) * 10.0**we
+    rel = 10 * RTOL[np.dtype(dtype)]
+    vals = []
+    for _ in range(6):
+        m, e = ex(arrays, strip_exponent=True)
+        vals.append(complex(m.to_numpy().item()) * 10.0**e)
+        assert abs(vals[-1] - want) <= rel * abs(want), (vals[-1], want)
+    assert max(abs(v - vals[0]) for v in vals) <= 1e-6 * abs(want)       # no run-to-run wobble beyond atomics' order
+    dev = qa.default_device()
+    if hasattr(dev, "torch"):
+        g = ex.graph(arrays, strip_exponent=True)
+        for _ in range(3):
+            m, e = g.replay()
+            got = complex(m.to_numpy().item()) * 10.0**e
+            assert abs(got - want) <= rel * abs(want), (got, want)

@@ -331,3 +331,62 @@ def test_sliced_complex_strip_exponent_gloo(tmp_path):
     for r in range(2):
         got = complex(np.load(tmp_path / f"r{r}.npy")[0])
         assert abs(got - want) <= 1e-10 * abs(want), (got, want)
+
+
+def _worker_blocks_complex(rank, world, port, outdir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+
+    import quimb_amd as qa
+    import quimb_amd.device as qd
+    from emu_device import EmuDevice
+    from quimb_amd.quadrants import QuadrantRank, QuadrantSharding, contract_quadrants
+    from quimb_amd.rangeslice import RangeSliced, RangeSlicedExecutor, contract_range_sliced, find_range_slices
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        qd.set_default_device(EmuDevice())
+        arrays, inputs, size = _complex_lattice()
+        quad = qa.ContractionTree(inputs, (), size, path=qa.quadrant_path_2d(4, 4))
+        rse = RangeSlicedExecutor(RangeSliced(quad, find_range_slices(quad, 4)), "complex128")
+        m1, e1 = contract_range_sliced(rse, arrays, strip_exponent=True)
+        v1 = contract_range_sliced(rse, arrays)
+        sh = QuadrantSharding(inputs, size, 4, 4, world)
+        plan = QuadrantRank(sh, rank, "complex128")
+        m2, e2 = contract_quadrants(plan, sh.shard(arrays, rank), strip_exponent=True)
+        v2 = contract_quadrants(plan, sh.shard(arrays, rank))
+        np.save(os.path.join(outdir, f"r{rank}.npy"),
+                np.asarray([m1 * 10.0**e1, np.asarray(v1).item(), m2 * 10.0**e2, v2], dtype=np.complex128))
+    finally:
+        dist.destroy_process_group()
+
+
+def _complex_lattice():
+    from oracle import np_oracle as orc
+
+    arrays, inputs = orc.tn2d_rand(4, 4, 4, seed=21, dtype="float64")
+    rng = np.random.default_rng(21)
+    arrays = [(a + 1j * rng.uniform(-0.5, 0.5, size=a.shape)).astype("complex128") for a in arrays]
+    inputs = [tuple(t) for t in inputs]
+    return arrays, inputs, {ix: 4 for t in inputs for ix in t}
+
+
+def test_range_sliced_and_quadrants_complex_gloo(tmp_path):
+    """the joins of ``contract_range_sliced`` / ``contract_quadrants`` carried the mantissa as
+    ONE float64 -- a complex network raised TypeError in the first and silently lost its imaginary part in the second.
+    Both now gather (re, im, exponent); real and imaginary part of the oracle's value on both ranks."""
+    import torch.multiprocessing as mp
+
+    from oracle import np_oracle as orc
+
+    port = _free_port()
+    mp.spawn(_worker_blocks_complex, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    arrays, inputs, _ = _complex_lattice()
+    want = complex(np.asarray(orc.oracle_array_contract(arrays, inputs, ())).item())
+    assert abs(want.imag) > 1e-6 * abs(want)
+    for r in range(2):
+        for got in np.load(tmp_path / f"r{r}.npy"):
+            assert abs(complex(got) - want) <= 1e-10 * abs(want), (got, want)

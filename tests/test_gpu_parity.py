@@ -545,6 +545,35 @@ def test_found_tree_6x6_D6(hip):
         assert m.to_numpy().item() * 10.0**e == pytest.approx(want, rel=1e-6)
 
 
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_sharded_quadrants_full_size(hip, world):
+    """The N > 1 WORKLOAD of ``bench.py --gpus N`` on the device: every rank's range-sliced share of the 10x10 D=6
+    network (legs of size 3, joins 3888 x 7776 x 7776 ... 1944 x 3888 x 7776) contracted in turn, the pairs summed:
+    the fp64 oracle value of the whole network at north_star's 1e-6.  The joins of every share must run on the k-outer
+    MFMA kernel; the kernels the size-3 legs take are printed (-s)."""
+    import collections
+    import json
+    import os
+
+    ref = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "full_size_oracle.json")))["7"]
+    names = checks.check_sharded_quadrants(10, 10, 6, world, "float32", 7, want_log10=ref["log10_abs"],
+                                           want_sign=ref["sign"], rel=1e-6)
+    for r, ns in names.items():
+        assert sum(n.startswith("gemmk_kernel") for n in ns) == 2, (r, ns)
+    short = collections.Counter(n.split("<")[0] for n in names[world - 1])
+    print(f"world {world}: kernels of the last rank's share:", dict(short))
+
+
+def test_range_sliced_found_tree_6x6_D6(hip):
+    """Range slices of a FOUND tree on the device: 2 / 3 / 6 slices of the 6x6 D=6 network sum to the oracle's value."""
+    checks.check_range_sliced_found_tree(6, 6, "float32", seed=12)
+
+
+@pytest.mark.parametrize("dtype", ["complex64", "complex128"])
+def test_complex_strip_exponent_across_lanes(hip, dtype):
+    checks.check_complex_strip_exponent_lanes(dtype)
+
+
 def test_config4_216_slices_full_size(hip):
     """BASELINE config #4 at full size on ONE device: the 10x10 D=6 sweep tree with 216 slices (three bonds; 256 is
     not reachable with all-6 bonds), every slice executed, summed on a common exponent: the fp64 oracle value at

@@ -431,3 +431,14 @@ def test_two_sided_small_shapes(emu, Lx, Ly, D, k):
 def test_dmrg_local_update_small_chi(emu):
     """The chi = 512 local-update check of the GPU suite, at chi = 24 on the plan interpreter."""
     checks.check_dmrg_local_update_full_chi(24, "float64", nmv=6)
+
+
+def test_round4_sharded_workload_checks_on_the_interpreter(emu):
+    """The round-4 device checks at sizes the interpreter finishes: every rank's share of a sharded quadrant tree summed,
+    range slices of a found tree, a complex quadrant tree under strip_exponent (lanes are a HIP-device feature; the
+    plan still has them)."""
+    for world in (2, 4, 8):
+        checks.check_sharded_quadrants(4, 6, 2, world, "float64", 7)
+    checks.check_sharded_quadrants(4, 4, 6, 6, "float64", 3)
+    checks.check_range_sliced_found_tree(4, 4, "float64", seed=12, nslices=(2, 4))
+    checks.check_complex_strip_exponent_lanes("complex128", L=6, D=2)
