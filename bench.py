@@ -161,6 +161,58 @@ def _full_network_record(seed):
                                  "container (tests/golden/make_full_size_oracle.py, recorded with the golden value)"}
 
 
+def _launch_work(spec):
+    """(shape, algorithmic bytes, flops) of ONE launch from its plan record: every operand read once, the result written
+    once, no credit for permutes; fp32."""
+    if hasattr(spec, "off_k1") and hasattr(spec, "K1"):  # fused pair of steps (Chain2Spec)
+        shape = {"fused_steps": 2, "M": spec.M, "D": spec.D, "K": spec.K1, "N": spec.NO * spec.D}
+        return shape, 4 * (spec.a_size + spec.c_size + spec.K1 * spec.D**2 + spec.D**3 * spec.NO), 2 * spec.mults
+    if hasattr(spec, "off_k1"):  # fused triple of steps (Chain3Spec)
+        shape = {"fused_steps": 3, "M": spec.a_size // spec.D**4, "D": spec.D, "K": spec.D**2, "N": spec.D**2}
+        return shape, 4 * (spec.a_size + spec.c_size + 3 * spec.D**4), 2 * spec.mults
+    shape = {"B": spec.B, "M": spec.M, "N": spec.N, "K": spec.K}
+    return (shape, 4 * spec.B * (spec.M * spec.K + spec.K * spec.N + spec.M * spec.N),
+            2 * spec.B * spec.M * spec.N * spec.K)
+
+
+TINY_BYTES = 4 << 20     # a launch moving less than this is latency, not bandwidth (~12 us on the device)
+
+
+def roofline_classes(prof_all, step_ms):
+    """Per step CLASS of one contraction (one launch-by-launch pass, an HIP event pair around every pairwise launch):
+    kernel instantiation, launches, summed device time, and what it reaches of the roof that bounds it --
+    min(MFMA peak, arithmetic intensity x HBM peak).  Launches below ``TINY_BYTES`` of algorithmic traffic are one class
+    of their own (latency-bound; their event-bracketed times include ~5 us of dispatch each).  Branches of the tree run
+    on parallel HIP streams, so the classes' times may add up to more than the step."""
+    cls = {}
+    for spec, _, name, _, e0, e1 in prof_all:
+        _, nbytes, nflops = _launch_work(spec)
+        key = "tiny launches (< 4 MiB of operands + result each)" if nbytes < TINY_BYTES else name
+        c = cls.setdefault(key, {"kernel": key, "launches_per_step": 0, "ms_per_step": 0.0, "_b": 0.0, "_f": 0.0, "_names": set()})
+        c["launches_per_step"] += 1
+        c["ms_per_step"] += e0.elapsed_time(e1)
+        c["_b"] += nbytes
+        c["_f"] += nflops
+        c["_names"].add(name.split("<")[0])
+    balance = MFMA_F32_PEAK_TF * 1e12 / (HBM_PEAK_GBS * 1e9)
+    out = []
+    for c in sorted(cls.values(), key=lambda c: -c["ms_per_step"]):
+        t = c["ms_per_step"] * 1e-3
+        b, f = c.pop("_b"), c.pop("_f")
+        names = sorted(c.pop("_names"))
+        if c["kernel"].startswith("tiny"):
+            c.update(bound="latency", achieved=None, peak=None, unit=None, frac=None, kernels=names,
+                     us_per_launch=1e3 * c["ms_per_step"] / c["launches_per_step"])
+        elif f / b < balance:
+            c.update(bound="hbm", achieved=b / t / 1e9, peak=HBM_PEAK_GBS, unit="GB/s", frac=b / t / 1e9 / HBM_PEAK_GBS)
+        else:
+            c.update(bound="mfma", achieved=f / t / 1e12, peak=MFMA_F32_PEAK_TF, unit="TFLOP/s", frac=f / t / 1e12 / MFMA_F32_PEAK_TF)
+        c["arithmetic_intensity_flop_per_byte"] = f / b
+        c["share_of_step_time"] = c["ms_per_step"] / step_ms
+        out.append(c)
+    return out
+
+
 def _time_steps(fn, n, sync):
     sync()
     t0 = time.perf_counter()
@@ -354,6 +406,21 @@ def main():
         fence()
         prof, dev.profile = dev.profile, None
         del os.environ["QAMD_SLICE_GRAPH"]
+    # one more UNTIMED launch-by-launch pass with an event pair around EVERY pairwise launch: the per-class roofline
+    # table (``roofline.achieved`` per step class).  Kept out of the timed region because an event pair costs
+    # each of the ~60 tiny first-row launches ~10 us of queue time.
+    prof_all = None
+    if rank == 0 and mode in ("single", "quadrants"):
+        os.environ["QAMD_SLICE_GRAPH"] = "0"
+        dev.profile_min_mults = 0
+        dev.profile = []
+        if mode == "quadrants":
+            qrank.executor(xs, strip_exponent=True)
+        else:
+            ex(xs, strip_exponent=True)
+        torch.cuda.synchronize()
+        prof_all, dev.profile = dev.profile, None
+        del os.environ["QAMD_SLICE_GRAPH"]
     scaling_report = None
     if mode == "quadrants":
         # what the ranks executed and how evenly: every rank's own time for its share without the collective
@@ -405,18 +472,7 @@ def main():
         # ---- dominant kernel from HIP-event timings over the timed region ------
         agg = {}
         for spec, dt_, name, sk, e0, e1 in prof:
-            if hasattr(spec, "off_k1") and hasattr(spec, "K1"):  # fused pair of steps (Chain2Spec)
-                shape = {"fused_steps": 2, "M": spec.M, "D": spec.D, "K": spec.K1, "N": spec.NO * spec.D}
-                nbytes = 4 * (spec.a_size + spec.c_size + spec.K1 * spec.D**2 + spec.D**3 * spec.NO)
-                nflops = 2 * spec.mults
-            elif hasattr(spec, "off_k1"):  # fused triple of steps (Chain3Spec)
-                shape = {"fused_steps": 3, "M": spec.a_size // spec.D**4, "D": spec.D, "K": spec.D**2, "N": spec.D**2}
-                nbytes = 4 * (spec.a_size + spec.c_size + 3 * spec.D**4)
-                nflops = 2 * spec.mults
-            else:
-                shape = {"B": spec.B, "M": spec.M, "N": spec.N, "K": spec.K}
-                nbytes = 4 * spec.B * (spec.M * spec.K + spec.K * spec.N + spec.M * spec.N)
-                nflops = 2 * spec.B * spec.M * spec.N * spec.K
+            shape, nbytes, nflops = _launch_work(spec)
             key = (name, tuple(sorted(shape.items())))
             a = agg.setdefault(key, [0.0, 0, shape, nbytes, nflops])
             a[0] += e0.elapsed_time(e1) * 1e-3
@@ -462,6 +518,10 @@ def main():
             roof["share_of_step_time"] = tsum / (dt / args.steps * (1 if graphed else args.steps))
             roof["algorithmic_bytes_per_launch"] = bytes_launch
             roof["flops_per_launch"] = flops_launch
+        if roof is not None and prof_all:
+            roof["classes"] = roofline_classes(prof_all, ms)
+            roof["classes_timed_in"] = ("one untimed launch-by-launch pass after the timed region, an HIP event pair around every "
+                                        "pairwise launch; branches overlap on parallel streams, so shares can exceed 1 in total")
         # ---- N = 1 extras (after the timed region): other BASELINE configs, what one rank of N = 2 / 4 / 8 costs -------
         secondary = projection = None
         if mode == "single" and not args.no_secondary and (args.Lx, args.Ly) == (10, 10):
@@ -541,6 +601,10 @@ def main():
                 "contractions_in_flight": args.inflight if pipelined else 1,
             },
             "pct_mfma_peak": 100.0 * value / (MFMA_F32_PEAK_TF * world),
+            # the same time priced by the CHEAPEST known tree's work: what an extra-FLOP tree cannot inflate
+            "value_useful_tflops": 2 * min(sweep_tree.contraction_cost(), quad_tree.contraction_cost()) / (dt / args.steps) / 1e12,
+            "pct_mfma_peak_useful": 100.0 * 2 * min(sweep_tree.contraction_cost(), quad_tree.contraction_cost())
+                                    / (dt / args.steps) / 1e12 / (MFMA_F32_PEAK_TF * world),
             "result": _result_with_parity(res, args) if not emulate else
                       {"mantissa": res[0], "exponent_log10": res[1], "note": "ONE rank's block z_ij of the sum, not the network's value"},
             "roofline": roof,

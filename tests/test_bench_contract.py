@@ -69,6 +69,9 @@ def test_bench_line_contract(emu, monkeypatch, argv, tree):
     assert d["metric"] == "contracted-FLOP/s on PEPS amplitude" and d["unit"] == "TFLOP/s" and d["n_gpus"] == 1
     assert d["dtype"] == "f32" and d["data"] == "synthetic" and d["higher_is_better"] is True and d["vs_baseline"] is None
     assert d["value"] > 0 and d["ms_per_step"] > 0 and "workload" in d["config"]
+    # the same time priced by the cheapest known tree's work: never above the headline value
+    assert 0 < d["value_useful_tflops"] <= d["value"] * (1 + 1e-12) or "slices" in d["config"]["workload"]
+    assert d["pct_mfma_peak_useful"] == pytest.approx(100.0 * d["value_useful_tflops"] / 157.3)
     assert d["config"]["best_known_tree_mults"] <= d["config"]["tree_mults"] or "slices" in d["config"]["workload"]
     if tree:
         assert d["config"]["tree"] == tree
@@ -142,3 +145,36 @@ def test_bench_multi_rank_line(tmp_path, world):
     arrays, inputs = orc.tn2d_rand(4, 4, 4, seed=7, dtype="float64")
     want = orc.oracle_array_contract(arrays, inputs, ()).item()
     assert d["result"]["mantissa"] * 10.0 ** d["result"]["exponent_log10"] == pytest.approx(want, rel=1e-4)
+
+
+def test_roofline_classes_table():
+    """``roofline.classes`` (achieved per step class): launches grouped by kernel instantiation, tiny launches
+    lumped as latency-bound, each class priced against min(MFMA peak, AI x HBM peak)."""
+    sys.path.insert(0, ROOT)
+    import bench
+    from quimb_amd.pairwise import GettSpec
+
+    class Ev:
+        def __init__(self, t):
+            self.t = t
+
+        def elapsed_time(self, other):
+            return other.t - self.t
+
+    def gett(M, N, K):
+        return GettSpec(b=(), m=((M, K, 0, N),), n=((N, 0, 1, 1),), k=((K, 1, N, 0),))
+
+    join, stream, tiny = gett(7776, 7776, 7776), gett(6**9, 36, 36), gett(216, 36, 36)
+    prof = [(join, None, "gemmk_kernel<3, 4, 3, 1>", 1, Ev(0.0), Ev(7.0)),
+            (join, None, "gemmk_kernel<3, 4, 3, 1>", 1, Ev(7.0), Ev(14.0)),
+            (stream, None, "sweep_kernel<float>", 1, Ev(0.0), Ev(0.6)),
+            (tiny, None, "gett_kernel<float,4,1,4>", 1, Ev(0.0), Ev(0.01)),
+            (tiny, None, "stream_kernel<float,2>", 1, Ev(0.0), Ev(0.02))]
+    cls = bench.roofline_classes(prof, 16.0)
+    assert [c["kernel"].split("<")[0] for c in cls] == ["gemmk_kernel", "sweep_kernel", "tiny launches ("]
+    g, sw, t = cls
+    assert g["launches_per_step"] == 2 and g["bound"] == "mfma" and g["ms_per_step"] == pytest.approx(14.0)
+    assert g["achieved"] == pytest.approx(2 * 7776**3 / 7e-3 / 1e12) and g["frac"] == pytest.approx(g["achieved"] / 157.3)
+    assert sw["bound"] == "hbm" and sw["achieved"] == pytest.approx(4 * (6**9 * 72 + 36 * 36) / 0.6e-3 / 1e9)
+    assert t["bound"] == "latency" and t["launches_per_step"] == 2 and t["kernels"] == ["gett_kernel", "stream_kernel"]
+    assert sum(c["share_of_step_time"] for c in cls) == pytest.approx((14.0 + 0.6 + 0.03) / 16.0)
