@@ -100,6 +100,20 @@ def _pair_contract(ops, tis, keep):
     return _einsum_inds(ops, tis, keep), tuple(keep)
 
 
+def _refuse_if_huge(ops, tis, keep):
+    import os
+
+    dims = {ix: d for t, a in zip(tis, ops) for ix, d in zip(t, np.shape(a))}
+    n = 1
+    for ix in keep:
+        n *= dims[ix]
+    nbytes = n * max(np.asarray(a).dtype.itemsize for a in ops)
+    limit = int(os.environ.get("QAMD_ORACLE_MAX_BYTES", MAX_INTERMEDIATE_BYTES))
+    if nbytes > limit:
+        raise MemoryError(f"oracle: this path builds an intermediate of {nbytes / 2**30:.1f} GiB (> {limit / 2**30:.1f} GiB); "
+                          f"pass an explicit path (e.g. a lattice sweep) or raise QAMD_ORACLE_MAX_BYTES")
+
+
 def oracle_contract_core(arrays, inputs, output, path, strip_exponent=False):
     """Pairwise evaluation along a linear (opt_einsum style) path."""
     arrays = list(arrays)
@@ -113,6 +127,7 @@ def oracle_contract_core(arrays, inputs, output, path, strip_exponent=False):
             keep = _pair_result_inds(tis[0], (), inputs, output)
         else:
             keep = _pair_result_inds(tis[0], tis[1], inputs, output)
+        _refuse_if_huge(ops, tis, keep)
         x, keep = _pair_contract(ops, tis, keep)
         if strip_exponent:
             f = np.max(np.abs(x))
@@ -133,6 +148,47 @@ def naive_path(n):
     return [(0, 1)] * (n - 1)
 
 
+#: a single intermediate larger than this many bytes is refused (MemoryError) instead of attempted: a path that builds a
+#: 6^14-element tensor on the way to a scalar is a mistake of the caller, and on a memory-limited box the attempt takes
+#: the whole container down with it (round 3 / 4: an un-pathed 6x6 D=6 call -- 627 GB -- lost four GPU boxes).  The
+#: full-size 10x10 D=6 sweep needs 6^11 doubles = 2.9 GB; override with QAMD_ORACLE_MAX_BYTES.
+MAX_INTERMEDIATE_BYTES = 8 << 30
+
+
+def small_first_path(inputs, output, size_dict):
+    """Default path when the caller names none: repeatedly contract the pair of tensors SHARING an index whose
+    result is smallest (ties: first in list order), outer products only once nothing shares an index -- a greedy
+    "smallest intermediate first" order in opt_einsum's linear format.  The value of a network does not depend on the
+    path (a sum of products), so any order is the reference's arithmetic; this one keeps un-pathed test calls cheap."""
+    live = [tuple(t) for t in inputs]
+    out = set(output)
+    path = []
+    vol = lambda t: math.prod(size_dict[ix] for ix in t)
+    while len(live) > 1:
+        holders = {}
+        for pos, t in enumerate(live):
+            for ix in set(t):
+                holders.setdefault(ix, []).append(pos)
+        pairs = {(i, j) for hs in holders.values() for a, i in enumerate(hs) for j in hs[a + 1:]}
+        if not pairs:                                   # disconnected pieces: outer product of the two smallest
+            i, j = sorted(sorted(range(len(live)), key=lambda q: (vol(live[q]), q))[:2])
+            pairs = {(i, j)}
+        best = None
+        for i, j in sorted(pairs):
+            shared = set(live[i]) & set(live[j])
+            keep = tuple(ix for ix in dict.fromkeys(live[i] + live[j])
+                         if ix in out or len(holders[ix]) > (2 if ix in shared else 1))
+            key = (vol(keep), i, j)
+            if best is None or key < best[0]:
+                best = (key, i, j, keep)
+        _, i, j, keep = best
+        path.append((i, j))
+        live.pop(j)
+        live.pop(i)
+        live.append(keep)
+    return path
+
+
 def oracle_array_contract(arrays, inputs, output=None, path=None, strip_exponent=False, sliced_inds=(),
                           size_dict=None, dtype=None):
     """The reference arithmetic: numpy pairwise contraction in path order,
@@ -142,7 +198,8 @@ def oracle_array_contract(arrays, inputs, output=None, path=None, strip_exponent
     if output is None:
         output = gen_output_inds(ix for t in inputs for ix in t)
     if path is None:
-        path = naive_path(len(arrays))
+        sd = {ix: d for t, a in zip(inputs, arrays) for ix, d in zip(t, np.shape(a))}
+        path = small_first_path([tuple(ix for ix in t if ix not in sliced_inds) for t in inputs], output, sd)
     if not sliced_inds:
         return oracle_contract_core(arrays, inputs, output, path, strip_exponent)
     if size_dict is None:

@@ -1577,6 +1577,25 @@ def check_dmrg_local_update_full_chi(chi=512, dtype="float64", nmv=8):
     trunc = np.linalg.norm(v.reshape(chi * d, d * chi) - (Uk * s_dev[:chi]) @ Vk)
     assert abs(trunc - np.sqrt(np.sum(s_ref[chi:] ** 2))) <= 100 * tol
     assert np.max(np.abs(Uk.T @ Uk - np.eye(chi))) < 1e3 * tol
+    # (b2) the same split through the Gram route (split="eig", reference svd_via_eig, quimb/tensor/decomp.py:1168): the
+    # two-site tensor of a Lanczos vector is numerically rank-deficient at chi = 512 (round 3 met rank 1023 of 1024 and a
+    # caller that assumed min(m, n) columns); the route may drop directions under the Gram matrix's noise floor, never one
+    # of the chi the step keeps, and what it keeps is isometric and reproduces the truncation error
+    from quimb_amd.split import array_split
+
+    U2, S2, Vh2 = qa.linalg.svd_via_eig(x)
+    k2 = S2.shape[0]
+    assert chi <= k2 <= chi * d and U2.shape == (chi * d, k2) and Vh2.shape == (k2, d * chi), (k2, U2.shape, Vh2.shape)
+    s2 = S2.to_numpy().astype(np.float64)
+    np.testing.assert_allclose(s2[:chi], s_ref[:chi], rtol=0, atol=(1e-8 if np.dtype(dtype) == np.float64 else 3e-3) * s_ref[0])
+    U2k = U2.to_numpy().astype(np.float64)[:, :chi]
+    V2k = Vh2.to_numpy().astype(np.float64)[:chi]
+    assert np.max(np.abs(U2k.T @ U2k - np.eye(chi))) < 1e3 * tol
+    trunc2 = np.linalg.norm(v.reshape(chi * d, d * chi) - (U2k * s2[:chi]) @ V2k)
+    assert abs(trunc2 - np.sqrt(np.sum(s_ref[chi:] ** 2))) <= 100 * tol
+    # ... and through the caller DMRG2(split="eig") uses: max_bond = chi, the new bond has exactly chi values
+    left_, s_, right_ = array_split(x, method="eig", absorb=None, max_bond=chi, cutoff=0.0)
+    assert left_.shape == (chi * d, chi) and s_.shape == (chi,) and right_.shape == (chi, d * chi)
     # (c) environment update with the new left-canonical site tensor
     Asite = np.ascontiguousarray(Uk.reshape(chi, d, chi)).astype(dtype)
     inputs = [("a", "w", "b"), ("a", "s", "A"), ("w", "W", "s", "t"), ("b", "t", "B")]
@@ -1709,7 +1728,8 @@ def check_sharded_quadrants(Lx, Ly, D, world, dtype, seed, want_log10=None, want
     inputs = [tuple(t) for t in inputs]
     size = {ix: D for t in inputs for ix in t}
     if want_log10 is None:
-        wm, we = orc.oracle_array_contract([a.astype(np.float64) for a in arrays], inputs, (), strip_exponent=True)
+        wm, we = orc.oracle_array_contract([a.astype(np.float64) for a in arrays], inputs, (), strip_exponent=True,
+                                           path=qa.sweep_path_2d(Lx, Ly))
         want_sign, want_log10 = float(np.sign(wm.item())), math.log10(abs(wm.item())) + we
     rel = RTOL[np.dtype(dtype)] if rel is None else rel
     sh = QuadrantSharding(inputs, size, Lx, Ly, world)
@@ -1739,7 +1759,7 @@ def check_range_sliced_found_tree(L, D, dtype, seed, nslices=(2, 3, 6)):
     arrays, inputs = orc.tn2d_rand(L, L, D, seed=seed, dtype=dtype)
     inputs = [tuple(t) for t in inputs]
     size = {ix: D for t in inputs for ix in t}
-    want = orc.oracle_array_contract([a.astype(np.float64) for a in arrays], inputs, ()).item()
+    want = orc.oracle_array_contract([a.astype(np.float64) for a in arrays], inputs, (), path=qa.sweep_path_2d(L, L)).item()
     tree = qa.find_path(inputs, (), size, "bisection")
     rel = RTOL[np.dtype(dtype)]
     for n in nslices:

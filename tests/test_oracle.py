@@ -87,3 +87,28 @@ def test_bench_generator_matches_oracle_generator():
         # same network structure (index names may differ): same sharing pattern
         rel = lambda ins: [[[j for j, u in enumerate(ins) if ix in u] for ix in t] for t in ins]
         assert rel(i1) == rel([tuple(t) for t in i2])
+
+
+def test_oracle_default_path_is_bounded_and_huge_paths_are_refused():
+    """Rounds 3 and 4 lost GPU boxes (container OOM-kill) to an oracle call WITHOUT a path on a 6x6 D=6 lattice: the old
+    default order built a 6^14-element intermediate (627 GB).  The default is now a smallest-intermediate-first order,
+    and any path -- the caller's too -- that would materialise more than ``MAX_INTERMEDIATE_BYTES`` raises instead."""
+    import quimb_amd as qa
+    from oracle import np_oracle as orc
+
+    arrays, inputs = orc.tn2d_rand(6, 6, 6, seed=12, dtype="float64")
+    inputs = [tuple(t) for t in inputs]
+    size = {ix: 6 for t in inputs for ix in t}
+    path = orc.small_first_path(inputs, (), size)
+    tree = qa.ContractionTree(inputs, (), size, path=path)
+    assert 2 ** tree.contraction_width() * 8 < 64 << 20               # < 64 MB where the old default needed 627 GB
+    want = orc.oracle_array_contract(arrays, inputs, (), path=qa.sweep_path_2d(6, 6)).item()
+    assert orc.oracle_array_contract(arrays, inputs, ()).item() == pytest.approx(want, rel=1e-12)
+    with pytest.raises(MemoryError, match="intermediate"):
+        orc.oracle_array_contract(arrays, inputs, (), path=orc.naive_path(36))
+    # open and hyper indices, disconnected pieces: same values as one whole-network einsum
+    rng = np.random.default_rng(0)
+    xs = [rng.normal(size=s) for s in ((3, 4), (4, 5, 3), (5, 2), (2,), (6,))]
+    ins = [("a", "b"), ("b", "c", "a"), ("c", "d"), ("d",), ("z",)]
+    np.testing.assert_allclose(orc.oracle_array_contract(xs, ins, ("z",)),
+                               np.einsum("ab,bca,cd,d,z->z", *xs), rtol=1e-12)
