@@ -19,6 +19,40 @@ def pytest_configure(config):
         subprocess.run(["make", "-s", "-j4", "-C", os.path.join(ROOT, "quimb_amd", "csrc")], check=False)
 
 
+def pytest_sessionstart(session):
+    """Host-memory watchdog.  A GPU box is a container with a memory limit (300 GiB on the round-4 pool): a checker
+    that runs away on the host -- rounds 3 / 4: an oracle call on a path with a 627 GB intermediate -- gets the whole
+    container OOM-killed, which the harness can only report as "the GPU box was lost".  A daemon thread samples this
+    process's resident set and ends the run with a message and exit code 99 long before that
+    (``QAMD_TEST_MAX_RSS_GB``, default 64; 0 disables)."""
+    import threading
+    import time
+
+    limit_gb = float(os.environ.get("QAMD_TEST_MAX_RSS_GB", "64"))
+    if limit_gb <= 0:
+        return
+    try:
+        import psutil
+    except ImportError:
+        return
+    proc = psutil.Process()
+
+    def watch():
+        while True:
+            try:
+                rss = proc.memory_info().rss
+            except Exception:
+                return
+            if rss > limit_gb * 2**30:
+                sys.stderr.write(f"\n[conftest] host memory watchdog: resident set {rss / 2**30:.1f} GiB > "
+                                 f"{limit_gb:.0f} GiB -- aborting the test run (QAMD_TEST_MAX_RSS_GB)\n")
+                sys.stderr.flush()
+                os._exit(99)
+            time.sleep(0.2)
+
+    threading.Thread(target=watch, name="qamd-rss-watchdog", daemon=True).start()
+
+
 def pytest_collection_modifyitems(config, items):
     """No test of this suite may hang a run: with pytest-timeout present (it is in this image) every test gets a
     15-minute ceiling unless the command line set its own -- a GPU test stuck in a device call ends the run with a
