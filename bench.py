@@ -182,8 +182,9 @@ def roofline_classes(prof_all, step_ms):
     """Per step CLASS of one contraction (one launch-by-launch pass, an HIP event pair around every pairwise launch):
     kernel instantiation, launches, summed device time, and what it reaches of the roof that bounds it --
     min(MFMA peak, arithmetic intensity x HBM peak).  Launches below ``TINY_BYTES`` of algorithmic traffic are one class
-    of their own (latency-bound; their event-bracketed times include ~5 us of dispatch each).  Branches of the tree run
-    on parallel HIP streams, so the classes' times may add up to more than the step."""
+    of their own (latency-bound; their event-bracketed times include ~5 us of dispatch each).  The pass runs on ONE
+    stream, every launch with the chip to itself: the times add up to the SERIAL step, which the timed region (branches
+    on parallel HIP streams) undercuts."""
     cls = {}
     for spec, _, name, _, e0, e1 in prof_all:
         _, nbytes, nflops = _launch_work(spec)
@@ -411,16 +412,22 @@ def main():
     # each of the ~60 tiny first-row launches ~10 us of queue time.
     prof_all = None
     if rank == 0 and mode in ("single", "quadrants"):
+        # ... and on ONE stream (QAMD_LANES=0): with the four corner sweeps overlapping, an event pair brackets a launch's
+        # share of a contended machine, not the kernel -- the table prices every class with the chip to itself
         os.environ["QAMD_SLICE_GRAPH"] = "0"
+        os.environ["QAMD_LANES"] = "0"
         dev.profile_min_mults = 0
         dev.profile = []
-        if mode == "quadrants":
-            qrank.executor(xs, strip_exponent=True)
-        else:
-            ex(xs, strip_exponent=True)
-        torch.cuda.synchronize()
-        prof_all, dev.profile = dev.profile, None
-        del os.environ["QAMD_SLICE_GRAPH"]
+        try:
+            if mode == "quadrants":
+                qrank.executor(xs, strip_exponent=True)
+            else:
+                ex(xs, strip_exponent=True)
+            torch.cuda.synchronize()
+        finally:
+            prof_all, dev.profile = dev.profile, None
+            del os.environ["QAMD_SLICE_GRAPH"]
+            del os.environ["QAMD_LANES"]
     scaling_report = None
     if mode == "quadrants":
         # what the ranks executed and how evenly: every rank's own time for its share without the collective
@@ -520,8 +527,9 @@ def main():
             roof["flops_per_launch"] = flops_launch
         if roof is not None and prof_all:
             roof["classes"] = roofline_classes(prof_all, ms)
-            roof["classes_timed_in"] = ("one untimed launch-by-launch pass after the timed region, an HIP event pair around every "
-                                        "pairwise launch; branches overlap on parallel streams, so shares can exceed 1 in total")
+            roof["classes_timed_in"] = ("one untimed launch-by-launch pass after the timed region on ONE stream (every launch with "
+                                        "the chip to itself), an HIP event pair around every pairwise launch; the timed region "
+                                        "overlaps the branches on parallel streams, so the shares can add up to more than 1")
         # ---- N = 1 extras (after the timed region): other BASELINE configs, what one rank of N = 2 / 4 / 8 costs -------
         secondary = projection = None
         if mode == "single" and not args.no_secondary and (args.Lx, args.Ly) == (10, 10):
