@@ -244,6 +244,11 @@ def main():
     ap.add_argument("--inflight", type=int, default=1, help="independent contractions in flight (alternating HIP streams); 1 = one at a time")
     ap.add_argument("--graph", action="store_true", help="N > 1: one hipGraph replay per step instead of launch by launch (measured: no faster -- "
                     "the host enqueues a share in 1.6 ms, the device needs 3.4 -- and the runtime maps the parallel branches of a graph onto fewer queues)")
+    ap.add_argument("--launch", choices=["auto", "python", "program"], default="auto",
+                    help="how a step is issued: launch by launch from Python, or as a recorded launch program replayed by one "
+                         "C call (quimb_amd/program.py).  auto: program for N > 1 (every step ends in a collective, so the "
+                         "host's enqueue time is on each step's critical path: 0.33 ms instead of 1.6 ms), Python for N = 1 "
+                         "(steps are enqueued back to back and the device never waits for the host; measured equal)")
     ap.add_argument("--emulate-world", type=int, default=0,
                     help="one GPU times ONE rank's share (the busiest) of a job over this many ranks -- no collective")
     args = ap.parse_args()
@@ -314,6 +319,8 @@ def main():
         xs = sharding.shard(xs, r_)
         if args.graph:
             qrank.capture(xs)
+        elif args.launch == "program" or (args.launch == "auto" and world > 1):
+            qrank.program(xs, mark_min_mults=10**9)
         tree, tree_name = quad_tree, "four quadrants + two joins"
     elif args.tree == "auto":
         # both trees, untimed: two warm-up contractions, then the best of three
@@ -329,14 +336,24 @@ def main():
         tree_name = min(tree_probe, key=lambda k: tree_probe[k]["ms"])
         tree = quad_tree if tree_name.startswith("four") else sweep_tree
     ex = qa.TreeExecutor(tree, dtype) if mode in ("single", "sliced") else (qrank.executor if qrank else None)
+    single_prog = None
+    if mode == "single" and args.launch == "program":
+        single_prog = ex.program(xs, strip_exponent=True, mark_min_mults=10**9)
+    prog_obj = single_prog or (getattr(qrank, "_program", None) if qrank else None)
+    step_no = [0]       # timing slot of a program step inside the timed region
     my = list(rank_slices(tree.nslices, rank, world)) if mode == "sliced" else None
 
     rank_stats = {}
+    timing_on = [False]
 
     def step():
         if mode == "two_sided":
             return contract_two_sided(plan, xs, strip_exponent=True, stats=rank_stats)
         if mode == "quadrants":
+            if getattr(qrank, "_program", None) is not None and timing_on[0] and rank == 0:
+                # the marked launches (>= 1e9 multiplications) write their durations into this step's slot
+                qrank._program._timing_slot = step_no[0]
+                step_no[0] += 1
             if emulate:
                 return qrank(xs, defer=True)                     # one rank's share, no collective
             return contract_quadrants(qrank, xs, strip_exponent=True)     # ... + the one all-gather
@@ -350,6 +367,10 @@ def main():
             return m.item(), e
         # unsliced: nothing is read back inside the step -- the (mantissa, exponent) pair stays on the device until the
         # timed region's closing synchronize (steps are enqueued back to back, as a training loop's would be)
+        if single_prog is not None:
+            slot = step_no[0] if timing_on[0] else None
+            step_no[0] += 1
+            return single_prog(defer_exponent=True, timing_slot=slot)
         return ex(xs, strip_exponent=True, defer_exponent=True)
 
     def materialize(r):
@@ -388,6 +409,14 @@ def main():
     if rank == 0 and not graphed:
         dev.profile_min_mults = 10**9
         dev.profile = []
+    if prog_obj is not None:
+        # a program carries its own timing events (one slot per step of the timed region; rank 0 reads them); one
+        # untimed pass creates them -- on EVERY rank, the steps of a multi-GPU job contain a collective
+        timing_on[0] = rank == 0
+        for _ in range(args.steps):
+            step()
+        fence()
+        step_no[0] = 0
     t0 = time.perf_counter()
     for _ in range(args.steps):
         res = step()
@@ -395,6 +424,10 @@ def main():
     dt = time.perf_counter() - t0
     res = materialize(res)
     prof, dev.profile = dev.profile, None
+    if prog_obj is not None and rank == 0:
+        timing_on[0] = False
+        prog_obj._timing_slot = None
+        prof = [rec for k in range(args.steps) for rec in prog_obj.timings(k)]
     if graphed:
         os.environ["QAMD_SLICE_GRAPH"] = "0"
         if rank == 0:
@@ -607,6 +640,8 @@ def main():
                 "contraction_width_log2": tree.contraction_width(),
                 "parallelism": par,
                 "contractions_in_flight": args.inflight if pipelined else 1,
+                "launch": ("launch program: one C call replays the step's recorded launches (quimb_amd/program.py)"
+                           if prog_obj is not None else "launch by launch from Python"),
             },
             "pct_mfma_peak": 100.0 * value / (MFMA_F32_PEAK_TF * world),
             # the same time priced by the CHEAPEST known tree's work: what an extra-FLOP tree cannot inflate

@@ -208,6 +208,9 @@ int qamd_contract_chain3(const qamd_chain3_plan* plan, const void* A, const void
  * tensors whose max is 0 are skipped.
  */
 int qamd_absmax_log10_sum(const void* slots, int64_t n_tensors, int32_t dtype, void* out_dev, void* stream);
+/* the same sum ADDED (atomically) to *acc_dev: the exponent accumulator of a contraction, which independent branches on
+ * other streams also add their un-fused strips to */
+int qamd_absmax_log10_sum_add(const void* slots, int64_t n_tensors, int32_t dtype, void* acc_dev, void* stream);
 /* x[i] /= max(slots[0..QAMD_ABSMAX_SLOTS))  (no-op if that max is 0) */
 int qamd_div_by_absmax(void* x, int64_t n, const void* slots, int32_t dtype, void* stream);
 
@@ -297,6 +300,49 @@ typedef struct {
 int qamd_microtree_run(int32_t dtype, const qamd_micro_step* steps_dev, int32_t nsteps, const int32_t* etab_dev,
                        const int32_t* ktab_dev, const void* const* inputs_dev, int32_t ninputs, void* arena_dev,
                        int64_t arena_elems, void* out_dev, int64_t out_elems, int32_t ninst, void* stream);
+
+/*
+ * Launch programs: the launch sequence of ONE contraction recorded once and replayed with one host call -- the
+ * replacement for the per-step Python loop of the reference's executor (ctg.array_contract under
+ * quimb/tensor/contraction.py:285; quimb caches the planned expression and re-runs that loop on every call,
+ * tests/test_tensor/test_contract.py:155-172).
+ *
+ *   P = qamd_program_create(nlanes);  qamd_program_record_begin(P);
+ *   ... the ordinary qamd_* calls of one contraction, on this thread: each is APPENDED to P instead of launched (its
+ *       stream argument is ignored); qamd_program_set_lane(P, l) routes what follows to lane l, qamd_program_wait(P, l, m)
+ *       makes lane l wait for everything recorded on lane m so far; qamd_program_mark(P, tag) brackets the NEXT
+ *       recorded launch with timing events ...
+ *   qamd_program_record_end(P);
+ *   qamd_program_bind_inputs(P, n, ptrs, nbytes);      (device pointers inside [ptrs[i], ptrs[i] + nbytes[i]) are
+ *                                                        re-based onto input_ptrs[i] at every run)
+ *   qamd_program_run(P, lane_streams, input_ptrs, timing);   (lane 0 = the caller's stream: forked from / joined to)
+ *
+ * Recorded are: qamd_contract_pair(_ex), qamd_contract_chain2 / chain3, qamd_permute, qamd_reduce_sum, qamd_binary,
+ * qamd_scale, qamd_axpby(_exp), qamd_conj, qamd_cast, qamd_fill, qamd_complex_expand, qamd_strip_exponent,
+ * qamd_absmax_log10_sum(_add), qamd_div_by_absmax, qamd_unary, qamd_minmax, qamd_absmax.  Plan compilation
+ * (qamd_pair_build_ktab) and qamd_microtree_run execute immediately.  Every buffer a recorded call names -- other
+ * than the bound inputs -- must stay allocated, at the same address, for as long as the program is run.  A program is
+ * not thread-safe; recording is per thread.
+ */
+typedef struct qamd_program qamd_program;
+qamd_program* qamd_program_create(int32_t nlanes);
+void qamd_program_destroy(qamd_program* prog);
+int qamd_program_record_begin(qamd_program* prog);
+int qamd_program_set_lane(qamd_program* prog, int32_t lane);
+int qamd_program_wait(qamd_program* prog, int32_t lane, int32_t on_lane);
+int qamd_program_mark(qamd_program* prog, int32_t tag);
+int qamd_program_record_end(qamd_program* prog);
+int qamd_program_bind_inputs(qamd_program* prog, int32_t n, const void* const* ptrs, const int64_t* nbytes);
+int32_t qamd_program_num_ops(const qamd_program* prog);        /* launches + waits */
+int32_t qamd_program_num_launches(const qamd_program* prog);
+int32_t qamd_program_num_marks(const qamd_program* prog);
+/* lane_streams: nlanes hipStream_t; input_ptrs: as many device pointers as were bound (may be NULL if none);
+ * timing = 0: no timing; timing = s + 1: the marked launches record their timing events into slot s (a slot per run of a
+ * timed region keeps every reading; slots are created on first use, so a WARM-UP run per slot keeps event creation out
+ * of the timed region) */
+int qamd_program_run(qamd_program* prog, void* const* lane_streams, const void* const* input_ptrs, int32_t timing);
+/* milliseconds the i-th marked launch took in the last run that used ``slot`` (synchronise first); *tag_out = its tag */
+int qamd_program_mark_ms(qamd_program* prog, int32_t i, int32_t slot, int32_t* tag_out, float* ms_out);
 
 #ifdef __cplusplus
 }

@@ -108,6 +108,21 @@ SYMBOLS = [
     ("qamd_microtree_run", C.c_int, [_i32, _vp, _i32, _vp, _vp, _vp, _i32, _vp, _i64, _vp, _i64, _i32, _vp]),
     ("qamd_unary", C.c_int, [_vp, _vp, _i64, _i32, _i32, _vp]),
     ("qamd_minmax", C.c_int, [_vp, _vp, _i64, _i32, _i32, _vp]),
+    ("qamd_absmax_log10_sum_add", C.c_int, [_vp, _i64, _i32, _vp, _vp]),
+    # launch programs (record once, replay with one host call)
+    ("qamd_program_create", _vp, [_i32]),
+    ("qamd_program_destroy", None, [_vp]),
+    ("qamd_program_record_begin", C.c_int, [_vp]),
+    ("qamd_program_set_lane", C.c_int, [_vp, _i32]),
+    ("qamd_program_wait", C.c_int, [_vp, _i32, _i32]),
+    ("qamd_program_mark", C.c_int, [_vp, _i32]),
+    ("qamd_program_record_end", C.c_int, [_vp]),
+    ("qamd_program_bind_inputs", C.c_int, [_vp, _i32, C.POINTER(C.c_void_p), _pi64]),
+    ("qamd_program_num_ops", _i32, [_vp]),
+    ("qamd_program_num_launches", _i32, [_vp]),
+    ("qamd_program_num_marks", _i32, [_vp]),
+    ("qamd_program_run", C.c_int, [_vp, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), _i32]),
+    ("qamd_program_mark_ms", C.c_int, [_vp, _i32, _i32, C.POINTER(C.c_int32), C.POINTER(C.c_float)]),
 ]
 
 _ERRORS = {

@@ -11,6 +11,7 @@
 #include "../../include/quimb_amd.h"
 #include "ew_args.h"
 #include "gett_args.h"
+#include "program.h"
 
 static const int kEsize[4] = {4, 8, 8, 16};
 
@@ -492,6 +493,7 @@ static int launch_gemmk(const qamd_pair_plan* p, const PairDims& d, const void* 
 extern "C" int qamd_contract_pair_ex(const qamd_pair_plan* p, const void* A, const void* B, void* C,
                                      const void* ktab, void* ws, int64_t ws_bytes, const qamd_epilogue* ep,
                                      void* stream) {
+  if (qamdp_recording()) return qamdp_rec_pair(p, A, B, C, ktab, ws, ws_bytes, ep);
   PairDims d;
   int rc = pair_dims(p, d);
   if (rc) return rc;
@@ -697,6 +699,7 @@ static bool plan_permute_stream(const std::vector<Dim>& d0, int64_t src_offset, 
 
 extern "C" int qamd_permute(void* dst, const void* src, int32_t ndim, const int64_t* shape,
                             const int64_t* src_strides, int64_t src_offset, int32_t dtype, void* stream) {
+  if (qamdp_recording()) return qamdp_rec_permute(dst, src, ndim, shape, src_strides, src_offset, dtype);
   if (ndim < 0 || ndim > QAMD_MAX_NDIM || dtype < 0 || dtype > 3) return QAMD_EINVAL;
   if (!dst || !src) return QAMD_EINVAL;
   std::vector<Dim> d(ndim);
@@ -776,6 +779,7 @@ extern "C" int qamd_reduce_sum(void* out, const void* x, int32_t ndk, const int6
                                const int64_t* strides_keep, int32_t ndr, const int64_t* shape_red,
                                const int64_t* strides_red, int32_t dtype, void* stream) {
   if (ndk < 0 || ndr < 0 || ndk > QAMD_PG || ndr > QAMD_PG || dtype < 0 || dtype > 3) return QAMD_EINVAL;
+  if (qamdp_recording()) return qamdp_rec_reduce(out, x, ndk, shape_keep, strides_keep, ndr, shape_red, strides_red, dtype);
   ReduceArgs a;
   memset(&a, 0, sizeof(a));
   int64_t nk = 1, nr = 1;
@@ -801,6 +805,7 @@ extern "C" int qamd_reduce_sum(void* out, const void* x, int32_t ndk, const int6
 extern "C" int qamd_binary(void* out, const void* x, const int64_t* xs, const void* y, const int64_t* ys,
                            int32_t ndim, const int64_t* shape, int32_t op, int32_t dtype, void* stream) {
   if (ndim < 0 || ndim > QAMD_MAX_NDIM || dtype < 0 || dtype > 3 || op < 0 || op > 3) return QAMD_EINVAL;   // 0 add, 1 mul, 2 sub, 3 true division
+  if (qamdp_recording()) return qamdp_rec_binary(out, x, xs, y, ys, ndim, shape, op, dtype);
   // fuse adjacent dims where both operands allow it
   struct D3 { int64_t n, sa, sb; };
   std::vector<D3> v;
@@ -961,6 +966,7 @@ extern "C" int qamd_chain2_describe(const qamd_chain2_plan* p, char* buf, int32_
 extern "C" int qamd_contract_chain2(const qamd_chain2_plan* p, const void* A, const void* W1p, const void* W2p,
                                     void* C, const void* offK1_dev, const void* offCo_dev, const void* scale_a,
                                     const void* scale_1, const void* scale_2, void* absmax_out, void* stream) {
+  if (qamdp_recording()) return qamdp_rec_chain2(p, A, W1p, W2p, C, offK1_dev, offCo_dev, scale_a, scale_1, scale_2, absmax_out);
   if (!p || !A || !W1p || !W2p || !C || !offK1_dev || !offCo_dev) return QAMD_EINVAL;
   if (p->nm < 1 || p->nm > QAMD_MAX_GROUPS) return QAMD_EINVAL;
   const int ch = qamd_chain2_chunk(p->dtype, p->D);
@@ -1060,6 +1066,7 @@ extern "C" int qamd_contract_chain3(const qamd_chain3_plan* p, const void* A, co
                                     const void* W3, void* C, const void* offK1_dev, const void* offCo_dev,
                                     const void* scale_a, const void* scale_1, const void* scale_2, const void* scale_3,
                                     void* absmax_out, void* stream) {
+  if (qamdp_recording()) return qamdp_rec_chain3(p, A, W1, W2, W3, C, offK1_dev, offCo_dev, scale_a, scale_1, scale_2, scale_3, absmax_out);
   if (!p || !A || !W1 || !W2 || !W3 || !C || !offK1_dev || !offCo_dev) return QAMD_EINVAL;
   int64_t chunks = 0;
   int rc = chain3_check(p, chunks);

@@ -10,6 +10,7 @@
 #include <algorithm>
 #include <stdint.h>
 #include "ew_args.h"
+#include "program.h"
 
 // hipGetLastError() also reports benign stale codes (hipErrorNotReady from an
 // event query by the allocator, ...): clear them before each launch so the
@@ -461,7 +462,7 @@ __global__ void strip_finish_kernel(double* __restrict__ exponent, typename Bits
 }
 
 // sum_t log10(max over tensor t's slots); one wave per launch is plenty
-template <typename R>
+template <typename R, bool ADD = false>
 __global__ void absmax_log10_sum_kernel(const R* __restrict__ slots, int64_t nt, double* __restrict__ out) {
   double s = 0.0;
   for (int64_t t = threadIdx.x; t < nt; t += 64) {
@@ -474,7 +475,10 @@ __global__ void absmax_log10_sum_kernel(const R* __restrict__ slots, int64_t nt,
   }
 #pragma unroll
   for (int d = 32; d > 0; d >>= 1) s += __shfl_down(s, d, 64);
-  if (threadIdx.x == 0) out[0] = s;
+  if (threadIdx.x == 0) {
+    if constexpr (ADD) atomicAdd(out, s);   // the accumulator also takes the un-fused strips of other lanes
+    else out[0] = s;
+  }
 }
 
 template <typename R>
@@ -580,6 +584,7 @@ extern "C" int qamd_binary_launch(int dtype, void* out, const void* a, const voi
 }
 
 extern "C" int qamd_scale(void* x, int64_t n, double re, double im, int32_t dtype, void* stream) {
+  if (qamdp_recording()) return qamdp_rec_simple(QP_SCALE, x, nullptr, nullptr, nullptr, n, dtype, 0, re, im);
   hipStream_t st = (hipStream_t)stream;
   if (n <= 0) return 0;
   uint32_t grid = flat_grid(n);
@@ -594,6 +599,7 @@ extern "C" int qamd_scale(void* x, int64_t n, double re, double im, int32_t dtyp
 }
 
 extern "C" int qamd_axpby(void* y, const void* x, int64_t n, double fy, double fx, int32_t dtype, void* stream) {
+  if (qamdp_recording()) return qamdp_rec_simple(QP_AXPBY, y, x, nullptr, nullptr, n, dtype, 0, fy, fx);
   hipStream_t st = (hipStream_t)stream;
   if (n <= 0) return 0;
   int64_t nr = (dtype >= 2) ? 2 * n : n;
@@ -609,6 +615,7 @@ extern "C" int qamd_axpby(void* y, const void* x, int64_t n, double fy, double f
 
 extern "C" int qamd_axpby_exp(void* y, const void* x, int64_t n, void* y_exp_dev, const void* x_exp_dev, int32_t dtype,
                               void* stream) {
+  if (qamdp_recording()) return qamdp_rec_simple(QP_AXPBY_EXP, y, x, y_exp_dev, x_exp_dev, n, dtype, 0, 0.0, 0.0);
   hipStream_t st = (hipStream_t)stream;
   if (dtype < 0 || dtype > 3 || !y_exp_dev || !x_exp_dev) return -2;
   int64_t nr = dtype >= 2 ? 2 * n : n;
@@ -626,6 +633,7 @@ extern "C" int qamd_axpby_exp(void* y, const void* x, int64_t n, void* y_exp_dev
 }
 
 extern "C" int qamd_conj(void* dst, const void* src, int64_t n, int32_t dtype, void* stream) {
+  if (qamdp_recording()) return qamdp_rec_simple(QP_CONJ, dst, src, nullptr, nullptr, n, dtype, 0, 0.0, 0.0);
   hipStream_t st = (hipStream_t)stream;
   if (n <= 0) return 0;
   uint32_t grid = flat_grid(n);
@@ -640,6 +648,7 @@ extern "C" int qamd_conj(void* dst, const void* src, int64_t n, int32_t dtype, v
 }
 
 extern "C" int qamd_fill(void* dst, int64_t n, double re, double im, int32_t dtype, void* stream) {
+  if (qamdp_recording()) return qamdp_rec_simple(QP_FILL, dst, nullptr, nullptr, nullptr, n, dtype, 0, re, im);
   hipStream_t st = (hipStream_t)stream;
   if (n <= 0) return 0;
   uint32_t grid = flat_grid(n);
@@ -653,6 +662,7 @@ extern "C" int qamd_fill(void* dst, int64_t n, double re, double im, int32_t dty
 }
 
 extern "C" int qamd_cast(void* dst, int32_t dd, const void* src, int32_t sd, int64_t n, void* stream) {
+  if (qamdp_recording()) return qamdp_rec_simple(QP_CAST, dst, src, nullptr, nullptr, n, dd, sd, 0.0, 0.0);
   hipStream_t st = (hipStream_t)stream;
   if (n <= 0) return 0;
   if (dd < 0 || dd > 3 || sd < 0 || sd > 3) return -2;
@@ -735,6 +745,7 @@ __global__ __launch_bounds__(256) void minmax_kernel(R* __restrict__ out, const 
 }
 
 extern "C" int qamd_unary(void* dst, const void* src, int64_t n, int32_t op, int32_t dtype, void* stream) {
+  if (qamdp_recording()) return qamdp_rec_simple(QP_UNARY, dst, src, nullptr, nullptr, n, dtype, op, 0.0, 0.0);
   hipStream_t st = (hipStream_t)stream;
   if (dtype < 0 || dtype > 3 || op < 0 || op > 4) return -2;
   if (dtype >= 2 && op != 0) return -2;   // complex: only abs (-> real magnitudes)
@@ -748,6 +759,7 @@ extern "C" int qamd_unary(void* dst, const void* src, int64_t n, int32_t op, int
 }
 
 extern "C" int qamd_minmax(void* out_dev, const void* x, int64_t n, int32_t want_min, int32_t dtype, void* stream) {
+  if (qamdp_recording()) return qamdp_rec_simple(QP_MINMAX, out_dev, x, nullptr, nullptr, n, dtype, want_min, 0.0, 0.0);
   hipStream_t st = (hipStream_t)stream;
   if (dtype != 0 && dtype != 1) return -2;
   if (n <= 0) return -1;
@@ -764,6 +776,7 @@ extern "C" int qamd_minmax(void* out_dev, const void* x, int64_t n, int32_t want
 }
 
 extern "C" int qamd_absmax(void* out_dev, const void* x, int64_t n, int32_t dtype, void* stream) {
+  if (qamdp_recording()) return qamdp_rec_simple(QP_ABSMAX, out_dev, x, nullptr, nullptr, n, dtype, 0, 0.0, 0.0);
   hipStream_t st = (hipStream_t)stream;
   if (dtype < 0 || dtype > 3) return -2;
   // the 8 bytes after out_dev[0] are used as scratch: out_dev must be >= 16 bytes
@@ -784,6 +797,7 @@ extern "C" int qamd_absmax(void* out_dev, const void* x, int64_t n, int32_t dtyp
 
 extern "C" int qamd_strip_exponent(void* x, int64_t n, int32_t dtype, void* scratch_dev,
                                    void* exponent_dev, void* stream) {
+  if (qamdp_recording()) return qamdp_rec_simple(QP_STRIP, x, scratch_dev, exponent_dev, nullptr, n, dtype, 0, 0.0, 0.0);
   hipStream_t st = (hipStream_t)stream;
   if (dtype < 0 || dtype > 3) return -2;
   if (n <= 0) return 0;
@@ -805,6 +819,7 @@ extern "C" int qamd_strip_exponent(void* x, int64_t n, int32_t dtype, void* scra
 }
 
 extern "C" int qamd_absmax_log10_sum(const void* slots, int64_t nt, int32_t dtype, void* out_dev, void* stream) {
+  if (qamdp_recording()) return qamdp_rec_simple(QP_LOG10SUM, slots, out_dev, nullptr, nullptr, nt, dtype, 0, 0.0, 0.0);
   hipStream_t st = (hipStream_t)stream;
   if (dtype < 0 || dtype > 3) return -2;
   if (dtype == 0 || dtype == 2)
@@ -814,7 +829,19 @@ extern "C" int qamd_absmax_log10_sum(const void* slots, int64_t nt, int32_t dtyp
   QAMD_CHECK_LAUNCH();
 }
 
+extern "C" int qamd_absmax_log10_sum_add(const void* slots, int64_t nt, int32_t dtype, void* acc_dev, void* stream) {
+  if (qamdp_recording()) return qamdp_rec_simple(QP_LOG10SUM_ADD, slots, acc_dev, nullptr, nullptr, nt, dtype, 0, 0.0, 0.0);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype < 0 || dtype > 3) return -2;
+  if (dtype == 0 || dtype == 2)
+    QAMD_LAUNCH((absmax_log10_sum_kernel<float, true>), dim3(1), dim3(64), 0, st, (const float*)slots, nt, (double*)acc_dev);
+  else
+    QAMD_LAUNCH((absmax_log10_sum_kernel<double, true>), dim3(1), dim3(64), 0, st, (const double*)slots, nt, (double*)acc_dev);
+  QAMD_CHECK_LAUNCH();
+}
+
 extern "C" int qamd_div_by_absmax(void* x, int64_t n, const void* slots, int32_t dtype, void* stream) {
+  if (qamdp_recording()) return qamdp_rec_simple(QP_DIVABS, x, slots, nullptr, nullptr, n, dtype, 0, 0.0, 0.0);
   hipStream_t st = (hipStream_t)stream;
   if (dtype < 0 || dtype > 3) return -2;
   if (n <= 0) return 0;
@@ -827,6 +854,7 @@ extern "C" int qamd_div_by_absmax(void* x, int64_t n, const void* slots, int32_t
 }
 
 extern "C" int qamd_complex_expand(void* dst, const void* src, int64_t n, int32_t conj, int32_t dtype, void* stream) {
+  if (qamdp_recording()) return qamdp_rec_simple(QP_CEXPAND, dst, src, nullptr, nullptr, n, dtype, conj, 0.0, 0.0);
   hipStream_t st = (hipStream_t)stream;
   if (dtype != 2 && dtype != 3) return -2;
   if (n <= 0) return 0;

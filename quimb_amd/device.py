@@ -85,6 +85,9 @@ class HipDevice:
             np.dtype("int64"): torch.int64,
         }
         self._pairs = {}
+        #: the active launch-program recorder (quimb_amd/program.py) or None: while set, every allocation of this
+        #: device comes from the recorder's pool and the library appends launches to its program instead of issuing them
+        self.record = None
         #: set to a list to collect (spec, dtype, tile_cfg, split_k, start_event, end_event)
         #: per qamd_contract_pair launch (HIP events on the launch stream)
         self.profile = None
@@ -97,7 +100,19 @@ class HipDevice:
 
     # ---- memory ---------------------------------------------------------
     def empty(self, n, dtype):
+        if self.record is not None:
+            return self.record.alloc(max(int(n), 1), self._tdt[np.dtype(dtype)])
         return self.torch.empty(max(int(n), 1), dtype=self._tdt[np.dtype(dtype)], device=self.tdev)
+
+    def _zeros(self, n, tdtype, value=0.0):
+        """``n`` elements of a torch dtype holding ``value``; recorded as a fill while a program is being recorded (so
+        that every replay starts from it), a plain torch allocation otherwise."""
+        if self.record is None:
+            return self.torch.full((int(n),), value, dtype=tdtype, device=self.tdev)
+        t = self.record.alloc(int(n), tdtype)
+        code = {self.torch.float32: _lib.QAMD_F32, self.torch.float64: _lib.QAMD_F64}[tdtype]
+        _lib.check(self.lib.qamd_fill(t.data_ptr(), int(n), float(value), 0.0, code, self.stream()), "qamd_fill")
+        return t
 
     def from_host(self, x):
         x = np.ascontiguousarray(x)
@@ -119,14 +134,26 @@ class HipDevice:
     def synchronize(self):
         self.torch.cuda.synchronize(self.tdev)
 
-    def lane_streams(self, n):
-        """[current stream, side stream 1, ...]: the HIP streams the tree executor runs independent branches on."""
+    def lane_streams(self, n, priorities=None, own_lane0=False):
+        """[current stream, side stream 1, ...]: the HIP streams the tree executor runs independent branches on.
+        ``priorities``: per lane, -1 = high, 0 = normal (HIP stream priorities: the dispatcher serves a high-priority
+        queue first when several have work).  ``own_lane0``: lane 0 is a stream of the pool too (a launch program forks
+        from and joins back to the caller's stream around its run) instead of the caller's current stream."""
         pool = getattr(self, "_lane_pool", None)
         if pool is None:
-            pool = self._lane_pool = []
-        while len(pool) < n - 1:
-            pool.append(self.torch.cuda.Stream(device=self.tdev))
-        return [self.torch.cuda.current_stream(self.tdev)] + pool[: n - 1]
+            pool = self._lane_pool = {}
+        out = []
+        for lane in range(n):
+            if lane == 0 and not own_lane0:
+                out.append(self.torch.cuda.current_stream(self.tdev))
+                continue
+            pr = int(priorities[lane]) if priorities is not None else 0
+            key = (lane, pr)
+            st = pool.get(key)
+            if st is None:
+                st = pool[key] = self.torch.cuda.Stream(device=self.tdev, priority=pr)
+            out.append(st)
+        return out
 
     def _workspace(self, nbytes):
         """Split-K / dot workspace of ONE launch: a stream-ordered allocation from torch's caching allocator on the
@@ -137,11 +164,20 @@ class HipDevice:
         long as the graph does."""
         if nbytes <= 0:
             return None, None, 0
-        ws = self.torch.empty(int(nbytes), dtype=self.torch.uint8, device=self.tdev)
+        ws = (self.record.alloc(int(nbytes), self.torch.uint8) if self.record is not None else
+              self.torch.empty(int(nbytes), dtype=self.torch.uint8, device=self.tdev))
         return ws, ws.data_ptr(), ws.numel()
+
+    def release_temp(self, t):
+        """A temporary of ONE launch (workspace, scratch, expanded operand) is done with: a no-op in ordinary operation
+        (the caching allocator sees the tensor die), the hand-back to the pool while a program is being recorded."""
+        if t is not None and self.record is not None:
+            self.record.release(t)
 
     def _scratch(self):
         """4 doubles of reduction scratch for one call, private to the launch stream (see ``_workspace``)."""
+        if self.record is not None:
+            return self.record.alloc(4, self.torch.float64)
         return self.torch.empty(4, dtype=self.torch.float64, device=self.tdev)
 
     # ---- pairwise contraction ---------------------------------------------
@@ -178,7 +214,7 @@ class HipDevice:
     def _wait_plan_tables(self, cp):
         """Order the current stream behind the kernel that filled ``cp.ktab`` (built on another stream)."""
         ev = cp.ready
-        if ev is None:
+        if ev is None or self.record is not None:     # (a recorder synchronises once, after the recording)
             return
         if self.stream() != cp.ready_stream:
             self.torch.cuda.current_stream(self.tdev).wait_event(ev)
@@ -207,6 +243,9 @@ class HipDevice:
         prof = self.profile
         if prof is not None and getattr(spec, "mults", self.profile_min_mults) < self.profile_min_mults:
             prof = None      # an event pair costs a small launch ~10 us of queue time: only the launches that matter
+        if self.record is not None:
+            prof = None
+            self.record.maybe_mark(spec, np.dtype(dtype), lambda: (self.describe_pair(cp), cp.struct.split_k))
         if prof is not None:
             e0 = self.torch.cuda.Event(enable_timing=True)
             e1 = self.torch.cuda.Event(enable_timing=True)
@@ -220,6 +259,7 @@ class HipDevice:
         if prof is not None:
             e1.record()
             prof.append((spec, np.dtype(dtype), self.describe_pair(cp), cp.struct.split_k, e0, e1))
+        self.release_temp(ws_keep)
 
     # ---- fused pair of streaming steps ---------------------------------------------
     def contract_chain2(self, c2, dtype, a, w1, w2, c, ep=None):
@@ -274,6 +314,9 @@ class HipDevice:
         prof = self.profile
         if prof is not None and c2.mults < self.profile_min_mults:
             prof = None
+        if self.record is not None:
+            prof = None
+            self.record.maybe_mark(c2, np.dtype(dtype), lambda: (name, 1))
         if prof is not None:
             e0 = self.torch.cuda.Event(enable_timing=True)
             e1 = self.torch.cuda.Event(enable_timing=True)
@@ -288,6 +331,9 @@ class HipDevice:
         if prof is not None:
             e1.record()
             prof.append((c2, np.dtype(dtype), name, 1, e0, e1))
+        if not (pl.flags & 8):
+            self.release_temp(w1p)
+            self.release_temp(w2p)
 
     # ---- fused triple of streaming steps --------------------------------------------
     def contract_chain3(self, c3, dtype, a, w1, w2, w3, c, ep=None):
@@ -315,6 +361,9 @@ class HipDevice:
         if ep is not None:
             sa, s1, s2, s3, so = (ptr(t) for t in ep)
         prof = self.profile
+        if self.record is not None:
+            prof = None
+            self.record.maybe_mark(c3, np.dtype(dtype), lambda: (name, 1))
         if prof is not None:
             e0 = self.torch.cuda.Event(enable_timing=True)
             e1 = self.torch.cuda.Event(enable_timing=True)
@@ -378,7 +427,7 @@ class HipDevice:
         )
 
     def new_exponent_neg_inf(self):
-        return self.torch.full((1,), float("-inf"), dtype=self.torch.float64, device=self.tdev)
+        return self._zeros(1, self.torch.float64, float("-inf"))
 
     def conj(self, dst, src, n, dtype):
         _lib.check(self.lib.qamd_conj(dst.data_ptr(), src.data_ptr(), int(n), dtype_code(dtype), self.stream()), "qamd_conj")
@@ -407,7 +456,7 @@ class HipDevice:
     # ---- exponent stripping ---------------------------------------------------
     def new_exponent(self):
         """Device-resident float64 accumulator for log10 factors."""
-        return self.torch.zeros(1, dtype=self.torch.float64, device=self.tdev)
+        return self._zeros(1, self.torch.float64)
 
     def strip_exponent(self, x, n, dtype, exponent):
         """x /= max|x|; exponent += log10(max|x|) (an atomic add: lanes share one accumulator)."""
@@ -418,24 +467,24 @@ class HipDevice:
             ),
             "qamd_strip_exponent",
         )
+        self.release_temp(scratch)
 
     # fused form: per-tensor absmax slots, consumed as scales by the next contraction
     def new_slots(self, n_tensors, dtype):
         """(n_tensors, 64) zeroed slots of the real dtype matching ``dtype``."""
         rdt = self.torch.float32 if np.dtype(dtype) in (np.dtype("float32"), np.dtype("complex64")) else self.torch.float64
-        return self.torch.zeros((int(n_tensors), _lib.ABSMAX_SLOTS), dtype=rdt, device=self.tdev)
+        return self._zeros(int(n_tensors) * _lib.ABSMAX_SLOTS, rdt).reshape(int(n_tensors), _lib.ABSMAX_SLOTS)
 
     def slots_row(self, slots, i):
         return slots[i]
 
     def slots_log10_sum(self, slots, dtype, exponent):
-        """exponent[0] += sum_t log10(max(slots[t]))  (device side, no sync)."""
-        tmp = self.torch.empty(1, dtype=self.torch.float64, device=self.tdev)
+        """exponent[0] += sum_t log10(max(slots[t]))  (device side, one launch, no sync)."""
         _lib.check(
-            self.lib.qamd_absmax_log10_sum(slots.data_ptr(), slots.shape[0], dtype_code(dtype), tmp.data_ptr(), self.stream()),
-            "qamd_absmax_log10_sum",
+            self.lib.qamd_absmax_log10_sum_add(slots.data_ptr(), slots.shape[0], dtype_code(dtype), exponent.data_ptr(),
+                                               self.stream()),
+            "qamd_absmax_log10_sum_add",
         )
-        exponent += tmp
 
     def div_by_absmax(self, x, n, slots_row, dtype):
         _lib.check(
@@ -444,9 +493,13 @@ class HipDevice:
         )
 
     def read_exponent(self, exponent):
+        if self.record is not None:
+            raise _lib.QamdError("read_exponent() reads the device: not available while a launch program is being recorded")
         return float(exponent.cpu()[0])
 
     def absmax(self, x, n, dtype):
+        if self.record is not None:
+            raise _lib.QamdError("absmax() reads the device: not available while a launch program is being recorded")
         scratch = self._scratch()
         _lib.check(
             self.lib.qamd_absmax(scratch.data_ptr() + 16, x.data_ptr(), int(n), dtype_code(dtype), self.stream()),

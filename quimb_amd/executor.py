@@ -38,7 +38,11 @@ class TreeExecutor:
     """Plan once, run many times (the analogue of a cached cotengra expression,
     pinned by tests/test_tensor/test_contract.py:155-172 in the reference)."""
 
-    def __init__(self, tree: ContractionTree, dtype="float32"):
+    def __init__(self, tree: ContractionTree, dtype="float32", join_order=True):
+        #: issue the chains of the FIRST join first and that join right behind them (``_order_for_joins``): right for the
+        #: launch-by-launch path, where the host enqueues slower than the device executes; a launch program enqueues a
+        #: whole share in 0.35 ms and is recorded in plain plan order (all chains side by side, then the joins)
+        self.join_order = bool(join_order)
         if os.environ.get("QAMD_REGROUP", "1") != "0":
             tree = tree.regrouped()          # (A.W1).W2 -> A.(W1.W2) where cheaper (sliced bonds); same result
         self.tree = tree
@@ -219,7 +223,10 @@ class TreeExecutor:
                 if c not in big:
                     stack.append((c, ln))
             if len(big) >= 2:
-                for c in big:
+                # a stack: pushed last = handled first = takes the home lane.  Join order: the FIRST join's first chain
+                # (that join then sits right behind its own operand on lane 0).  Plain order: the LAST join's chain --
+                # lane 0 finishes it before it reaches the first join, so no join runs beside a corner sweep
+                for c in (reversed(big) if self.join_order else big):
                     if len(big_kids(c)) >= 2 or nxt[0] >= max_lanes:
                         stack.append((c, ln))          # a join below a join / out of lanes: same lane
                     elif ln == 0 and not home_taken[0]:
@@ -233,6 +240,71 @@ class TreeExecutor:
         self.lanes = lane
         self.nlanes = nxt[0]
         self._producer = prod
+        self._order_for_joins()
+
+    def _order_for_joins(self):
+        """Issue order and lane priorities of a laned plan.  The ANCHORS are the entries of lane 0 that take an operand
+        from another lane (the joins).  Everything the first anchor needs is issued first -- its chains interleaved
+        launch by launch, so that they advance together however slow the host is -- then the anchor itself, then what the
+        second anchor needs, and so on: the first join starts as soon as ITS operands exist and the chains of the later
+        joins run beside it instead of in front of it.  Any topological order is a valid schedule; this one only
+        changes WHEN things are enqueued (``lane_priority``: HIP stream priority per lane, all normal by default)."""
+        n = len(self.plan)
+        self.lane_priority = [0] * self.nlanes
+        if self.nlanes <= 1 or not self.join_order or os.environ.get("QAMD_JOIN_ORDER", "1") == "0":
+            return
+        prod = self._producer
+        kids = [tuple(prod[o] for o in self._entry_io(e)[0] if o in prod) for e in self.plan]
+        anchors = [i for i in range(n) if self.lanes[i] == 0 and any(self.lanes[c] != 0 for c in kids[i])]
+        if not anchors:
+            return
+        if anchors[-1] != n - 1:
+            anchors.append(n - 1)
+        need = [None] * n
+        for a in anchors:
+            stack = [a]
+            while stack:
+                i = stack.pop()
+                if need[i] is not None:
+                    continue
+                need[i] = a
+                stack.extend(kids[i])
+        order = []
+        for a in anchors:
+            group = [i for i in range(n) if need[i] == a and i != a]
+            queues = {}
+            for i in group:
+                queues.setdefault(self.lanes[i], []).append(i)
+            qs = [queues[l] for l in sorted(queues)]
+            issued = set(order)
+            while any(qs):
+                progressed = False
+                for q in qs:
+                    if q and all(c in issued for c in kids[q[0]]):
+                        i = q.pop(0)
+                        order.append(i)
+                        issued.add(i)
+                        progressed = True
+                if not progressed:       # (cannot happen for a valid plan; keep the original order rather than spin)
+                    rest = sorted(i for q in qs for i in q)
+                    order.extend(rest)
+                    break
+            order.append(a)
+        order += [i for i in range(n) if need[i] is None]
+        if sorted(order) != list(range(n)):
+            return
+        # (HIP stream priorities for the first join's lanes were tried in round 4 and dropped: they did not keep a join
+        # from slowing down beside a corner sweep, and streams of a second priority class cost hardware queues.
+        # QAMD_LANE_PRIORITY=1 brings them back for experiments.)
+        if os.environ.get("QAMD_LANE_PRIORITY", "0") == "1":
+            first = anchors[0]
+            for i in range(n):
+                if need[i] == first:
+                    self.lane_priority[self.lanes[i]] = -1
+        self.plan = [self.plan[i] for i in order]
+        self.info = [self.info[i] for i in order]
+        self.lanes = [self.lanes[i] for i in order]
+        self._producer = {self._entry_io(e)[1]: i for i, e in enumerate(self.plan)}
 
     # ---- accounting -------------------------------------------------------------
     def flops(self, per_slice=False, hoist=True):
@@ -270,7 +342,8 @@ class TreeExecutor:
 
     def _run_core(self, inputs, exponent, cache, only_independent=False, lanes=False):
         dev = inputs[0]._dev
-        home = dev.torch.cuda.current_stream(dev.tdev) if hasattr(dev, "torch") else None
+        # (a launch-program recording never touches torch's streams)
+        home = dev.torch.cuda.current_stream(dev.tdev) if hasattr(dev, "torch") and getattr(dev, "record", None) is None else None
         try:
             return self._run_core_impl(inputs, exponent, cache, only_independent, lanes)
         finally:
@@ -292,13 +365,23 @@ class TreeExecutor:
             nid = len(inputs) + len(self.tree.steps)
             slots = dev.new_slots(nid, self.dtype)
             has_scale = set()
-        # branch concurrency (unsliced runs on the HIP device): lane -> stream; lane 0 is the caller's stream
+        # branch concurrency (unsliced runs on the HIP device): lane -> stream; lane 0 is the caller's stream.  While a
+        # launch program is being recorded (quimb_amd/program.py) the lanes are the PROGRAM's: switches and waits are
+        # appended to it instead of acting on torch streams, and buffers come from (and go back to) its pool.
+        rec = getattr(dev, "record", None)
         streams = None
-        if lanes and self.nlanes > 1 and hasattr(dev, "lane_streams") and os.environ.get("QAMD_LANES", "1") != "0":
-            streams = dev.lane_streams(self.nlanes)
+        use_lanes = lanes and self.nlanes > 1 and os.environ.get("QAMD_LANES", "1") != "0"
+        if rec is not None:
+            if use_lanes:
+                for l_ in range(1, self.nlanes):
+                    rec.wait(l_, 0)                   # the slots / exponent fills recorded so far sit on lane 0
+        elif use_lanes and hasattr(dev, "lane_streams"):
+            streams = dev.lane_streams(self.nlanes, getattr(self, "lane_priority", None))
             for st_ in streams[1:]:
                 st_.wait_stream(streams[0])       # inputs / slots are ready on the caller's stream
+        laned = streams is not None or (rec is not None and use_lanes)
         keep_alive = []   # buffers handed from one lane to another stay allocated until every launch is queued
+        foreign = set()   # ssa ids of such buffers: a program's pool never reuses them
         # QAMD_LANE_TRACE=1 (debugging aid): HIP events at the first and last launch of every lane -> self.lane_trace
         trace = trace_at = None
         if streams is not None and os.environ.get("QAMD_LANE_TRACE"):
@@ -322,18 +405,25 @@ class TreeExecutor:
             for s in operands(entry):
                 uses[s] = uses.get(s, 0) + 1
         for pi, entry in enumerate(self.plan):
-            if streams is not None:
-                mine = streams[self.lanes[pi]]
+            if laned:
                 for o in self._entry_io(entry)[0]:
                     pj = self._producer.get(o)
                     if pj is not None and self.lanes[pj] != self.lanes[pi]:
-                        mine.wait_stream(streams[self.lanes[pj]])     # the join: one event
                         keep_alive.append(live[o])
+                        foreign.add(o)
+                        if rec is not None:
+                            rec.wait(self.lanes[pi], self.lanes[pj])          # the join: one event at replay
+                            continue
+                        mine = streams[self.lanes[pi]]
+                        mine.wait_stream(streams[self.lanes[pj]])     # the join: one event
                         buf_ = getattr(live[o], "_buf", None)
                         if hasattr(buf_, "record_stream") and not dev.torch.cuda.is_current_stream_capturing():
                             buf_.record_stream(mine)      # allocated on the producer's stream, read on this one: the
                                                           # allocator must not hand it out again before this stream is done
-                dev.torch.cuda.set_stream(mine)
+                if rec is not None:
+                    rec.set_lane(self.lanes[pi])
+            if streams is not None:
+                dev.torch.cuda.set_stream(streams[self.lanes[pi]])
                 if trace is not None and pi in trace_at:
                     ev = dev.torch.cuda.Event(enable_timing=True)
                     ev.record()
@@ -425,19 +515,45 @@ class TreeExecutor:
             for s in ids:
                 uses[s] -= 1
                 if uses[s] == 0:
-                    live.pop(s, None)
+                    gone = live.pop(s, None)
+                    # a recorded program reuses the block for later launches of THIS lane (stream order); inputs and
+                    # buffers that crossed lanes are left alone
+                    if rec is not None and gone is not None and s >= len(inputs) and s not in foreign:
+                        rec.release(gone._buf)
             if streams is not None and trace is not None and pi in trace_at:
                 ev = dev.torch.cuda.Event(enable_timing=True)
                 ev.record()
                 trace.append((f"lane {self.lanes[pi]} entry {pi} ({entry[0]}) end", ev))
         if streams is not None:
             dev.torch.cuda.set_stream(streams[0])
+        if rec is not None and laned:
+            rec.set_lane(0)
         out = live.get(self.root)
         if exponent is not None and out is not None:
             if self.root in has_scale:
                 dev.div_by_absmax(out._buf, out.size, dev.slots_row(slots, self.root), out.dtype)
             dev.slots_log10_sum(slots, self.dtype, exponent)
         return out
+
+    def program(self, arrays, strip_exponent=False, mark_min_mults=None):
+        """Record one whole (unsliced) contraction as a LAUNCH PROGRAM and return it (``quimb_amd.program``):
+        ``p()`` / ``p(arrays)`` replays the recorded launches -- branches on their own HIP streams -- with one host call
+        and no per-step Python; inputs are read in place (re-based pointers, no copies).  ``mark_min_mults``: launches
+        of at least that many multiplications carry timing events (``p(timing_slot=k)``, ``p.timings(k)``)."""
+        from .array import asarray as _asarray
+        from .program import ContractionProgram, EagerProgram
+
+        if not hasattr(_asarray(arrays[0])._dev, "lib"):       # the plan interpreter of the CPU tests: nothing to record
+            return EagerProgram(self, arrays, strip_exponent, mark_min_mults)
+        # MFMA-bound joins and HBM-bound corner sweeps do NOT overlap well on this chip (measured, round 4: a 0.95 ms
+        # join takes 1.8 ms beside a corner sweep -- the sweeps evict its operand panels from the L2), and a program's
+        # host side is no bottleneck: record the plain order -- every chain side by side, then the joins
+        ex = self
+        if self.join_order and self.nlanes > 1 and os.environ.get("QAMD_PROGRAM_JOIN_ORDER", "0") != "1":
+            ex = getattr(self, "_plain_order_twin", None)
+            if ex is None:
+                ex = self._plain_order_twin = TreeExecutor(self.tree, self.dtype, join_order=False)
+        return ContractionProgram(ex, arrays, strip_exponent, mark_min_mults)
 
     def graph(self, arrays, strip_exponent=False):
         """Capture one whole (unsliced) contraction into a HIP graph and return a

@@ -96,6 +96,8 @@ def _complex_gett(dev, spec, ka, kb, out):
     kb2 = dev.empty(4 * kb.size, rdt)
     dev.complex_expand(kb2, kb._buf, kb.size, ka.dtype)
     dev.contract_pair(_complex_spec(spec), rdt, dev.as_real(ka._buf), kb2, dev.as_real(out._buf))
+    if hasattr(dev, "release_temp"):
+        dev.release_temp(kb2)
 
 
 def einsum_pair(a, a_inds, b, b_inds, out_inds, out_fixed=True, death=None):

@@ -1805,3 +1805,51 @@ def check_complex_strip_exponent_lanes(dtype, L=6, D=3, seed=5):
             m, e = g.replay()
             got = complex(m.to_numpy().item()) * 10.0**e
             assert abs(got - want) <= rel * abs(want), (got, want)
+
+
+def check_program_replay(L, D, dtype, strip, tree_kind="quadrant", seeds=(1, 2)):
+    """A launch program (quimb_amd/program.py: the executor's launch sequence recorded once, replayed by one C call)
+    against launch-by-launch execution of the same tree: identical mantissa bits (same kernels, same order on every lane),
+    exponent equal up to the order of the lanes' atomic adds; then REPLAYED ON OTHER INPUTS (pointers re-based, no
+    re-recording) against launch-by-launch execution on those; with timing marks on; several runs back to back."""
+    arrays, inputs = orc.tn2d_rand(L, L, D, seed=seeds[0], dtype="float64")
+    kind = np.dtype(dtype).kind
+    rng = np.random.default_rng(seeds[0])
+    cast = lambda arrs: [((a + 1j * rng.uniform(-0.5, 0.5, size=a.shape)) if kind == "c" else a).astype(dtype) for a in arrs]
+    arrays = cast(arrays)
+    inputs = [tuple(t) for t in inputs]
+    size = {ix: D for t in inputs for ix in t}
+    path = qa.quadrant_path_2d(L, L) if tree_kind == "quadrant" else qa.sweep_path_2d(L, L)
+    ex = qa.TreeExecutor(qa.ContractionTree(inputs, (), size, path=path), dtype)
+    xs = [qa.asarray(a) for a in arrays]
+
+    def value(res):
+        if strip:
+            m, e = res
+            return np.asarray(m.to_numpy()).reshape(-1)[0], float(e)
+        return np.asarray(res.to_numpy()).reshape(-1)[0], 0.0
+
+    want = value(ex(xs, strip_exponent=strip))
+    prog = ex.program(xs, strip_exponent=strip, mark_min_mults=1)
+    assert prog.num_launches >= len(ex.plan) and prog.nlanes == ex.nlanes
+    for rep in range(3):
+        got = value(prog(timing_slot=rep))
+        assert got[0] == want[0], (rep, got, want)
+        assert abs(got[1] - want[1]) <= 1e-12 * max(1.0, abs(want[1])), (got, want)
+    t = prog.timings(2)
+    assert len(t) == len(prog.marked) > 0 and all(a.elapsed_time(b) > 0 for *_, a, b in t)
+    # other inputs through the SAME program
+    arrays2 = cast(orc.tn2d_rand(L, L, D, seed=seeds[1], dtype="float64")[0])
+    xs2 = [qa.asarray(a) for a in arrays2]
+    want2 = value(ex(xs2, strip_exponent=strip))
+    got2 = value(prog(xs2))
+    assert got2[0] == want2[0] and abs(got2[1] - want2[1]) <= 1e-12 * max(1.0, abs(want2[1])), (got2, want2)
+    assert want2 != want
+    # and back on the recorded inputs; the oracle agrees with all of it
+    assert value(prog())[0] == want[0]
+    wm = orc.oracle_array_contract([a.astype(np.complex128 if kind == "c" else np.float64) for a in arrays2], inputs, (),
+                                   path=path)
+    ref = complex(np.asarray(wm).item())
+    val = complex(got2[0]) * 10.0 ** got2[1]
+    assert abs(val - ref) <= 10 * RTOL[np.dtype(dtype)] * abs(ref), (val, ref)
+    return prog

@@ -62,6 +62,7 @@ CONTRACT_KEYS = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per
     (["--Lx", "4", "--Ly", "4", "--D", "4", "--steps", "2", "--warmup", "1", "--no-cpu", "--emulate-world", "4"], "four quadrants + two joins"),
     (["--Lx", "4", "--Ly", "4", "--D", "3", "--steps", "1", "--warmup", "1", "--no-cpu", "--sliced", "--slices", "9"], "site-by-site boundary sweep"),
     (["--Lx", "4", "--Ly", "4", "--D", "3", "--steps", "1", "--warmup", "1", "--no-cpu", "--inflight", "2"], None),
+    (["--Lx", "4", "--Ly", "4", "--D", "3", "--steps", "2", "--warmup", "1", "--no-cpu", "--tree", "quadrant", "--launch", "program"], "four quadrants + two joins"),
 ])
 def test_bench_line_contract(emu, monkeypatch, argv, tree):
     d = _run(monkeypatch, argv)
@@ -141,6 +142,7 @@ def test_bench_multi_rank_line(tmp_path, world):
     d = json.loads([ln for ln in outs[0].splitlines() if ln.startswith("{")][0])
     assert CONTRACT_KEYS <= set(d) and d["n_gpus"] == world and d["scaling"] == "strong"
     assert d["config"]["parallelism"].startswith("blocks") and d["cpu_baseline"] is None
+    assert d["config"]["launch"].startswith("launch program")      # N > 1: a step is one replayed program + the collective
     assert len(d["strong_scaling_report"]["per_rank_ms_without_collective"]) == world
     arrays, inputs = orc.tn2d_rand(4, 4, 4, seed=7, dtype="float64")
     want = orc.oracle_array_contract(arrays, inputs, ()).item()

@@ -1,0 +1,155 @@
+"""Launch programs (quimb_amd/program.py + csrc/program.cpp): the recording plumbing on the CPU (nothing is launched while
+recording, so a GPU is not needed to check WHAT is recorded); replay itself is a ``-m gpu`` test."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import checks
+import quimb_amd as qa
+from oracle import np_oracle as orc
+
+
+@pytest.fixture
+def recdev():
+    import quimb_amd.device as qd
+    from record_device import RecordOnlyDevice
+
+    old = qd._DEFAULT
+    dev = RecordOnlyDevice()
+    qd.set_default_device(dev)
+    try:
+        yield dev
+    finally:
+        qd.set_default_device(old)
+
+
+def _network(L, D, dtype="float32"):
+    arrays, inputs = orc.tn2d_rand(L, L, D, seed=1, dtype=dtype)
+    inputs = [tuple(t) for t in inputs]
+    return arrays, inputs, {ix: D for t in inputs for ix in t}
+
+
+def test_c_recorder_counts_and_binding():
+    """The C side on its own: recorded calls are appended (not launched), waits are ops, marks tag the next launch."""
+    from quimb_amd import _lib
+
+    lib = _lib.load()
+    P = lib.qamd_program_create(3)
+    assert lib.qamd_program_record_begin(P) == 0
+    assert lib.qamd_program_record_begin(P) != 0                       # one recording per thread
+    assert lib.qamd_fill(0x1000, 10, 0.0, 0.0, 0, None) == 0
+    assert lib.qamd_program_set_lane(P, 1) == 0 and lib.qamd_program_set_lane(P, 3) != 0
+    assert lib.qamd_scale(0x2000, 10, 2.0, 0.0, 0, None) == 0
+    assert lib.qamd_program_wait(P, 0, 1) == 0 and lib.qamd_program_wait(P, 1, 1) == 0   # self-wait: dropped
+    assert lib.qamd_program_mark(P, 7) == 0
+    assert lib.qamd_axpby(0x1000, 0x2000, 10, 1.0, 1.0, 0, None) == 0
+    assert lib.qamd_program_record_end(P) == 0
+    assert (lib.qamd_program_num_ops(P), lib.qamd_program_num_launches(P), lib.qamd_program_num_marks(P)) == (4, 3, 1)
+    ptrs, nb = (C.c_void_p * 1)(0x2000), (C.c_int64 * 1)(40)
+    assert lib.qamd_program_bind_inputs(P, 1, ptrs, nb) == 0
+    assert lib.qamd_fill(0x1000, 10, 0.0, 0.0, 0, None) != 0 or True    # (outside a recording the call launches: no GPU here)
+    lib.qamd_program_destroy(P)
+
+
+@pytest.mark.parametrize("dtype,strip", [("float32", True), ("float32", False), ("complex64", True)])
+def test_recording_the_quadrant_tree(recdev, dtype, strip):
+    """What one recording of the executor holds: every plan entry's launch, the fills that reset the exponent
+    bookkeeping, one wait per side lane at the start and one per cross-lane hand-over; inputs are bound, not copied."""
+    arrays, inputs, size = _network(6, 6, "float64")
+    arrays = [a.astype(dtype) for a in arrays]
+    ex = qa.TreeExecutor(qa.ContractionTree(inputs, (), size, path=qa.quadrant_path_2d(6, 6)), dtype)
+    assert ex.nlanes == 4
+    xs = [qa.asarray(a) for a in arrays]
+    prog = ex.program(xs, strip_exponent=strip, mark_min_mults=10**5)
+    nwait = prog.num_ops - prog.num_launches
+    cross = sum(1 for i, e in enumerate(ex.plan) for o in ex._entry_io(e)[0]
+                if o in ex._producer and ex.lanes[ex._producer[o]] != ex.lanes[i])
+    assert nwait == (ex.nlanes - 1) + cross
+    assert prog.num_launches >= len(ex.plan) + (2 if strip else 0)
+    big = sum(1 for inf in ex.info if inf.mults >= 10**5)
+    # (a complex step runs as ONE real launch with 4x the multiplications: more of them pass the bar)
+    assert len(prog.marked) == big if np.dtype(dtype).kind != "c" else len(prog.marked) >= big
+    assert recdev.record is None                                         # recording mode is left on every path
+    # the pool: intermediates only (inputs are read in place), far fewer blocks than intermediates where lanes reuse
+    assert prog.pool_bytes < 4 * sum(a.nbytes for a in arrays) + 40 * max(inf.bytes for inf in ex.info)
+    assert all(p in [x._buf.data_ptr() for x in xs] for p in prog._in_ptrs0)
+
+
+def test_pool_reuse_stays_on_the_lane(recdev):
+    """A block goes back to the lane that used it last and is handed out again only there; buffers that cross lanes are
+    never released."""
+    import quimb_amd.program as qp
+
+    log = []
+    alloc0, release0 = qp.RecordPool.alloc, qp.RecordPool.release
+
+    def alloc(self, n, tdtype):
+        t = alloc0(self, n, tdtype)
+        log.append(("a", t.untyped_storage().data_ptr(), self.lane))
+        return t
+
+    def release(self, t):
+        before = len(self.in_use)
+        release0(self, t)
+        if len(self.in_use) != before:
+            log.append(("r", t.untyped_storage().data_ptr(), self.lane))
+
+    qp.RecordPool.alloc, qp.RecordPool.release = alloc, release
+    try:
+        arrays, inputs, size = _network(8, 4, "float32")
+        ex = qa.TreeExecutor(qa.ContractionTree(inputs, (), size, path=qa.quadrant_path_2d(8, 8)), "float32")
+        prog = ex.program([qa.asarray(a) for a in arrays], strip_exponent=True)
+    finally:
+        qp.RecordPool.alloc, qp.RecordPool.release = alloc0, release0
+    owner, reused = {}, 0
+    for what, base, lane in log:
+        if what == "a":
+            if base in owner:
+                assert owner[base] == ("free", lane), (base, owner[base], lane)      # handed out again on the SAME lane only
+                reused += 1
+            owner[base] = ("used", lane)
+        else:
+            assert owner[base][0] == "used"
+            owner[base] = ("free", lane)
+    assert reused > 10 and len(prog._pool.blocks) < len([1 for w, *_ in log if w == "a"])
+
+
+def test_program_refuses_what_it_cannot_record(recdev):
+    arrays, inputs, size = _network(4, 3)
+    tree = qa.find_slices(qa.ContractionTree(inputs, (), size, path=qa.sweep_path_2d(4, 4)), target_slices=3)
+    with pytest.raises(ValueError, match="unsliced"):
+        qa.TreeExecutor(tree, "float32").program([qa.asarray(a) for a in arrays])
+    ex = qa.TreeExecutor(qa.ContractionTree(inputs, (), size, path=qa.sweep_path_2d(4, 4)), "float32")
+    with pytest.raises(ValueError, match="expected 16 arrays"):
+        ex.program([qa.asarray(a) for a in arrays[:-1]])
+    assert recdev.record is None
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype,strip,kind", [("float32", True, "quadrant"), ("float32", False, "quadrant"),
+                                              ("float64", True, "sweep"), ("complex64", True, "quadrant"),
+                                              ("complex128", False, "quadrant")])
+def test_program_replay_matches_launch_by_launch(hip, dtype, strip, kind):
+    checks.check_program_replay(6, 4 if np.dtype(dtype).kind == "c" else 6, dtype, strip, kind)
+
+
+@pytest.mark.gpu
+def test_program_full_size_quadrant_tree(hip):
+    """The headline network through a launch program: the fp64 oracle's value at 1e-6, the two joins on gemmk, the
+    timing marks deliver their durations, ~100 launches with one host call."""
+    import json
+    import os
+
+    ref = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "full_size_oracle.json")))["7"]
+    arrays, inputs, size = _network(10, 6)
+    arrays, _ = orc.tn2d_rand(10, 10, 6, seed=7, dtype="float32")
+    ex = qa.TreeExecutor(qa.ContractionTree(inputs, (), size, path=qa.quadrant_path_2d(10, 10)), "float32")
+    prog = ex.program([qa.asarray(a) for a in arrays], strip_exponent=True, mark_min_mults=10**9)
+    for slot in range(2):
+        m, e = prog(timing_slot=slot)
+        m = m.to_numpy().item()
+        assert np.sign(m) == ref["sign"] and abs(np.log10(abs(m)) + e - ref["log10_abs"]) < np.log10(1.0 + 1e-6)
+    names = [n for (_, _, n, _, _, _) in prog.timings(1)]
+    assert sum(n.startswith("gemmk_kernel") for n in names) == 2, names
+    assert 90 <= prog.num_launches <= 130
