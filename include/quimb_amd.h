@@ -74,7 +74,7 @@ typedef struct {
   int32_t dtype;     /* qamd_dtype                                       */
   int32_t nb, nm, nn, nk;
   int32_t conj_a, conj_b; /* complex only                                */
-  int32_t kernel;    /* filled by finalize: 0 tiled GETT, 1 streaming (big x small), 2 streaming with LDS-transposed stores, 4 few-rows x long-vector reduction (split_k slabs of workspace), 5 k-outer MFMA GETT (gemmk.hip: GEMM-shaped joins, fp32, both free bundles stride-1; tile_cfg = 16 ta + tb names the (64 ta) x (64 tb) workgroup tile; env QAMD_GEMMK=0 keeps 0, QAMD_GEMMK_TILE=<ta><tb> pins the tile); set -1 to force 0 */
+  int32_t kernel;    /* filled by finalize: 0 tiled GETT, 1 streaming (big x small), 2 streaming with LDS-transposed stores, 4 few-rows x long-vector reduction (split_k slabs of workspace), 5 k-outer MFMA GETT (gemmk.hip: GEMM-shaped joins, fp32, both free bundles stride-1; tile_cfg = 16 ta + tb names the (64 ta) x (64 tb) workgroup tile; env QAMD_GEMMK=0 keeps 0, QAMD_GEMMK_TILE=<ta><tb> pins the tile), 6 fp64 MFMA GETT on an LDS-DMA ring (gemmd.hip: GEMM-shaped fp64 contractions with either operand free- or k-contiguous; tile_cfg = 16 ta + tb names the (32 ta) x (64 tb) workgroup tile, split_k the number of k slabs; env QAMD_GEMMD=0 keeps 0, QAMD_GEMMD_TILE=<ta><tb> pins the tile); set -1 to force 0 */
   int64_t dim_b[QAMD_MAX_GROUPS], sa_b[QAMD_MAX_GROUPS], sb_b[QAMD_MAX_GROUPS], sc_b[QAMD_MAX_GROUPS];
   int64_t dim_m[QAMD_MAX_GROUPS], sa_m[QAMD_MAX_GROUPS], sc_m[QAMD_MAX_GROUPS];
   int64_t dim_n[QAMD_MAX_GROUPS], sb_n[QAMD_MAX_GROUPS], sc_n[QAMD_MAX_GROUPS];

@@ -172,6 +172,92 @@ static bool gemmk_config(const qamd_pair_plan* p, const PairDims& d, int64_t ali
   return tiles >= 96 || (te != nullptr);
 }
 
+// ---- gemmd.hip eligibility and tile choice (fp64, LDS-DMA ring, either operand layout) -----------------------------
+// An operand is FREE-contiguous (its innermost free group is stride-1: granules of two consecutive free elements) or
+// K-contiguous (its innermost K group is stride-1: granules of two consecutive k).  Either way the granule group has
+// an even size and every other stride of the operand is even (16-byte granules stay aligned); K % 16 == 0.
+static bool gemmd_operand_ok(bool kcontig, int nfree, const int64_t* dfree, const int64_t* sfree, int nk,
+                             const int64_t* dk, const int64_t* sk, int nb, const int64_t* sb) {
+  if (nfree < 1 || nk < 1) return false;
+  const int gi = kcontig ? nk - 1 : nfree - 1;
+  const int64_t* gd = kcontig ? dk : dfree;
+  const int64_t* gs = kcontig ? sk : sfree;
+  if (gs[gi] != 1 || gd[gi] % 2) return false;
+  for (int g = 0; g < nfree; ++g)
+    if (sfree[g] < 0 || (!(g == nfree - 1 && !kcontig) && sfree[g] % 2)) return false;
+  for (int g = 0; g < nk; ++g)
+    if (sk[g] < 0 || (!(g == nk - 1 && kcontig) && sk[g] % 2)) return false;
+  for (int g = 0; g < nb; ++g)
+    if (sb[g] % 2) return false;
+  return true;
+}
+
+// cost of a (32 ta) x (64 tb) tiling with ``split`` k-slabs: rounds of one workgroup per CU x MFMAs per k-step of a
+// wave, plus what the slab reduction moves; narrow wave tiles read more LDS per MFMA, which fp64's 64-cycle MFMAs
+// mostly forgive
+static double gemmd_model(int64_t M, int64_t N, int64_t K, int64_t B, int ta, int tb, int split) {
+  const int64_t tiles = ((M + 32 * ta - 1) / (32 * ta)) * ((N + 64 * tb - 1) / (64 * tb)) * B * split;
+  const int64_t rounds = (tiles + kNumCU - 1) / kNumCU;
+  const int w = ta * tb;
+  const double eff = w >= 10 ? 0.92 : (w >= 8 ? 0.9 : (w >= 6 ? 0.87 : (w >= 4 ? 0.82 : 0.75)));
+  const double ksteps = (double)((K / 16 + split - 1) / split) + 3.0;          // + prologue / epilogue of a tile
+  double t = (double)rounds * w * ksteps / eff;
+  if (split > 1) t += 0.04 * (double)(split + 1) * (double)(M * N * B) / (256.0 * 64.0);   // slab write + reduce, in MFMA units
+  return t;
+}
+
+// A k-contiguous operand is gathered row by row, so the ORDER of its free groups is the kernel's to choose: put the group
+// that is most contiguous in C innermost.  The lanes of the result tile then run along C's stride-1 index and a store
+// instruction writes 128-byte runs (the chi = 512 matvec's first product writes its result as [S1, p, S2, B, a] with the
+// free bundle of L = (a, p): 42 MB of 8-byte stores 4 KB apart before this, 157 us; 16 consecutive a per store after).
+static void gemmd_order_for_stores(qamd_pair_plan* p) {
+  auto to_back = [](int n, int64_t* dim, int64_t* s_op, int64_t* s_c) {
+    int best = n - 1;
+    for (int g = 0; g < n; ++g)
+      if (s_c[g] > 0 && (s_c[best] <= 0 || s_c[g] < s_c[best])) best = g;
+    for (int g = best; g + 1 < n; ++g) {
+      std::swap(dim[g], dim[g + 1]);
+      std::swap(s_op[g], s_op[g + 1]);
+      std::swap(s_c[g], s_c[g + 1]);
+    }
+  };
+  if (p->a_kcontig && p->nm > 1) to_back(p->nm, p->dim_m, p->sa_m, p->sc_m);
+  if (p->b_kcontig && p->nn > 1) to_back(p->nn, p->dim_n, p->sb_n, p->sc_n);
+  const bool n1 = p->nn > 0 && p->sc_n[p->nn - 1] == 1;
+  const bool m1 = p->nm > 0 && p->sc_m[p->nm - 1] == 1;
+  p->c_ncontig = (n1 || !m1) ? 1 : 0;
+}
+
+static bool gemmd_config(const qamd_pair_plan* p, const PairDims& d, int64_t align_a, int64_t align_b, int& ta, int& tb,
+                         int& split) {
+  const char* e = getenv("QAMD_GEMMD");
+  if (e && atoi(e) == 0) return false;
+  if (p->dtype != QAMD_F64) return false;
+  const char* te = getenv("QAMD_GEMMD_TILE");   // e.g. 54: pin (ta, tb) -- and take every shape the kernel can run
+  if (d.K % 16 || d.K < (te ? 16 : 64) || d.M < (te ? 2 : 64) || d.N < (te ? 2 : 64) || d.M % 2 || d.N % 2) return false;
+  if (p->nk < 1 || p->dim_k[p->nk - 1] % 16) return false;     // a k-tile (16 rows) stays inside the innermost K group
+  if ((align_a % 16) || (align_b % 16)) return false;
+  if (!gemmd_operand_ok(p->a_kcontig, p->nm, p->dim_m, p->sa_m, p->nk, p->dim_k, p->sa_k, p->nb, p->sa_b) ||
+      !gemmd_operand_ok(p->b_kcontig, p->nn, p->dim_n, p->sb_n, p->nk, p->dim_k, p->sb_k, p->nb, p->sb_b))
+    return false;
+  const bool compact = c_extent(p) == d.B * d.M * d.N;   // the slab reduction needs a compact C
+  double best = 0;
+  ta = tb = 0;
+  split = 1;
+  for (int a = 2; a <= 5; ++a)
+    for (int b = 1; b <= 2; ++b) {
+      if (te && atoi(te) != 10 * a + b) continue;
+      for (int s = 1; s <= 16; s *= 2) {
+        if (s > 1 && (!compact || d.K / 16 / s < 8)) break;
+        const double t = gemmd_model(d.M, d.N, d.K, d.B, a, b, s);
+        if (!ta || t < best) { best = t; ta = a; tb = b; split = s; }
+      }
+    }
+  if (!ta) return false;
+  const int64_t tiles = ((d.M + 32 * ta - 1) / (32 * ta)) * ((d.N + 64 * tb - 1) / (64 * tb)) * d.B * split;
+  return tiles >= 64 || te != nullptr;       // tiny grids keep the generic kernels
+}
+
 extern "C" int qamd_pair_plan_finalize(qamd_pair_plan* p, int64_t align_a, int64_t align_b, int64_t align_c) {
   PairDims d;
   int rc = pair_dims(p, d);
@@ -266,6 +352,15 @@ extern "C" int qamd_pair_plan_finalize(qamd_pair_plan* p, int64_t align_a, int64
         p->kernel = 5;
         p->tile_cfg = 16 * ta + tb;
         p->split_k = 1;
+        return QAMD_OK;
+      }
+      // kernel 6 (gemmd.hip): fp64, GEMM-shaped, either operand layout
+      int split = 1;
+      if (gemmd_config(p, d, align_a, align_b, ta, tb, split)) {
+        gemmd_order_for_stores(p);
+        p->kernel = 6;
+        p->tile_cfg = 16 * ta + tb;
+        if (p->split_k < 1 || c_extent(p) != d.B * d.M * d.N) p->split_k = split;     // (a caller's split is kept)
         return QAMD_OK;
       }
     }
@@ -490,6 +585,55 @@ static int launch_gemmk(const qamd_pair_plan* p, const PairDims& d, const void* 
   return qamd_gemmk_launch(ta, tb, &a, swap ? B : A, swap ? A : B, C, sa, sb, ep ? ep->absmax_out : nullptr, stream);
 }
 
+extern "C" int qamd_gemmd_launch(int ta, int tb, const GettArgs* a, int swap, const void* A, const void* B, void* C,
+                                 const void* ktab, const void* scale_a, const void* scale_b, void* absmax_out,
+                                 void* stream);
+
+static int launch_gemmd(const qamd_pair_plan* p, const PairDims& d, const void* A, const void* B, void* C,
+                        const void* ktab, void* ws, int64_t ws_bytes, const qamd_epilogue* ep, void* stream) {
+  const int ta = p->tile_cfg / 16, tb = p->tile_cfg % 16;
+  if (ta < 2 || ta > 5 || tb < 1 || tb > 2 || p->dtype != QAMD_F64 || !A || !B || !C || !ktab || p->split_k < 1)
+    return QAMD_EINVAL;
+  if (((uintptr_t)A & 15) || ((uintptr_t)B & 15) || d.K % 16) return QAMD_EINVAL;
+  GettArgs a;
+  memset(&a, 0, sizeof(a));
+  a.nb = p->nb; a.nm = p->nm; a.nn = p->nn; a.nk = p->nk;
+  for (int i = 0; i < p->nb; ++i) {
+    a.dim_b[i] = (uint32_t)p->dim_b[i];
+    a.sa_b[i] = p->sa_b[i]; a.sb_b[i] = p->sb_b[i]; a.sc_b[i] = p->sc_b[i];
+  }
+  for (int i = 0; i < p->nm; ++i) { a.dim_m[i] = (uint32_t)p->dim_m[i]; a.sa_m[i] = p->sa_m[i]; a.sc_m[i] = p->sc_m[i]; }
+  for (int i = 0; i < p->nn; ++i) { a.dim_n[i] = (uint32_t)p->dim_n[i]; a.sb_n[i] = p->sb_n[i]; a.sc_n[i] = p->sc_n[i]; }
+  for (int i = 0; i < p->nk; ++i) { a.dim_k[i] = (uint32_t)p->dim_k[i]; a.sa_k[i] = p->sa_k[i]; a.sb_k[i] = p->sb_k[i]; }
+  a.B = (uint32_t)d.B; a.M = (uint32_t)d.M; a.N = (uint32_t)d.N; a.K = (uint32_t)d.K;
+  a.Kpad = (uint32_t)kpad_of(d.K);
+  a.Kloop = a.K;
+  const int64_t ksteps = d.K / 16;
+  int split = (int)std::min<int64_t>(p->split_k, ksteps);
+  const int64_t steps_per = (ksteps + split - 1) / split;
+  split = (int)((ksteps + steps_per - 1) / steps_per);
+  a.Kc = (uint32_t)(steps_per * 16);
+  a.split_k = (uint32_t)split;
+  a.tiles_m = (uint32_t)((d.M + 32 * ta - 1) / (32 * ta));
+  a.tiles_n = (uint32_t)((d.N + 64 * tb - 1) / (64 * tb));
+  a.a_kcontig = p->a_kcontig; a.b_kcontig = p->b_kcontig;
+  const int swap = p->c_ncontig ? 0 : 1;
+  const void* sa = ep ? ep->scale_a : nullptr;
+  const void* sb = ep ? ep->scale_b : nullptr;
+  void* amax = ep ? ep->absmax_out : nullptr;
+  if (split == 1) {
+    a.slab_stride = 0;
+    return qamd_gemmd_launch(ta, tb, &a, swap, A, B, C, ktab, sa, sb, amax, stream);
+  }
+  const int64_t csz = d.B * d.M * d.N;
+  if (c_extent(p) != csz) return QAMD_EUNSUPPORTED;  // split-K needs a compact C
+  if (!ws || ws_bytes < (int64_t)split * csz * 8) return QAMD_EWORKSPACE;
+  a.slab_stride = csz;
+  int rc = qamd_gemmd_launch(ta, tb, &a, swap, A, B, ws, ktab, nullptr, nullptr, nullptr, stream);
+  if (rc) return rc;
+  return qamd_splitk_reduce_launch(p->dtype, C, ws, csz, split, sa, sb, amax, stream);
+}
+
 extern "C" int qamd_contract_pair_ex(const qamd_pair_plan* p, const void* A, const void* B, void* C,
                                      const void* ktab, void* ws, int64_t ws_bytes, const qamd_epilogue* ep,
                                      void* stream) {
@@ -499,6 +643,7 @@ extern "C" int qamd_contract_pair_ex(const qamd_pair_plan* p, const void* A, con
   if (rc) return rc;
   if (p->dtype != QAMD_F32 && p->dtype != QAMD_F64) return QAMD_EUNSUPPORTED;
   if (p->kernel == 5) return launch_gemmk(p, d, A, B, C, ep, stream);
+  if (p->kernel == 6) return launch_gemmd(p, d, A, B, C, ktab, ws, ws_bytes, ep, stream);
   if (p->tile_cfg < 0 || p->tile_cfg >= kNumTileCfg || p->split_k < 1) return QAMD_EINVAL;
   if (!A || !B || !C || !ktab) return QAMD_EINVAL;
   if (p->kernel == 1 || p->kernel == 2) return launch_stream(p, d, A, B, C, ktab, ep, stream);
@@ -842,6 +987,11 @@ extern "C" int qamd_pair_describe(const qamd_pair_plan* p, char* buf, int32_t bu
   if (p->kernel == 5) {
     const int ta = p->tile_cfg / 16, tb = p->tile_cfg % 16;
     snprintf(buf, buflen, "gemmk_kernel<%d, %d, 3, %d>", ta, tb, ta * tb <= 6 ? 2 : 1);
+    return QAMD_OK;
+  }
+  if (p->kernel == 6) {
+    snprintf(buf, buflen, "gemmd_kernel<%d, %d, %s, %s, %s> split_k=%d", p->tile_cfg / 16, p->tile_cfg % 16,
+             p->a_kcontig ? "true" : "false", p->b_kcontig ? "true" : "false", p->c_ncontig ? "false" : "true", p->split_k);
     return QAMD_OK;
   }
   if (p->kernel == 1 || p->kernel == 2) {

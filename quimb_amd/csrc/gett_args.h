@@ -23,6 +23,10 @@ struct GettArgs {
   int32_t tail_first;   // gemmk.hip: first tile of the k-split tail (>= tiles: no tail)
   int32_t tail_split;   // gemmk.hip: k parts per tail tile
   int32_t pad_;
+  // gemmd.hip: the K groups themselves (k offsets are computed in registers, not read from the k-offset table: a
+  // table read in the request path would tie the request counter to ordinary loads)
+  uint32_t dim_k[QAMD_G];
+  int64_t sa_k[QAMD_G], sb_k[QAMD_G];
 };
 
 // "big tensor x small tensor" streaming kernel (stream.hip)

@@ -546,6 +546,61 @@ def check_gemmk(seed=21, tiles=(None,)):
                 dev._pairs.clear()
 
 
+GEMMD_CASES = [
+    # GEMM-shaped fp64 contractions -> gemmd_kernel (gemmd.hip); every operand-layout combination, K % 16 == 0
+    ("mk,kn->mn", dict(m=260, k=64, n=132)),            # A k-contiguous, B free-contiguous, ragged edges on both sides
+    ("km,kn->mn", dict(m=200, k=80, n=96)),             # both free-contiguous (swizzled images)
+    ("mk,nk->mn", dict(m=136, k=96, n=150)),            # both k-contiguous (gathered granules)
+    ("km,nk->mn", dict(m=128, k=128, n=66)),            # A free-contiguous, B k-contiguous
+    ("mk,kn->nm", dict(m=192, k=64, n=100)),            # C m-contiguous: MFMA operand roles swap
+    ("apA,Astb->apstb", dict(a=32, p=5, A=64, s=2, t=2, b=24)),      # the DMRG matvec's first product, scaled down
+    ("arstB,brB->astb", dict(a=24, r=5, s=2, t=2, B=48, b=70)),      # ... and its last: K = (r, B) in two groups, split-K
+    ("bmk,bkn->bmn", dict(b=3, m=96, k=64, n=128)),     # batch bundle
+    ("mk,kn->mn", dict(m=64, k=1024, n=64)),            # one tile, long K: k slabs + the slab reduction
+    ("xmk,kn->xmn", dict(x=2, m=70, k=48, n=64)),       # K = 48: three k-tiles exactly (the ring's prologue alone)
+    ("mk,kn->mn", dict(m=66, k=16, n=64)),              # K = 16: ONE k-tile (below the planner's bar: pinned tiles only)
+]
+
+
+def check_gemmd(seed=31, tiles=(None,)):
+    """fp64 MFMA GETT on the LDS-DMA ring.  ``tiles``: values of QAMD_GEMMD_TILE to pin (None = the planner's choice);
+    also run with the fused exponent epilogue (scales in, absmax out) through a two-step tree."""
+    import os
+
+    rng = np.random.default_rng(seed)
+    dev = qa.default_device()
+    for tile in tiles:
+        if tile is None:
+            os.environ.pop("QAMD_GEMMD_TILE", None)
+        else:
+            os.environ["QAMD_GEMMD_TILE"] = str(tile)
+        if hasattr(dev, "_pairs"):
+            dev._pairs.clear()
+        try:
+            for eq, dims in GEMMD_CASES:
+                lhs, out = eq.split("->")
+                ai, bi = lhs.split(",")
+                a = rand(rng, [dims[c] for c in ai], "float64")
+                b = rand(rng, [dims[c] for c in bi], "float64")
+                want = np.einsum(eq, a, b)
+                got = qa.einsum(eq, qa.asarray(a), qa.asarray(b)).to_numpy()
+                bound = 1e-13 * np.max(np.einsum(eq, np.abs(a), np.abs(b)))
+                err = np.max(np.abs(got - want))
+                assert got.shape == want.shape and err <= bound, (eq, tile, err, bound)
+        finally:
+            os.environ.pop("QAMD_GEMMD_TILE", None)
+            if hasattr(dev, "_pairs"):
+                dev._pairs.clear()
+    # the fused strip_exponent epilogue: (A . B) . C with every result normalised on the way
+    a, b, c = rand(rng, (96, 160), "float64") * 1e40, rand(rng, (160, 128), "float64") * 1e-25, rand(rng, (128, 80), "float64")
+    inputs = [("i", "k"), ("k", "j"), ("j", "l")]
+    tree = qa.ContractionTree(inputs, ("i", "l"), dict(i=96, k=160, j=128, l=80), path=[(0, 1), (0, 1)])
+    m, e = qa.TreeExecutor(tree, "float64")([a, b, c], strip_exponent=True)
+    want = a @ b @ c
+    np.testing.assert_allclose(m.to_numpy() * 10.0**e, want, rtol=0, atol=1e-12 * np.max(np.abs(want)))
+    assert np.max(np.abs(m.to_numpy())) == pytest.approx(1.0, rel=1e-12)
+
+
 # ---------------------------------------------------------------------------
 # golden vectors generated by the real quimb (tests/golden/make_golden.py)
 # ---------------------------------------------------------------------------

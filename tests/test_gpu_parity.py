@@ -86,6 +86,23 @@ def test_gemmk(hip):
     assert {n for n in pinned} >= {f"gemmk_kernel<{a}, {b}, 3, {2 if a * b <= 6 else 1}>" for a in (2, 3, 4) for b in (2, 3, 4)}
 
 
+def test_gemmd(hip):
+    """fp64 MFMA GETT on the LDS-DMA ring (gemmd.hip): k-contiguous and free-contiguous operands in every combination,
+    ragged edges, swapped roles, K in two groups, batch, k slabs -- with the planner's tile and with workgroup tiles
+    pinned; the fused exponent epilogue."""
+    hip.profile = []
+    try:
+        checks.check_gemmd(tiles=(None, 42, 52, 32, 22, 41, 51, 31, 21))
+        names = [n for (_, _, n, _, _, _) in hip.profile]
+    finally:
+        hip.profile = None
+    n0 = len(checks.GEMMD_CASES)
+    pinned = names[n0:n0 * 9]               # (the planner leaves shapes this small to the generic kernels: first pass)
+    assert len(pinned) == 8 * n0 and all(n.startswith("gemmd_kernel") for n in pinned), \
+        [n for n in pinned if not n.startswith("gemmd_kernel")]
+    assert any("split_k=" in n and not n.endswith("split_k=1") for n in names), names
+
+
 @pytest.mark.parametrize("Lx,Ly,D", [(6, 6, 4), (8, 8, 2), (5, 8, 4), (3, 8, 6), (3, 9, 6)])
 def test_fused_triples(hip, Lx, Ly, D):
     """Three adjacent interior site absorptions in ONE launch (chain3 kernel, chunk state exchanged through

@@ -70,3 +70,39 @@ def test_what_gemmk_does_not_cover_keeps_the_older_kernels():
     # tensor addressing: free bundles of two groups each, batch bundle
     assert k5("kab", (256, 32, 64), "kcd", (256, 64, 32), "acbd")
     assert k5("bkm", (3, 512, 1024), "bkn", (3, 512, 1024), "bmn")
+
+
+# ---- round 4: the fp64 kernel on the LDS-DMA ring (gemmd.hip) ------------------------------------------------------------
+def test_fp64_gemm_shapes_take_gemmd():
+    """The two GEMM-shaped products of the chi = 512 effective-Hamiltonian matvec (BASELINE config #5) in the layouts the
+    executor gives them, and square GEMMs in every operand layout: the tile that makes ONE round of 256 CUs, k slabs where
+    the grid is under-filled, the store order re-arranged for a k-contiguous operand."""
+    chi, w, d = 512, 5, 2
+    # first product: L[a, p, A] . x[A, S1, S2, B]  (A k-contiguous in L), result written as [S1, p, S2, B, a]
+    name, p = _describe("apA", (chi, w, chi), "AstB", (chi, d, d, chi), "sptBa", dtype="float64")
+    assert p.kernel == 6 and name == "gemmd_kernel<5, 2, true, false, true> split_k=1", name      # 160 x 128: 16 x 16 tiles
+    assert (p.dim_m[p.nm - 1], p.sc_m[p.nm - 1]) == (chi, 1)       # a -- C's stride-1 index -- moved innermost in M: lanes store runs
+    # last product: T[r, B, a, s1, s2] . R[b, r, B]: K = (r, B), 64 tiles of 128 x 128 -> 4 k slabs
+    name, p = _describe("rBast", (w, chi, chi, d, d), "brB", (chi, w, chi), "astb", dtype="float64")
+    assert p.kernel == 6 and name == "gemmd_kernel<4, 2, false, true, false> split_k=4", name
+    for a_inds, b_inds in (("mk", "kn"), ("km", "kn"), ("mk", "nk"), ("km", "nk")):
+        shape = lambda t: tuple(4096 for _ in t)
+        name, p = _describe(a_inds, shape(a_inds), b_inds, shape(b_inds), "mn", dtype="float64")
+        assert p.kernel == 6 and name.startswith("gemmd_kernel<4, 2,") and p.split_k == 1, name
+        assert (p.a_kcontig, p.b_kcontig) == (int(a_inds == "mk"), int(b_inds == "nk"))
+
+
+def test_what_gemmd_does_not_cover():
+    k6 = lambda *a, **kw: _describe(*a, dtype=kw.pop("dtype", "float64"), **kw)[1].kernel == 6
+    assert k6("mk", (2048, 512), "kn", (512, 2048), "mn")
+    assert not k6("mk", (2048, 512), "kn", (512, 2048), "mn", dtype="float32")            # fp64 only
+    assert not k6("mk", (2048, 520), "kn", (520, 2048), "mn")                              # K % 16
+    assert not k6("mk", (2048, 48), "kn", (48, 2048), "mn")                                # K < 64
+    assert not k6("mk", (2047, 512), "kn", (512, 2048), "mn")                              # odd M: granules of two elements
+    assert not k6("mk", (2048, 512), "kn", (512, 2048), "mn", env={"QAMD_GEMMD": "0"})    # switched off
+    assert not k6("mk", (2048, 512), "kn", (512, 2048), "mn", aligns=(8, 16, 16))         # operand not 16-byte aligned
+    assert not k6("mk", (128, 512), "kn", (512, 128), "mn")                                # tiny grid: the generic kernels
+    assert not k6("muk", (2048, 32, 24), "ukn", (32, 24, 2048), "mn")                      # innermost K group not a multiple of 16
+    assert k6("muk", (2048, 24, 32), "ukn", (24, 32, 2048), "mn")                          # ... outer K groups are free
+    name, p = _describe("mk", (128, 512), "kn", (512, 128), "mn", dtype="float64", env={"QAMD_GEMMD_TILE": "21"})
+    assert p.kernel == 6 and name.startswith("gemmd_kernel<2, 1, true, false, false>")     # pinning overrides the floors
