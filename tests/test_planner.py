@@ -102,7 +102,8 @@ def test_what_gemmd_does_not_cover():
     assert not k6("mk", (2048, 512), "kn", (512, 2048), "mn", env={"QAMD_GEMMD": "0"})    # switched off
     assert not k6("mk", (2048, 512), "kn", (512, 2048), "mn", aligns=(8, 16, 16))         # operand not 16-byte aligned
     assert not k6("mk", (128, 512), "kn", (512, 128), "mn")                                # tiny grid: the generic kernels
-    assert not k6("muk", (2048, 32, 24), "ukn", (32, 24, 2048), "mn")                      # innermost K group not a multiple of 16
-    assert k6("muk", (2048, 24, 32), "ukn", (24, 32, 2048), "mn")                          # ... outer K groups are free
+    # K in two groups that cannot fuse (their order differs between the operands): the innermost one holds the k-tiles
+    assert not k6("muk", (2048, 32, 24), "kun", (24, 32, 2048), "mn")                      # ... 24: not a multiple of 16
+    assert k6("muk", (2048, 24, 32), "kun", (32, 24, 2048), "mn")                          # ... 32: fine, the outer group is free
     name, p = _describe("mk", (128, 512), "kn", (512, 128), "mn", dtype="float64", env={"QAMD_GEMMD_TILE": "21"})
     assert p.kernel == 6 and name.startswith("gemmd_kernel<2, 1, true, false, false>")     # pinning overrides the floors
