@@ -23,6 +23,7 @@ import numpy as np
 
 from .array import Array, asarray
 from .executor import TreeExecutor
+from .ops import einsum_pair
 from .pairwise import prod
 from .pathfind import find_path, find_slices
 from .tree import ContractionTree  # noqa: F401  (re-exported: quimb_amd.contract.ContractionTree)
@@ -138,11 +139,15 @@ class ContractExpression:
     """Callable ``expr(*arrays, backend=None)`` bound to one tree + dtype."""
 
     def __init__(self, tree, dtype, strip_exponent=False, constants=None):
-        self.tree = tree
-        self.executor = TreeExecutor(tree, dtype)
         self.strip_exponent = strip_exponent
         self.constants = dict(constants or {})
         self._const_dev = {k: asarray(v).astype(dtype) for k, v in self.constants.items()}
+        self._ninputs = len(tree.inputs)
+        self._order = None          # position in the caller's input list -> position in the executed tree's
+        if self._const_dev and not strip_exponent and tree.nslices == 1 and os.environ.get("QAMD_FOLD_CONSTANTS", "1") != "0":
+            tree = self._fold_constants(tree, dtype)
+        self.tree = tree
+        self.executor = TreeExecutor(tree, dtype)
         # trees of many small tensors (circuit amplitudes) are dispatch-bound step by step: let the device walk
         # them in one launch (MicroTree) -- same plan, same arithmetic order per step; QAMD_MICROTREE=0 opts out
         self._micro = None
@@ -155,9 +160,62 @@ class ContractExpression:
             except ValueError:
                 self._micro = None
 
+    def _fold_constants(self, tree, dtype):
+        """Contract, once, every sub-tree whose leaves are all constants (cotengra does the same for the
+        ``constants=`` of ``array_contract_expression``: quimb names a ``TNLinearOperator``'s own tensors that way,
+        quimb/tensor/tensor_core.py:12378-12381): the product of two MPO tensors of a DMRG effective Hamiltonian is
+        not recomputed per matvec.  Returns the reduced tree; ``self._const_dev`` / ``self._order`` are re-keyed to
+        its inputs."""
+        if os.environ.get("QAMD_REGROUP", "1") != "0":
+            tree = tree.regrouped()            # (the executor would do this anyway: it can create constant-only products)
+        n = len(tree.inputs)
+        const = set(self._const_dev)
+        val = dict(self._const_dev)            # ssa id -> device array of constant (sub-)results
+        inds = {i: tuple(t) for i, t in enumerate(tree.inputs)}
+        folded = set()
+        for si, (con, res, ops_, keep, _) in enumerate(tree.steps):
+            inds[res] = tuple(keep)
+            if len(con) == 2 and all(c in const for c in con):
+                a, b = con
+                out, _ = einsum_pair(val[a], inds[a], val[b], inds[b], tuple(keep), True)
+                val[res] = out
+                const.add(res)
+                folded.add(si)
+        if not folded:
+            return tree
+        # inputs of the reduced tree: what the kept steps still consume that is an original input or a folded result
+        kept = [st for si, st in enumerate(tree.steps) if si not in folded]
+        needed = {c for con, _, _, _, _ in kept for c in con if c < n or (c - n) in folded}
+        if not kept:                        # the whole network is constant: one input, no steps
+            needed = set(tree.remaining)
+        needed = list(needed)
+        needed.sort()
+        new_id = {c: i for i, c in enumerate(needed)}
+        m = len(needed)
+        ssa = []
+        for k, (con, res, _, _, _) in enumerate(kept):
+            new_id[res] = m + k
+            ssa.append(tuple(new_id[c] for c in con))
+        new_tree = ContractionTree([inds[c] for c in needed], tree.output, tree.size_dict, ssa_path=ssa)
+        self._order = [new_id.get(i) for i in range(n)]          # None: folded away
+        self._const_dev = {new_id[c]: val[c] for c in needed if c in val}
+        self._ninputs_exec = m
+        return new_tree
+
     def __call__(self, *arrays, backend=None, slices=None):
         _check_backend(backend)
-        if self._const_dev:
+        if self._order is not None:
+            # the caller's non-constant arrays, in the caller's order, land on the reduced tree's inputs
+            it = iter(arrays)
+            slots = [None] * self._ninputs_exec
+            for i in range(self._ninputs):
+                if i in self.constants:
+                    continue
+                x = next(it)
+                if self._order[i] is not None:
+                    slots[self._order[i]] = x
+            arrays = [self._const_dev[j] if slots[j] is None else slots[j] for j in range(self._ninputs_exec)]
+        elif self._const_dev:
             it = iter(arrays)
             n = len(self.tree.inputs)
             arrays = [self._const_dev[i] if i in self._const_dev else next(it) for i in range(n)]

@@ -157,7 +157,10 @@ class ContractionTree:
         Site-by-site absorption orders (``sweep_path_2d``, or any path found on the unsliced network) stay
         optimal while every site tensor has all its legs; once a bond next to two neighbouring sites is
         sliced away, contracting the two small tensors first makes ONE pass over the big operand instead
-        of two -- fewer multiplications and a third of the HBM traffic.  Only consecutive steps are
+        of two -- fewer multiplications and a third of the HBM traffic.  The same rewrite is taken where it costs no more
+        multiplications (within 2 %) and moves a quarter less data -- two THIN absorptions in a row (product of the two small
+        tensors <= 1024 elements with indices of MIXED sizes: MPO tensors, gates; site tensors of a uniform-bond lattice are
+        left to the fused-pair kernels, which make the same single pass without the extra product).  Only consecutive steps are
         rewritten, and only where the two steps' multiplications drop below ``gain`` x their old count (the
         caller's tree is otherwise executed as given); the small product is capped at ``max_small`` elements, and the result is the same
         tensor (contraction is associative); ids, inputs and output are unchanged."""
@@ -174,7 +177,7 @@ class ContractionTree:
                 if w2 < r1:
                     # local evaluation (no tree rebuild): only the two steps' index sets matter.  An index of
                     # W1 u W2 survives into W12 iff A or the pair's final result still carries it.
-                    _, _, ops1, _, m1 = best.steps[si]
+                    _, _, ops1, keep1, m1 = best.steps[si]
                     _, _, ops2, keep2, m2 = best.steps[si + 1]
                     w2_inds = set(ops2[0] if c2[1] == r1 else ops2[1])
                     final = set(keep2)
@@ -184,7 +187,15 @@ class ContractionTree:
                         w12 = pair & (a_set | final)
                         small = prod(size[ix] for ix in w12)
                         cost = prod(size[ix] for ix in pair) + prod(size[ix] for ix in a_set | w12)
-                        if small <= max_small and cost < gain * (m1 + m2):
+                        # ... or where it costs no more multiplications and HALVES the traffic: two thin absorptions in a
+                        # row (MPO tensors on a DMRG effective Hamiltonian: K = N = 10 each) read and write the big
+                        # tensor twice; one application of the 20 x 20 product reads and writes it once
+                        elems_before = prod(size[ix] for ix in a_set) + 2 * prod(size[ix] for ix in keep1) + \
+                            prod(size[ix] for ix in keep2)
+                        elems_after = prod(size[ix] for ix in a_set) + prod(size[ix] for ix in keep2) + 2 * small
+                        thin = (small <= 1024 and cost <= 1.02 * (m1 + m2) and elems_after < 0.75 * elems_before
+                                and len({size[ix] for ix in pair}) > 1)    # uniform bonds: the fused-pair kernels' case
+                        if small <= max_small and (cost < gain * (m1 + m2) or thin):
                             trial = list(ssa)
                             trial[si], trial[si + 1] = (w1, w2), (a, r1)
                             best = ContractionTree(self.inputs, self.output, self.size_dict, ssa_path=trial,

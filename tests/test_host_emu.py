@@ -442,3 +442,38 @@ def test_round4_sharded_workload_checks_on_the_interpreter(emu):
     checks.check_sharded_quadrants(4, 4, 6, 6, "float64", 3)
     checks.check_range_sliced_found_tree(4, 4, "float64", seed=12, nslices=(2, 4))
     checks.check_complex_strip_exponent_lanes("complex128", L=6, D=2)
+
+
+def test_constants_are_folded_once(emu):
+    import quimb_amd as qa
+
+    """``array_contract_expression(constants=...)`` contracts constant-only sub-trees ONCE, as cotengra does for the
+    constants quimb names (a ``TNLinearOperator``'s own tensors, quimb/tensor/tensor_core.py:12378-12381): the two MPO
+    tensors of a DMRG effective Hamiltonian become one 20 x 20 tensor at construction (the thin-absorption regrouping
+    makes their product a step of its own), every call applies it; values unchanged, argument order unchanged."""
+    rng = np.random.default_rng(3)
+    chi, w, d = 20, 5, 2
+    L, R = rng.normal(size=(chi, w, chi)), rng.normal(size=(chi, w, chi))
+    W1, W2 = rng.normal(size=(w, w, d, d)), rng.normal(size=(w, w, d, d))
+    inputs = [("a", "p", "A"), ("p", "q", "s1", "S1"), ("q", "r", "s2", "S2"), ("b", "r", "B"), ("A", "S1", "S2", "B")]
+    shapes = [L.shape, W1.shape, W2.shape, R.shape, (chi, d, d, chi)]
+    consts = {0: L, 1: W1, 2: W2, 3: R}
+    expr = qa.array_contract_expression(inputs, ("a", "s1", "s2", "b"), shapes=shapes, optimize="random-greedy",
+                                        dtype="float64", constants=consts, cache=False)
+    plain = qa.array_contract_expression(inputs, ("a", "s1", "s2", "b"), shapes=shapes, optimize="random-greedy",
+                                         dtype="float64", cache=False)
+    assert len(expr.tree.inputs) == 4 and len(expr.tree.steps) == 3 and len(plain.tree.steps) == 4
+    for _ in range(2):
+        x = rng.normal(size=(chi, d, d, chi))
+        want = np.einsum("apA,pqsS,qrtT,brB,ASTB->astb", L, W1, W2, R, x)
+        np.testing.assert_allclose(np.asarray(expr(x)), want, rtol=0, atol=1e-11 * np.abs(want).max())
+        np.testing.assert_allclose(np.asarray(plain(L, W1, W2, R, x)), want, rtol=0, atol=1e-11 * np.abs(want).max())
+    # constants in the MIDDLE of the argument list, a variable on either side; and a network of constants only
+    expr2 = qa.array_contract_expression([("i", "j"), ("j", "k"), ("k", "l"), ("l", "m")], ("i", "m"),
+                                         shapes=[(3, 4), (4, 5), (5, 6), (6, 2)], optimize="greedy", dtype="float64",
+                                         constants={1: np.ones((4, 5)), 2: np.full((5, 6), 2.0)}, cache=False)
+    a, b = rng.normal(size=(3, 4)), rng.normal(size=(6, 2))
+    np.testing.assert_allclose(np.asarray(expr2(a, b)), a @ np.ones((4, 5)) @ np.full((5, 6), 2.0) @ b, rtol=1e-12)
+    expr3 = qa.array_contract_expression([("i", "j"), ("j", "k")], ("k", "i"), shapes=[(3, 4), (4, 5)], optimize="greedy",
+                                         dtype="float64", constants={0: a, 1: np.ones((4, 5))}, cache=False)
+    np.testing.assert_allclose(np.asarray(expr3()), (a @ np.ones((4, 5))).T, rtol=1e-12)
