@@ -202,23 +202,32 @@ class ContractExpression:
         self._ninputs_exec = m
         return new_tree
 
-    def __call__(self, *arrays, backend=None, slices=None):
-        _check_backend(backend)
+    def exec_inputs(self, arrays):
+        """The executed tree's input list for the caller's (non-constant) ``arrays`` -- constants and folded products
+        filled in -- and, per caller array, its position in that list (``None``: folded away, cannot happen for a
+        non-constant)."""
+        arrays = list(arrays)
         if self._order is not None:
-            # the caller's non-constant arrays, in the caller's order, land on the reduced tree's inputs
             it = iter(arrays)
             slots = [None] * self._ninputs_exec
+            where = []
             for i in range(self._ninputs):
                 if i in self.constants:
                     continue
-                x = next(it)
-                if self._order[i] is not None:
-                    slots[self._order[i]] = x
-            arrays = [self._const_dev[j] if slots[j] is None else slots[j] for j in range(self._ninputs_exec)]
-        elif self._const_dev:
+                slots[self._order[i]] = next(it)
+                where.append(self._order[i])
+            return [self._const_dev[j] if slots[j] is None else slots[j] for j in range(self._ninputs_exec)], where
+        if self._const_dev:
             it = iter(arrays)
             n = len(self.tree.inputs)
-            arrays = [self._const_dev[i] if i in self._const_dev else next(it) for i in range(n)]
+            where = [i for i in range(n) if i not in self._const_dev]
+            return [self._const_dev[i] if i in self._const_dev else next(it) for i in range(n)], where
+        return arrays, list(range(len(arrays)))
+
+    def __call__(self, *arrays, backend=None, slices=None):
+        _check_backend(backend)
+        if self._const_dev:
+            arrays, _ = self.exec_inputs(arrays)
         host_in = not any(isinstance(a, Array) for a in arrays if not any(a is c for c in self._const_dev.values()))
         if self._micro is not None and slices is None:
             out = self._micro(arrays)

@@ -555,6 +555,20 @@ class TreeExecutor:
                 ex = self._plain_order_twin = TreeExecutor(self.tree, self.dtype, join_order=False)
         return ContractionProgram(ex, arrays, strip_exponent, mark_min_mults)
 
+    def check_inputs(self, arrays):
+        """The arrays as device arrays of the plan's dtype -- after checking that there is one per input of the tree, of
+        the size the tree says.  EVERY way into ``_run_core`` goes through here: a plan run on arrays of other shapes
+        launches kernels on addresses those arrays do not have."""
+        tree = self.tree
+        if len(arrays) != len(tree.inputs):
+            raise ValueError(f"expected {len(tree.inputs)} arrays, got {len(arrays)}")
+        xs = [asarray(x).astype(self.dtype) for x in arrays]
+        for x, t in zip(xs, tree.inputs):
+            want = tuple(tree.size_dict[ix] for ix in t)
+            if x.shape != want:
+                raise ValueError(f"array shape {x.shape} does not match indices {t} with sizes {want}")
+        return xs
+
     def graph(self, arrays, strip_exponent=False):
         """Capture one whole (unsliced) contraction into a HIP graph and return a
         ``GraphedContraction``: ``g.replay()`` re-launches the recorded kernel sequence
@@ -619,13 +633,7 @@ class TreeExecutor:
         the exponent comes back as the device-resident accumulator instead of a float, so the call does not
         synchronise with the device -- ``dev.read_exponent(e)`` reads it later."""
         tree = self.tree
-        if len(arrays) != len(tree.inputs):
-            raise ValueError(f"expected {len(tree.inputs)} arrays, got {len(arrays)}")
-        xs = [asarray(x).astype(self.dtype) for x in arrays]
-        for x, t in zip(xs, tree.inputs):
-            want = tuple(tree.size_dict[ix] for ix in t)
-            if x.shape != want:
-                raise ValueError(f"array shape {x.shape} does not match indices {t} with sizes {want}")
+        xs = self.check_inputs(arrays)
         dev = xs[0]._dev
         nsl = tree.nslices
         if slices is not None:
@@ -711,7 +719,7 @@ class GraphedContraction:
             raise ValueError("graph capture supports unsliced trees")
         self.executor = executor
         self.strip_exponent = strip_exponent
-        self.inputs = [asarray(x).astype(executor.dtype).copy() for x in arrays]
+        self.inputs = [x.copy() for x in executor.check_inputs(arrays)]
         dev = self.inputs[0]._dev
         if not hasattr(dev, "torch"):
             raise RuntimeError("graph capture needs the HIP device")

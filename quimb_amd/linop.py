@@ -84,8 +84,11 @@ class TNLinearOperator:
                 from .executor import GraphedContraction
 
                 x0 = Array.full(self.rdims, 0.0, self.dtype, xd._dev)
-                self._graphed = GraphedContraction(self._expr(0).executor, list(self._arrays) + [x0])
-            self._graphed.update(len(self._arrays), xd)
+                expr = self._expr(0)
+                ins, where = expr.exec_inputs([x0])       # constants may have been folded: the executed tree's own list
+                self._graphed = GraphedContraction(expr.executor, ins)
+                self._graph_slot = where[0]
+            self._graphed.update(self._graph_slot, xd)
             out = self._graphed.replay().copy()      # the graph's output buffer is reused by the next replay
         else:
             out = self._expr(ncols)(xd)

@@ -116,9 +116,7 @@ class ContractionProgram:
         if executor.tree.nslices != 1:
             raise ValueError("launch programs record unsliced trees")
         self.executor, self.strip_exponent = executor, bool(strip_exponent)
-        xs = [asarray(x).astype(executor.dtype) for x in arrays]
-        if len(xs) != len(executor.tree.inputs):
-            raise ValueError(f"expected {len(executor.tree.inputs)} arrays, got {len(xs)}")
+        xs = executor.check_inputs(arrays)
         dev = xs[0]._dev
         if not hasattr(dev, "lib") or not hasattr(dev, "torch"):
             raise RuntimeError("launch programs need the HIP device")
@@ -237,9 +235,7 @@ class EagerProgram:
         if executor.tree.nslices != 1:
             raise ValueError("launch programs record unsliced trees")
         self.executor, self.strip_exponent = executor, bool(strip_exponent)
-        self.inputs = [asarray(x).astype(executor.dtype) for x in arrays]
-        if len(self.inputs) != len(executor.tree.inputs):
-            raise ValueError(f"expected {len(executor.tree.inputs)} arrays, got {len(self.inputs)}")
+        self.inputs = executor.check_inputs(arrays)
         self.nlanes = max(int(getattr(executor, "nlanes", 1)), 1)
         self.marked, self.num_launches, self.num_ops, self.pool_bytes = [], len(executor.plan), len(executor.plan), 0
 
