@@ -251,7 +251,10 @@ class TreeExecutor:
         changes WHEN things are enqueued (``lane_priority``: HIP stream priority per lane, all normal by default)."""
         n = len(self.plan)
         self.lane_priority = [0] * self.nlanes
-        if self.nlanes <= 1 or not self.join_order or os.environ.get("QAMD_JOIN_ORDER", "1") == "0":
+        if self.nlanes <= 1 or os.environ.get("QAMD_JOIN_ORDER", "1") == "0":
+            return
+        if not self.join_order:
+            self._interleave_chains()
             return
         prod = self._producer
         kids = [tuple(prod[o] for o in self._entry_io(e)[0] if o in prod) for e in self.plan]
@@ -301,6 +304,38 @@ class TreeExecutor:
             for i in range(n):
                 if need[i] == first:
                     self.lane_priority[self.lanes[i]] = -1
+        self.plan = [self.plan[i] for i in order]
+        self.info = [self.info[i] for i in order]
+        self.lanes = [self.lanes[i] for i in order]
+        self._producer = {self._entry_io(e)[1]: i for i, e in enumerate(self.plan)}
+
+    def _interleave_chains(self):
+        """Plain order of a laned plan (what a launch program records): the entries of the side chains and of lane 0's
+        own chain dealt round robin, lane 0's joins behind them.  Nothing overlaps that did not before -- every chain
+        still ends before the first join starts -- but a step that begins on an idle device (a rank whose previous step
+        ended in a collective) has all its chains started within the first few launches instead of one chain's 22
+        launches after the other."""
+        n = len(self.plan)
+        prod = self._producer
+        kids = [tuple(prod[o] for o in self._entry_io(e)[0] if o in prod) for e in self.plan]
+        first_join = next((i for i in range(n) if self.lanes[i] == 0 and any(self.lanes[c] != 0 for c in kids[i])), n)
+        queues = {}
+        for i in range(first_join):
+            queues.setdefault(self.lanes[i], []).append(i)
+        qs = [queues[l] for l in sorted(queues)]
+        order, issued = [], set()
+        while any(qs):
+            progressed = False
+            for q in qs:
+                if q and all(c in issued for c in kids[q[0]]):
+                    issued.add(q[0])
+                    order.append(q.pop(0))
+                    progressed = True
+            if not progressed:
+                return                      # (not a chain structure after all: keep the plan order)
+        order += list(range(first_join, n))
+        if sorted(order) != list(range(n)):
+            return
         self.plan = [self.plan[i] for i in order]
         self.info = [self.info[i] for i in order]
         self.lanes = [self.lanes[i] for i in order]
