@@ -1908,3 +1908,39 @@ def check_program_replay(L, D, dtype, strip, tree_kind="quadrant", seeds=(1, 2))
     val = complex(got2[0]) * 10.0 ** got2[1]
     assert abs(val - ref) <= 10 * RTOL[np.dtype(dtype)] * abs(ref), (val, ref)
     return prog
+
+
+def check_program_on_general_trees(dtype, seed=11):
+    """Launch programs on the GENERAL path: random regular networks with open indices (greedy trees: single-operand
+    steps, outer products, permuted outputs), a hyper-index network (batched steps, elementwise products), an MPS
+    amplitude chain -- replayed twice on the recorded inputs and once on fresh ones, against launch-by-launch execution
+    of the same executor (identical bits without exponent stripping) and the oracle."""
+    rng = np.random.default_rng(seed)
+    hi = np.complex128 if np.dtype(dtype).kind == "c" else np.float64
+    cases = []
+    for n, deg, D, n_out in [(6, 3, 3, 0), (8, 3, 2, 2), (10, 3, 3, 1), (5, 4, 3, 3)]:
+        arrays, inputs, output = rand_reg_network(n, deg, D, rng, dtype, n_out)
+        cases.append((arrays, [tuple(t) for t in inputs], tuple(output)))
+    inputs = [("a", "x"), ("b", "x"), ("c", "x", "y"), ("y", "d"), ("a", "b"), ("c", "d", "y")]
+    size = dict(a=3, b=4, c=2, d=5, x=3, y=4)
+    cases.append(([rand(rng, [size[i] for i in t], dtype) for t in inputs], inputs, ("y", "x")))
+    for arrays, inputs, output in cases:
+        sd = {ix: d for t, a in zip(inputs, arrays) for ix, d in zip(t, a.shape)}
+        tree = qa.find_path(inputs, output, sd, "greedy")
+        ex = qa.TreeExecutor(tree, dtype)
+        for strip in (False, True):
+            xs = [qa.asarray(a) for a in arrays]
+            prog = ex.program(xs, strip_exponent=strip)
+            fresh = [rand(rng, a.shape, dtype) for a in arrays]
+            for ins in (None, None, [qa.asarray(a) for a in fresh]):
+                host = arrays if ins is None else fresh
+                res = prog() if ins is None else prog(ins)
+                ref = ex(host, strip_exponent=strip)
+                if strip:
+                    got, want = res[0].to_numpy() * 10.0 ** res[1], ref[0].to_numpy() * 10.0 ** ref[1]
+                    assert_close(got, want, dtype)
+                else:
+                    np.testing.assert_array_equal(res.to_numpy(), ref.to_numpy())
+                    want = ref.to_numpy()
+                truth = orc.oracle_array_contract([a.astype(hi) for a in host], inputs, output)
+                assert_close(want, np.asarray(truth), dtype)

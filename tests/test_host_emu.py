@@ -477,3 +477,8 @@ def test_constants_are_folded_once(emu):
     expr3 = qa.array_contract_expression([("i", "j"), ("j", "k")], ("k", "i"), shapes=[(3, 4), (4, 5)], optimize="greedy",
                                          dtype="float64", constants={0: a, 1: np.ones((4, 5))}, cache=False)
     np.testing.assert_allclose(np.asarray(expr3()), (a @ np.ones((4, 5))).T, rtol=1e-12)
+
+
+def test_program_interface_on_the_interpreter(emu):
+    """The program checks' host logic on the plan interpreter (``EagerProgram``: every call re-executes the plan)."""
+    checks.check_program_on_general_trees("float64")

@@ -153,3 +153,9 @@ def test_program_full_size_quadrant_tree(hip):
     names = [n for (_, _, n, _, _, _) in prog.timings(1)]
     assert sum(n.startswith("gemmk_kernel") for n in names) == 2, names
     assert 90 <= prog.num_launches <= 130
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", ["float32", "float64", "complex64"])
+def test_program_on_general_trees(hip, dtype):
+    checks.check_program_on_general_trees(dtype)
