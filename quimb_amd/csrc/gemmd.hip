@@ -19,9 +19,9 @@
 //      k-contiguous operand ([x][k], k stride-1):     a DMA piece is 8 rows x one 128-byte line (16 k) each -- 8 lanes
 //        share a line, so the gather stays coalesced -- stored row by row with the 8 granules of row x permuted by
 //        slot ^ (x & 7): the fragment reads of 16 consecutive rows meet at most 2 lanes per bank.
-//  * 3-stage ring, software-pipelined over k-steps and k-tiles like gemmk.hip: the ONE barrier per k-tile sits before
-//    the last k-step of the previous tile, the request for the tile after next is threaded between that step's MFMAs
-//    and the next step's fragments are always read under the current step's MFMAs.  k offsets are scalar arithmetic on
+//  * 4-stage ring, software-pipelined over k-steps and k-tiles like gemmk.hip: the ONE barrier per k-tile sits before
+//    the last k-step of the previous tile, the request for the tile after next goes out one piece per k-step behind
+//    that step's first MFMA, and the next step's fragments are always read under the current step's MFMAs.  k offsets are scalar arithmetic on
 //    the K groups (no table reads among the requests, no per-lane divisions behind the barrier: both were measured as
 //    ~2000 idle matrix-pipe cycles per k-tile).
 //  * workgroup = 8 waves (2 x 4), wave tile (16 TA) x (16 TB), TA in {2..5}, TB in {1, 2}: workgroup tiles
@@ -110,7 +110,7 @@ __global__ __launch_bounds__(512, 1) void gemmd_kernel(const GettArgs p, const d
                                                        const double* __restrict__ scale_a,
                                                        const double* __restrict__ scale_b,
                                                        double* __restrict__ absmax_out) {
-  constexpr int BM = 32 * TA, BN = 64 * TB, BK = 16, NS = 3;
+  constexpr int BM = 32 * TA, BN = 64 * TB, BK = 16, NS = 4;
   constexpr int STAGE = BK * (BM + BN);   // doubles per stage: A image, then B image
   extern __shared__ __attribute__((aligned(16))) char dsmem[];
   double* stages = reinterpret_cast<double*>(dsmem);
@@ -184,6 +184,7 @@ __global__ __launch_bounds__(512, 1) void gemmd_kernel(const GettArgs p, const d
   // between the MFMAs of a k-step, the prologue issues them in one go
   const double* At = Ab;
   const double* Bt = Bb;
+  uint32_t krem = 0;                       // rows left in the innermost K group from the tile At / Bt point at
   auto tile_base = [&](uint32_t k0) {
     // the tile's first k row in both operands: wave-uniform, scalar arithmetic (k0 is a multiple of 16 and so is the
     // innermost K group: the rows of the tile differ in that group only, which xoff already carries)
@@ -192,12 +193,24 @@ __global__ __launch_bounds__(512, 1) void gemmd_kernel(const GettArgs p, const d
     for (int g = p.nk - 1; g >= 0; --g) {
       const uint32_t d = p.dim_k[g];
       const uint32_t qd = idx / d, r = idx - qd * d;
+      if (g == p.nk - 1) krem = d - r;
       ka += (int64_t)r * p.sa_k[g];
       kb += (int64_t)r * p.sb_k[g];
       idx = qd;
     }
     At = Ab + ka;
     Bt = Bb + kb;
+  };
+  // the NEXT tile (k0 + 16): two additions while it stays inside the innermost K group, the full decomposition at a
+  // group boundary
+  auto tile_next = [&](uint32_t k0_next) {
+    if (krem > BK) {
+      krem -= BK;
+      At += (int64_t)BK * p.sa_k[p.nk - 1];
+      Bt += (int64_t)BK * p.sb_k[p.nk - 1];
+    } else {
+      tile_base(k0_next);
+    }
   };
   auto issue_piece = [&](int st, int piece) {
     double* sa = stages + st * STAGE;
@@ -213,7 +226,7 @@ __global__ __launch_bounds__(512, 1) void gemmd_kernel(const GettArgs p, const d
     }
   };
   constexpr int P = LA::NPW + LB::NPW;      // requests per wave and tile
-  static_assert(P <= TA * TB, "every piece of a request needs an MFMA of the k-step to hide behind");
+  static_assert((P + 3) / 4 <= TA * TB, "every piece of a request needs an MFMA of its k-step to hide behind");
 
   acc4 acc[TA][TB];
 #pragma unroll
@@ -221,12 +234,13 @@ __global__ __launch_bounds__(512, 1) void gemmd_kernel(const GettArgs p, const d
 #pragma unroll
     for (int j = 0; j < TB; ++j) acc[i][j] = acc4{0.0, 0.0, 0.0, 0.0};
 
-  // prologue: tiles 0 and 1 requested (the loop waits for them)
+  // prologue: tiles 0 and 1 requested in one go; from then on the request for tile t + 2 is issued DURING tile t, a piece
+  // per k-step (its stage held tile t - 2, which every wave left before the barrier that opened tile t)
   tile_base(kbeg);
 #pragma unroll
   for (int pc = 0; pc < P; ++pc) issue_piece(0, pc);
   if (nt > 1) {
-    tile_base(kbeg + BK);
+    tile_next(kbeg + BK);
 #pragma unroll
     for (int pc = 0; pc < P; ++pc) issue_piece(1, pc);
   }
@@ -252,14 +266,17 @@ __global__ __launch_bounds__(512, 1) void gemmd_kernel(const GettArgs p, const d
     sb_[s] = BKC ? 2 * ((2 * s + (fk >> 1)) ^ (fr & 7)) : 4 * s * BN;
   }
 
-  // ---- main loop, software-pipelined over k-steps AND k-tiles (gemmk.hip's schedule) ---------------------------------
+  // ---- main loop, software-pipelined over k-steps AND k-tiles (gemmk.hip's schedule, 4 stages) ------------------------
   // The barrier that opens tile t + 1 sits INSIDE tile t, before its last k-step: by then every wave has waited for its
-  // own pieces of tile t + 1 (requested a whole tile earlier) and has finished tile t - 1, whose stage the request for
-  // tile t + 2 -- threaded between that k-step's MFMAs -- overwrites.  The fragments of the next k-step (of the next
-  // tile's first step at the end of a tile) are read while the current step's MFMAs run: neither LDS latency nor the
-  // barrier nor the requests' issue cost ever leaves the matrix pipe idle on a SIMD whose two waves arrive together.
-  if (nt > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(P) : "memory");      // tile 0 has landed, tile 1 may be in flight
-  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  // own pieces of tile t + 1 (requested during tile t - 1) and has finished tile t - 1.  The request for tile t + 2 goes
+  // into the stage tile t - 2 left (free since the barrier that opened tile t) one piece per k-step, each behind the
+  // first MFMA of its step; the next k-step's fragments (the next tile's first step at the end of a tile) are read while
+  // the current step's MFMAs run.  What is left per k-tile besides MFMAs is the barrier skew: requests, scalar offset
+  // updates and LDS latency all sit under MFMAs of the same wave, and the two waves of a SIMD no longer do their
+  // housekeeping at the same moment (measured before: ~1000 idle pipe cycles per 4096-cycle tile).
+  constexpr int Q012 = P - P / 4;            // pieces of a request issued in k-steps 0..2 (piece pc goes to step pc % 4)
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(0) : "memory");
+  if (nt > 1) { /* (tile 1 may still be in flight: only tile 0 is needed) */ }
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
   double af[2][TA], bf[2][TB];
@@ -273,14 +290,17 @@ __global__ __launch_bounds__(512, 1) void gemmd_kernel(const GettArgs p, const d
     const int stn = st + 1 >= NS ? 0 : st + 1;
     const int st2 = stn + 1 >= NS ? 0 : stn + 1;
     const bool more = t + 1 < nt, req = t + 2 < nt;
+    if (req) tile_next(kbeg + (uint32_t)(t + 2) * BK);
 #pragma unroll
     for (int s = 0; s < BK / 4; ++s) {
       const bool last = s == BK / 4 - 1;
       if (last && more) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // this wave's pieces of tile t + 1 (one tile old)
+        // this wave's pieces of tile t + 1 (requested during tile t - 1); the pieces of tile t + 2 issued in steps 0..2
+        // of this tile may still be in flight
+        if (req) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(Q012) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        if (req) tile_base(kbeg + (uint32_t)(t + 2) * BK);
       }
       if (!last) {                      // the next k-step's fragments, read while this step's MFMAs run
 #pragma unroll
@@ -300,7 +320,8 @@ __global__ __launch_bounds__(512, 1) void gemmd_kernel(const GettArgs p, const d
         for (int j = 0; j < TB; ++j) {
           if (SWAP) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(bf[s & 1][j], af[s & 1][i], acc[i][j], 0, 0, 0);
           else acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[s & 1][i], bf[s & 1][j], acc[i][j], 0, 0, 0);
-          if (last && req && i * TB + j < P) issue_piece(st2, i * TB + j);   // one piece behind each of the first P MFMAs
+          // this k-step's share of the request for tile t + 2: pieces s, s + 4, ... behind the first MFMAs
+          if (req && s + 4 * (i * TB + j) < P) issue_piece(st2, s + 4 * (i * TB + j));
         }
     }
     st = stn;
@@ -349,7 +370,7 @@ template <int TA, int TB, bool AKC, bool BKC>
 static int launch_swap(const GettArgs& a, int swap, const void* A, const void* B, void* C, const void* ktab,
                        const void* sa, const void* sb, void* amax, hipStream_t st) {
   constexpr int BM = 32 * TA, BN = 64 * TB;
-  const size_t lds = (size_t)3 * 16 * (BM + BN) * sizeof(double) + (size_t)(BM + BN) * sizeof(int64_t) + 1024;
+  const size_t lds = (size_t)4 * 16 * (BM + BN) * sizeof(double) + (size_t)(BM + BN) * sizeof(int64_t) + 1024;
   const unsigned grid = a.tiles_m * a.tiles_n * a.B * a.split_k;
   if (swap) {
     if (lds > 64 * 1024)
