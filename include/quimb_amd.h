@@ -276,6 +276,28 @@ int qamd_unary(void* dst, const void* src, int64_t n, int32_t op, int32_t dtype,
 int qamd_minmax(void* out_dev, const void* x, int64_t n, int32_t want_min, int32_t dtype, void* stream);
 
 /*
+ * The vector work of one Lanczos step, on the device (the Krylov solver around TNLinearOperator.matvec in DMRG's local
+ * solve: quimb/tensor/tn1d/dmrg.py:626-645 -> quimb/linalg/base_linalg.py:80, ARPACK on HOST vectors in the
+ * reference).  Q: `rows` basis vectors of n elements, row stride ldq (elements); w: the matvec result, updated in place.
+ *   project : h[i] = <Q_i, w> (conjugating Q), i < rows; with h_sum_dev != NULL also h_sum[i] = h[i] (accumulate == 0)
+ *             or h_sum[i] += h[i] (a second Gram-Schmidt pass: subtract takes h, alpha is read from h_sum)
+ *   subtract: w -= sum_i h[i] Q_i; want_norm != 0 leaves the partial sums of ||w||^2 in the workspace
+ *   extend  : beta = ||w|| from those partial sums, alpha = Re h_j[0]; alpha_beta_dev[0..1] = (alpha, beta);
+ *             q_next = w / beta, or ZERO when beta <= breakdown_eps * max(|alpha|, 1) (Krylov space exhausted: the
+ *             host sees it in beta and the later steps stay finite)
+ * No host read anywhere: a whole restart cycle is enqueued and (alpha, beta) are fetched once.  Reductions are
+ * two-stage with a fixed order.  ws_dev: qamd_krylov_workspace_bytes(rows, n, dtype) bytes, shared by the three
+ * calls of one step.  Not recordable in launch programs (-9 while recording).
+ */
+int64_t qamd_krylov_workspace_bytes(int32_t rows, int64_t n, int32_t dtype);
+int qamd_krylov_project(void* h_dev, void* h_sum_dev, const void* Q, int64_t ldq, int32_t rows, const void* w, int64_t n,
+                        int32_t accumulate, int32_t dtype, void* ws_dev, void* stream);
+int qamd_krylov_subtract(void* w, const void* Q, int64_t ldq, int32_t rows, const void* h_dev, int64_t n,
+                         int32_t want_norm, int32_t dtype, void* ws_dev, void* stream);
+int qamd_krylov_extend(void* q_next, const void* w, int64_t n, const void* h_j_dev, double* alpha_beta_dev,
+                       double breakdown_eps, int32_t dtype, const void* ws_dev, void* stream);
+
+/*
  * A whole tree of SMALL contractions walked on the device (quimb's circuit amplitudes: hundreds of
  * pairwise steps on <= 2^10-element tensors, quimb/tensor/circuit/exact.py:417-501 -> the per-step
  * tensordot loop of ctg.array_contract, contraction.py:285).  steps_dev / etab_dev / ktab_dev: the lowered

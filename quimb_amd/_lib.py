@@ -109,6 +109,11 @@ SYMBOLS = [
     ("qamd_unary", C.c_int, [_vp, _vp, _i64, _i32, _i32, _vp]),
     ("qamd_minmax", C.c_int, [_vp, _vp, _i64, _i32, _i32, _vp]),
     ("qamd_absmax_log10_sum_add", C.c_int, [_vp, _i64, _i32, _vp, _vp]),
+    # the vector work of a Lanczos step (krylov.hip)
+    ("qamd_krylov_workspace_bytes", _i64, [_i32, _i64, _i32]),
+    ("qamd_krylov_project", C.c_int, [_vp, _vp, _vp, _i64, _i32, _vp, _i64, _i32, _i32, _vp, _vp]),
+    ("qamd_krylov_subtract", C.c_int, [_vp, _vp, _i64, _i32, _vp, _i64, _i32, _i32, _vp, _vp]),
+    ("qamd_krylov_extend", C.c_int, [_vp, _vp, _i64, _vp, _vp, C.c_double, _i32, _vp, _vp]),
     # launch programs (record once, replay with one host call)
     ("qamd_program_create", _vp, [_i32]),
     ("qamd_program_destroy", None, [_vp]),

@@ -442,6 +442,32 @@ class HipDevice:
         v = complex(value)
         _lib.check(self.lib.qamd_fill(dst.data_ptr(), int(n), v.real, v.imag, dtype_code(dtype), self.stream()), "qamd_fill")
 
+    # ---- the vector work of a Lanczos step (krylov.hip) ---------------------------------
+    def krylov_workspace(self, rows, n, dtype):
+        nb = int(self.lib.qamd_krylov_workspace_bytes(int(rows), int(n), dtype_code(dtype)))
+        if nb < 0:
+            raise _lib.QamdError("qamd_krylov_workspace_bytes failed")
+        return self.torch.empty(nb, dtype=self.torch.uint8, device=self.tdev)
+
+    def krylov_project(self, h, h_sum, Q, ldq, rows, w, n, accumulate, dtype, ws):
+        """h[i] = <Q_i, w>, i < rows; ``h_sum`` (or None): = h, or += h when ``accumulate``"""
+        _lib.check(self.lib.qamd_krylov_project(h.data_ptr(), None if h_sum is None else h_sum.data_ptr(), Q.data_ptr(),
+                                                int(ldq), int(rows), w.data_ptr(), int(n), int(bool(accumulate)),
+                                                dtype_code(dtype), ws.data_ptr(), self.stream()),
+                   "qamd_krylov_project")
+
+    def krylov_subtract(self, w, Q, ldq, rows, h, n, want_norm, dtype, ws):
+        """w -= sum_i h[i] Q_i (in place); ``want_norm``: leave ||w||^2 for ``krylov_extend`` in ``ws``"""
+        _lib.check(self.lib.qamd_krylov_subtract(w.data_ptr(), Q.data_ptr(), int(ldq), int(rows), h.data_ptr(), int(n),
+                                                 int(bool(want_norm)), dtype_code(dtype), ws.data_ptr(), self.stream()),
+                   "qamd_krylov_subtract")
+
+    def krylov_extend(self, q_next, w, n, h_j, ab, eps, dtype, ws):
+        """ab[0:2] = (Re h_j[0], ||w||); q_next = w / ||w|| (zero on breakdown)"""
+        _lib.check(self.lib.qamd_krylov_extend(q_next.data_ptr(), w.data_ptr(), int(n), h_j.data_ptr(), ab.data_ptr(),
+                                               float(eps), dtype_code(dtype), ws.data_ptr(), self.stream()),
+                   "qamd_krylov_extend")
+
     # ---- complex support ----------------------------------------------------------
     def as_real(self, buf):
         """Interleaved (re, im) real view of a complex buffer (shares memory)."""
@@ -510,6 +536,10 @@ class HipDevice:
 
     def buffer_address(self, buf):
         return buf.data_ptr()
+
+    def shares_storage(self, a, b):
+        """Do two buffers (views included) live in the same allocation?"""
+        return a.untyped_storage().data_ptr() == b.untyped_storage().data_ptr()
 
     def microtree_run(self, mt, table, keep, out):
         """One launch for ``table.shape[0]`` instances of the compiled tree ``mt`` (microtree.hip).

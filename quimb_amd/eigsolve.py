@@ -58,10 +58,14 @@ def eigh_lanczos(A, k=1, which="SA", v0=None, ncv=None, tol=1e-10, maxiter=None,
             v0 = v0 + 1j * rng.standard_normal(n).astype(rdt)
     q = asarray(v0).astype(dtype).reshape(n)
     dev = q._dev
-    # basis rows beyond the current step are kept at zero, so that every projection runs on the SAME
-    # (m + 1, n) shape: one cached kernel plan for the whole solve instead of one per step
-    Q = Array.full((m + 1, n), 0.0, dtype, dev)
+    Q = Array.full((m + 1, n), 0.0, dtype, dev)       # basis rows; rows beyond the current step stay zero
     passes = 1 if rdt == np.float64 else 2   # classical Gram-Schmidt twice in single precision
+    # the vector work of a step runs in three device launches per pass (csrc/krylov.hip): projection coefficients,
+    # (alpha, beta) and the norm never visit the host inside a cycle -- they are read when a convergence test is due
+    h = dev.empty(m + 1, dtype)
+    h_sum = dev.empty(m + 1, dtype) if passes > 1 else None       # alpha = the coefficient summed over the passes
+    ab = dev.empty(2 * (m + 1), np.float64)
+    ws = dev.krylov_workspace(m + 1, n, dtype)
 
     def put(row, vec):      # Q[row] <- vec  (device-to-device, one strided copy)
         dev.permute(Q._buf[row * n:], vec._buf, (n,), (1,), 0, dtype)
@@ -75,6 +79,7 @@ def eigh_lanczos(A, k=1, which="SA", v0=None, ncv=None, tol=1e-10, maxiter=None,
         raise ValueError("v0 is zero")
     put(0, q / nrm)
     theta = S = None
+    first_test = max(k, min(int(miniter), m))          # no residual test (hence no host read) before this many steps
     while True:
         alphas, betas = [], []
         j_done = 0
@@ -82,29 +87,36 @@ def eigh_lanczos(A, k=1, which="SA", v0=None, ncv=None, tol=1e-10, maxiter=None,
             qj = Array(dev, Q._buf[j * n:], (n,), dtype)
             w = _matvec(A, qj)
             nmv += 1
-            # full re-orthogonalisation against the whole basis: h = Q^H w ; w -= Q^T h
-            Qc = Q.conj()
-            hh = np.zeros(m + 1, dtype)
-            for _ in range(passes):
-                h = ops.tensordot(Qc, w, axes=([1], [0]))
-                w = w - ops.tensordot(h, Q, axes=([0], [0]))
-                hh = hh + h.to_numpy()
-            alphas.append(float(np.real(hh[j])))
-            beta = norm(w)
-            betas.append(beta)
+            if w.dtype != dtype or w.size != n:
+                w = w.astype(dtype).reshape(n)
+            if dev.shares_storage(w._buf, Q._buf):
+                w = w.copy()                            # an operator that hands its argument back: w is updated in place
+            # full re-orthogonalisation against the basis so far: h = Q^H w ; w -= Q^T h ; Q[j+1] = w / |w|
+            for ps in range(passes):
+                dev.krylov_project(h, h_sum, Q._buf, n, j + 1, w._buf, n, ps > 0, dtype, ws)
+                dev.krylov_subtract(w._buf, Q._buf, n, j + 1, h, n, ps == passes - 1, dtype, ws)
+            dev.krylov_extend(Q._buf[(j + 1) * n:], w._buf, n, (h if h_sum is None else h_sum)[j:], ab[2 * j:], eps, dtype, ws)
             j_done = j + 1
-            # Ritz values of the (j+1) x (j+1) tridiagonal matrix
+            if j_done < first_test and j_done < m:
+                continue                                # (a breakdown in here zeroes the later rows: found below)
+            got = np.asarray(dev.to_host(ab, 2 * j_done, np.float64), dtype=np.float64)
+            alphas, betas = [float(x) for x in got[0::2]], [float(x) for x in got[1::2]]
+            dead = [i for i in range(j_done) if betas[i] <= eps * max(abs(alphas[i]), 1.0)]
+            if dead:                                    # invariant subspace found at step dead[0]
+                j_done = dead[0] + 1
+                alphas, betas = alphas[:j_done], betas[:j_done]
+            beta = betas[-1]
+            # Ritz values of the j_done x j_done tridiagonal matrix
             T = np.diag(alphas) + np.diag(betas[:-1], 1) + np.diag(betas[:-1], -1)
             evals, evecs = np.linalg.eigh(T)
             order = np.argsort(evals) if which == "SA" else np.argsort(-evals)
             kk = min(k, j_done)
             theta, S = evals[order[:kk]], evecs[:, order[:kk]]
             resid = np.abs(beta * S[-1, :])
-            if j_done >= max(k, min(int(miniter), m)) and np.all(resid <= tol * np.maximum(np.abs(theta), 1.0)):
+            if j_done >= first_test and np.all(resid <= tol * np.maximum(np.abs(theta), 1.0)):
                 break
-            if beta <= eps * max(abs(alphas[-1]), 1.0) or j + 1 == m:
+            if dead or j + 1 == m:
                 break                                  # invariant subspace found, or basis full
-            put(j + 1, w / beta)
         Sfull = np.zeros((m + 1, S.shape[1]), dtype)
         Sfull[:j_done] = S
         X = ops.tensordot(asarray(Sfull), Q, axes=([0], [0]))               # (k, n) Ritz vectors

@@ -35,7 +35,7 @@ def timed(fn, reps=5):
 
 
 nmv = 12
-t_eig, (e0, vec) = timed(lambda: qa.eigh_lanczos(A, k=1, which="SA", v0=v0, ncv=nmv, tol=1e-14, maxiter=nmv))
+t_eig, (e0, vec) = timed(lambda: qa.eigh_lanczos(A, k=1, which="SA", v0=v0, ncv=nmv, tol=1e-14, maxiter=nmv, miniter=nmv))
 x = vec.reshape(chi * d, d * chi)
 t_svd, (U, S, Vh) = timed(lambda: qa.linalg.svd(x))
 t_svde, (U, S, Vh) = timed(lambda: qa.linalg.svd_via_eig(x))

@@ -109,7 +109,7 @@ def config5(qa, sync, chi=512, d=2, w=5, nmv=12):
                     names.append(dev.describe_pair(dev.compile_pair(e[4].spec, np.dtype("float64"))))
                 except Exception:
                     pass
-    t_eig, (e0, vec) = _timed(lambda: qa.eigh_lanczos(A, k=1, which="SA", v0=v0, ncv=nmv, tol=1e-14, maxiter=nmv), 3, sync)
+    t_eig, (e0, vec) = _timed(lambda: qa.eigh_lanczos(A, k=1, which="SA", v0=v0, ncv=nmv, tol=1e-14, maxiter=nmv, miniter=nmv), 3, sync)
     x = vec.reshape(chi * d, d * chi)
     t_split, (U, S, Vh) = _timed(lambda: qa.linalg.svd_via_eig(x), 3, sync)
     Asite = qa.asarray(np.ascontiguousarray(U.to_numpy()[:, :chi].reshape(chi, d, chi)))    # keep chi columns

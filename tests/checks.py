@@ -961,6 +961,78 @@ def check_long_reductions(dtype, seed=14):
     assert abs(nn - float(x.astype(np.float64) @ x.astype(np.float64))) <= 1e-5 * nn
 
 
+def check_krylov_step(dtype):
+    """The three launches of a Lanczos step (csrc/krylov.hip) against numpy: projections onto 1 ... 70 basis rows (more
+    than one row group, more than one launch of the update), vector lengths with and without a 16-byte tail, a basis
+    whose rows start off 16-byte alignment, both Gram-Schmidt passes' bookkeeping (h_sum), the breakdown guard."""
+    import quimb_amd.device as qd
+
+    dev = qd.default_device()
+    dt = np.dtype(dtype)
+    rdt = np.zeros(0, dt).real.dtype
+    rng = np.random.default_rng(11)
+    tol = 2e-5 if rdt == np.float32 else 1e-12
+
+    def rand(*shape):
+        x = rng.standard_normal(shape)
+        if dt.kind == "c":
+            x = x + 1j * rng.standard_normal(shape)
+        return x.astype(dt)
+
+    for rows, n, ldq, off in ((1, 1000, 1000, 0), (5, 4099, 4099, 0), (13, 65536, 65536, 0), (9, 3001, 3005, 1),
+                              (33, 20000, 20000, 0), (70, 5000, 5008, 0)):
+        Qh, wh = rand(rows + 1, ldq), rand(n)
+        Qh /= np.sqrt(n)
+        Qd = dev.from_host(np.concatenate([np.zeros(off, dt), Qh.reshape(-1)]))[off:]
+        wd = dev.from_host(wh)
+        h, hs = dev.empty(rows, dt), dev.empty(rows, dt)
+        ab = dev.empty(2, np.float64)
+        ws = dev.krylov_workspace(rows, n, dt)
+        Q64 = Qh[:rows, :n].astype(np.complex128 if dt.kind == "c" else np.float64)
+        w64 = wh.astype(Q64.dtype)
+        # pass 1
+        dev.krylov_project(h, hs, Qd, ldq, rows, wd, n, False, dt, ws)
+        h1 = Q64.conj() @ w64
+        got = dev.to_host(h, rows, dt)
+        scale = np.linalg.norm(h1) + 1.0
+        assert np.max(np.abs(got - h1)) <= tol * scale, (dtype, rows, n, "project")
+        dev.krylov_subtract(wd, Qd, ldq, rows, h, n, False, dt, ws)
+        w1 = w64 - got.astype(Q64.dtype) @ Q64
+        # pass 2 (accumulating into h_sum), with the norm
+        dev.krylov_project(h, hs, Qd, ldq, rows, wd, n, True, dt, ws)
+        h2 = Q64.conj() @ w1
+        got2 = dev.to_host(h, rows, dt)
+        assert np.max(np.abs(got2 - h2)) <= tol * scale, (dtype, rows, n, "project 2")
+        assert np.max(np.abs(dev.to_host(hs, rows, dt) - (got.astype(Q64.dtype) + got2))) <= tol * scale
+        dev.krylov_subtract(wd, Qd, ldq, rows, h, n, True, dt, ws)
+        w2 = w1 - got2.astype(Q64.dtype) @ Q64
+        assert np.max(np.abs(dev.to_host(wd, n, dt) - w2)) <= tol * (np.max(np.abs(w64)) + 1), (dtype, rows, n, "subtract")
+        # extend into the spare basis row
+        dev.krylov_extend(Qd[rows * ldq:], wd, n, hs[rows - 1:], ab, float(np.finfo(rdt).eps), dt, ws)
+        a, b = dev.to_host(ab, 2, np.float64)
+        wfin = dev.to_host(wd, n, dt).astype(Q64.dtype)
+        assert abs(b - np.linalg.norm(wfin)) <= 10 * tol * b
+        assert abs(a - np.real(dev.to_host(hs, rows, dt)[rows - 1])) <= tol * scale
+        qn = dev.to_host(Qd[rows * ldq:], n, dt)
+        assert np.max(np.abs(qn - wfin / b)) <= tol, (dtype, rows, n, "extend")
+        # the rest of the spare row (ldq > n) is untouched
+        if ldq > n:
+            assert np.array_equal(dev.to_host(Qd[rows * ldq + n:], ldq - n, dt), Qh[rows, n:])
+    # breakdown: a vector inside the span leaves (numerically) nothing -> the next row is ZERO, beta is reported
+    n, rows = 4096, 3
+    Qh = np.linalg.qr(rand(n, rows))[0].T.copy().astype(dt)
+    wh = (Qh.T @ rand(rows)).astype(dt)
+    Qd = dev.from_host(np.concatenate([Qh.reshape(-1), np.ones(n, dt)]))
+    wd, h, ab = dev.from_host(wh), dev.empty(rows, dt), dev.empty(2, np.float64)
+    ws = dev.krylov_workspace(rows, n, dt)
+    for _ in range(2):
+        dev.krylov_project(h, None, Qd, n, rows, wd, n, False, dt, ws)
+        dev.krylov_subtract(wd, Qd, n, rows, h, n, True, dt, ws)
+    dev.krylov_extend(Qd[rows * n:], wd, n, h, ab, 1e-3, dt, ws)
+    a, b = dev.to_host(ab, 2, np.float64)
+    assert b <= 1e-3 and not np.any(dev.to_host(Qd[rows * n:], n, dt))
+
+
 def check_lanczos(dtype, chi=6):
     """Device Lanczos (quimb_amd.eigh_lanczos) on a dense symmetric matrix and on a symmetric DMRG-style
     effective Hamiltonian (TNLinearOperator) against numpy's dense eigh -- the call DMRG._eigs makes
@@ -1597,7 +1669,7 @@ def check_dmrg_local_update_full_chi(chi=512, dtype="float64", nmv=8):
 
     A = qa.TNLinearOperator([(L, li), (W1, w1i), (W2, w2i), (R, ri)], left, right, optimize="random-greedy")
     v0 = qa.asarray(np.random.default_rng(1).standard_normal(n).astype(dtype))
-    e0, vec = qa.eigh_lanczos(A, k=1, which="SA", v0=v0, ncv=nmv, tol=1e-14, maxiter=nmv)
+    e0, vec = qa.eigh_lanczos(A, k=1, which="SA", v0=v0, ncv=nmv, tol=1e-14, maxiter=nmv, miniter=nmv)
     e0 = float(np.asarray(e0).reshape(-1)[0])
     v = vec.to_numpy().astype(np.float64).reshape(n)
     hv = H(v)

@@ -162,6 +162,28 @@ class EmuDevice:
         y[:n] = y[:n] * np.asarray(fy, y.real.dtype) + x[:n] * np.asarray(fx, x.real.dtype)
         y_exp[0] = m
 
+    # the vector work of a Lanczos step (csrc/krylov.hip)
+    def krylov_workspace(self, rows, n, dtype):
+        return np.zeros(2, np.float64)                  # [0] = ||w||^2 left by krylov_subtract
+
+    def krylov_project(self, h, h_sum, Q, ldq, rows, w, n, accumulate, dtype, ws):
+        got = np.array([np.vdot(Q[i * ldq: i * ldq + n], w[:n]) for i in range(rows)], dtype=np.dtype(dtype))
+        h[:rows] = got
+        if h_sum is not None:
+            h_sum[:rows] = (h_sum[:rows] + got) if accumulate else got
+
+    def krylov_subtract(self, w, Q, ldq, rows, h, n, want_norm, dtype, ws):
+        for i in range(rows):
+            w[:n] -= h[i] * Q[i * ldq: i * ldq + n]
+        if want_norm:
+            ws[0] = float(np.sum(np.abs(w[:n].astype(np.complex128 if np.dtype(dtype).kind == "c" else np.float64)) ** 2))
+
+    def krylov_extend(self, q_next, w, n, h_j, ab, eps, dtype, ws):
+        beta, alpha = float(np.sqrt(ws[0])), float(np.real(h_j[0]))
+        ab[0], ab[1] = alpha, beta
+        scale = 1.0 / beta if beta > eps * max(abs(alpha), 1.0) else 0.0
+        q_next[:n] = (w[:n] * scale).astype(np.dtype(dtype))
+
     def new_exponent_neg_inf(self):
         return np.full(1, -np.inf)
 
@@ -216,6 +238,9 @@ class EmuDevice:
 
     def absmax(self, x, n, dtype):
         return float(np.max(np.abs(x[:n]))) if n else 0.0
+
+    def shares_storage(self, a, b):
+        return bool(np.shares_memory(a, b))
 
     def buffer_address(self, buf):
         """Stand-in for a device address: a handle the interpreter can turn back into the buffer."""

@@ -318,6 +318,11 @@ def test_lanczos(hip, dtype):
     checks.check_lanczos(dtype)
 
 
+@pytest.mark.parametrize("dtype", ["float32", "float64", "complex64", "complex128"])
+def test_krylov_step(hip, dtype):
+    checks.check_krylov_step(dtype)
+
+
 @pytest.mark.parametrize("dtype", ["complex64", "complex128"])
 def test_microtree(hip, dtype):
     checks.check_microtree(dtype)

@@ -72,6 +72,11 @@ def test_lanczos(emu, dtype):
     checks.check_lanczos(dtype)
 
 
+@pytest.mark.parametrize("dtype", ["float64", "complex64"])
+def test_krylov_step_on_the_interpreter(emu, dtype):
+    checks.check_krylov_step(dtype)
+
+
 @pytest.mark.parametrize("dtype", ["complex64", "complex128"])
 def test_microtree(emu, dtype):
     checks.check_microtree(dtype)
