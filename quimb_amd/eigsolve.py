@@ -22,6 +22,8 @@ from .array import Array, asarray
 
 
 def _matvec(A, x):
+    if hasattr(A, "matvec_borrow"):          # the product is consumed (in place) before the next one is asked for
+        return asarray(A.matvec_borrow(x))
     if hasattr(A, "matvec"):
         return asarray(A.matvec(x))
     return ops.matmul(A, x)

@@ -64,7 +64,7 @@ class TNLinearOperator:
             self._exprs[ncols] = ex
         return ex
 
-    def _apply(self, x, ncols):
+    def _apply(self, x, ncols, borrow=False):
         host = not isinstance(x, Array)
         xin = asarray(x)
         if xin.dtype.kind == "c" and self.dtype.kind != "c":
@@ -89,7 +89,9 @@ class TNLinearOperator:
                 self._graphed = GraphedContraction(expr.executor, ins)
                 self._graph_slot = where[0]
             self._graphed.update(self._graph_slot, xd)
-            out = self._graphed.replay().copy()      # the graph's output buffer is reused by the next replay
+            out = self._graphed.replay()             # the graph's own output buffer, reused by the next replay:
+            if not borrow:                           # handed out as it is only to a caller that says it is done with it by then
+                out = out.copy()
         else:
             out = self._expr(ncols)(xd)
         if isinstance(out, np.ndarray):
@@ -101,6 +103,12 @@ class TNLinearOperator:
 
     def matvec(self, vec):
         return self._apply(vec, 0)
+
+    def matvec_borrow(self, vec):
+        """``matvec`` whose result may be a buffer the operator owns, valid (and the caller's to overwrite) until the next
+        application -- what an iterative solver that consumes each product before asking for the next one needs; saves
+        one pass over the vector per application."""
+        return self._apply(vec, 0, borrow=True)
 
     _matvec = matvec
 
