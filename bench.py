@@ -583,20 +583,20 @@ def main():
                     r_ = int(np.argmax(rep_["per_rank_mults"]))
                     qr_ = QuadrantRank(sh_, r_, dtype)
                     loc_ = sh_.shard([qa.asarray(a) for a in arrays], r_)
-                    cnt_ = [0]
+                    # what a rank of `--gpus N` runs: its share as a launch program, and a host read after every step
+                    # (the collective needs the pair) -- a SYNCHRONOUS step, not a pipelined one
+                    qr_.program(loc_)
 
                     def one_():
-                        cnt_[0] += 1
-                        if not pipelined:
-                            return qr_(loc_, defer=True)
-                        with torch.cuda.stream(rings[cnt_[0] % len(rings)]):
-                            return qr_(loc_, defer=True)
+                        m_, e_ = qr_(loc_, defer=True)
+                        return float(e_.cpu()[0]) if hasattr(e_, "cpu") else float(np.asarray(e_).reshape(-1)[0])
 
                     for _ in range(2):
                         one_()
                     t_, _ = _time_steps(one_, 8, sync)
                     projection[str(w_)] = {"grid": rep_["grid"], "busiest_rank_ms": t_ * 1e3, "speedup_vs_one_gpu": ms / (t_ * 1e3),
-                                           "busiest_rank_fraction_of_flops": rep_["busiest_rank_fraction"]}
+                                           "busiest_rank_fraction_of_flops": rep_["busiest_rank_fraction"],
+                                           "step": "launch program + host read of the (mantissa, exponent) pair per step"}
                     del qr_, loc_
                 except Exception as err:
                     projection[str(w_)] = {"error": f"{type(err).__name__}: {err}"}
