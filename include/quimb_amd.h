@@ -276,6 +276,22 @@ int qamd_unary(void* dst, const void* src, int64_t n, int32_t op, int32_t dtype,
 int qamd_minmax(void* out_dev, const void* x, int64_t n, int32_t want_min, int32_t dtype, void* stream);
 
 /*
+ * A pairwise contraction whose result is consumed by ONE inner product over all its indices with a tensor T of the same
+ * layout -- the closing pair of steps of a two-sided / four-quadrant contraction (cotengra's last two steps of
+ * ctg.array_contract, quimb/tensor/contraction.py:285: the second join, then the `tensordot` over everything):
+ *     out_dev[0] = sum_{b,m,n} (A . B)[b, m, n] * T[b, m, n]  /  (scale_a * scale_b * scale_t)
+ * The result tensor never reaches memory (no 242 MB store and no 484 MB read-back on the 10x10 D=6 headline).  T is
+ * addressed exactly as C would have been (plan->sc_*).  Only plans the planner put on the k-outer fp32 kernel
+ * (qamd_pair_describe: gemmk_kernel<..>) are supported, anything else returns QAMD_EUNSUPPORTED and the caller issues
+ * the two steps separately.  workspace: qamd_pair_dot_workspace_bytes(plan) bytes (one double per workgroup, summed in a
+ * fixed order).  ep->scale_a / scale_b as in qamd_contract_pair_ex, scale_t = T's slots; ep->absmax_out[0] = |out|.
+ */
+int64_t qamd_pair_dot_workspace_bytes(const qamd_pair_plan* plan);
+int qamd_contract_pair_dot(const qamd_pair_plan* plan, const void* A, const void* B, const void* T, void* out_dev,
+                           void* workspace, int64_t workspace_bytes, const qamd_epilogue* ep, const void* scale_t,
+                           void* stream);
+
+/*
  * The vector work of one Lanczos step, on the device (the Krylov solver around TNLinearOperator.matvec in DMRG's local
  * solve: quimb/tensor/tn1d/dmrg.py:626-645 -> quimb/linalg/base_linalg.py:80, ARPACK on HOST vectors in the
  * reference).  Q: `rows` basis vectors of n elements, row stride ldq (elements); w: the matvec result, updated in place.
@@ -339,7 +355,7 @@ int qamd_microtree_run(int32_t dtype, const qamd_micro_step* steps_dev, int32_t 
  *                                                        re-based onto input_ptrs[i] at every run)
  *   qamd_program_run(P, lane_streams, input_ptrs, timing);   (lane 0 = the caller's stream: forked from / joined to)
  *
- * Recorded are: qamd_contract_pair(_ex), qamd_contract_chain2 / chain3, qamd_permute, qamd_reduce_sum, qamd_binary,
+ * Recorded are: qamd_contract_pair(_ex), qamd_contract_pair_dot, qamd_contract_chain2 / chain3, qamd_permute, qamd_reduce_sum, qamd_binary,
  * qamd_scale, qamd_axpby(_exp), qamd_conj, qamd_cast, qamd_fill, qamd_complex_expand, qamd_strip_exponent,
  * qamd_absmax_log10_sum(_add), qamd_div_by_absmax, qamd_unary, qamd_minmax, qamd_absmax.  Plan compilation
  * (qamd_pair_build_ktab) and qamd_microtree_run execute immediately.  Every buffer a recorded call names -- other

@@ -109,6 +109,9 @@ SYMBOLS = [
     ("qamd_unary", C.c_int, [_vp, _vp, _i64, _i32, _i32, _vp]),
     ("qamd_minmax", C.c_int, [_vp, _vp, _i64, _i32, _i32, _vp]),
     ("qamd_absmax_log10_sum_add", C.c_int, [_vp, _i64, _i32, _vp, _vp]),
+    # a join consumed by one inner product (gemmk.hip, DOT variant)
+    ("qamd_pair_dot_workspace_bytes", _i64, [_vp]),
+    ("qamd_contract_pair_dot", C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp]),
     # the vector work of a Lanczos step (krylov.hip)
     ("qamd_krylov_workspace_bytes", _i64, [_i32, _i64, _i32]),
     ("qamd_krylov_project", C.c_int, [_vp, _vp, _vp, _i64, _i32, _vp, _i64, _i32, _i32, _vp, _vp]),

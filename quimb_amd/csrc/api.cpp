@@ -539,8 +539,17 @@ static int launch_stream(const qamd_pair_plan* p, const PairDims& d, const void*
                             ep ? ep->scale_b : nullptr, ep ? ep->absmax_out : nullptr, stream);
 }
 
+extern "C" int qamd_gemmk_dot_launch(int ta, int tb, const GettArgs* a, const void* A, const void* B, const void* T,
+                                     void* partial, void* stream);
+extern "C" int qamd_gemmk_dot_finish(void* out, const void* partial, int n, const void* scale_a, const void* scale_b,
+                                     const void* scale_t, void* absmax_out, void* stream);
+
+// dot_T != NULL: the result is not stored but multiplied with the tensor at dot_T (C's layout) and summed -- one double
+// per workgroup into dot_partial (qamd_contract_pair_dot); C is then only consulted for its alignment class (= dot_T's)
 static int launch_gemmk(const qamd_pair_plan* p, const PairDims& d, const void* A, const void* B, void* C,
-                        const qamd_epilogue* ep, void* stream) {
+                        const qamd_epilogue* ep, void* stream, const void* dot_T = nullptr, void* dot_partial = nullptr,
+                        int* tiles_out = nullptr) {
+  if (dot_T) C = const_cast<void*>(dot_T);
   const int ta = p->tile_cfg / 16, tb = p->tile_cfg % 16;
   if (ta < 2 || ta > 4 || tb < 2 || tb > 4 || p->dtype != QAMD_F32 || p->nk != 1 || !A || !B || !C) return QAMD_EINVAL;
   if (((uintptr_t)A & 15) || ((uintptr_t)B & 15)) return QAMD_EINVAL;
@@ -580,6 +589,8 @@ static int launch_gemmk(const qamd_pair_plan* p, const PairDims& d, const void* 
     }
     a.vec_c = v;
   }
+  if (tiles_out) *tiles_out = (int)(a.tiles_m * a.tiles_n * a.B);
+  if (dot_T) return dot_partial ? qamd_gemmk_dot_launch(ta, tb, &a, swap ? B : A, swap ? A : B, dot_T, dot_partial, stream) : 0;
   const void* sa = ep ? (swap ? ep->scale_b : ep->scale_a) : nullptr;
   const void* sb = ep ? (swap ? ep->scale_a : ep->scale_b) : nullptr;
   return qamd_gemmk_launch(ta, tb, &a, swap ? B : A, swap ? A : B, C, sa, sb, ep ? ep->absmax_out : nullptr, stream);
@@ -632,6 +643,37 @@ static int launch_gemmd(const qamd_pair_plan* p, const PairDims& d, const void* 
   int rc = qamd_gemmd_launch(ta, tb, &a, swap, A, B, ws, ktab, nullptr, nullptr, nullptr, stream);
   if (rc) return rc;
   return qamd_splitk_reduce_launch(p->dtype, C, ws, csz, split, sa, sb, amax, stream);
+}
+
+// ---- a join consumed by one inner product (the closing step of a two-sided / four-quadrant contraction) -------------
+extern "C" int64_t qamd_pair_dot_workspace_bytes(const qamd_pair_plan* p) {
+  if (!p || p->kernel != 5) return 0;
+  PairDims d;
+  if (pair_dims(p, d)) return 0;
+  const int ta = p->tile_cfg / 16, tb = p->tile_cfg % 16;
+  if (ta < 2 || ta > 4 || tb < 2 || tb > 4) return 0;
+  const bool swap = !p->c_ncontig;
+  const int64_t M = swap ? d.N : d.M, N = swap ? d.M : d.N;
+  return (int64_t)sizeof(double) * d.B * ((M + 64 * ta - 1) / (64 * ta)) * ((N + 64 * tb - 1) / (64 * tb));
+}
+
+extern "C" int qamd_contract_pair_dot(const qamd_pair_plan* p, const void* A, const void* B, const void* T, void* out_dev,
+                                      void* ws, int64_t ws_bytes, const qamd_epilogue* ep, const void* scale_t,
+                                      void* stream) {
+  if (!p || !A || !B || !T || !out_dev) return QAMD_EINVAL;
+  if (p->kernel != 5 || p->dtype != QAMD_F32) return QAMD_EUNSUPPORTED;
+  if (qamdp_recording()) return qamdp_rec_pair_dot(p, A, B, T, out_dev, ws, ws_bytes, ep, scale_t);
+  PairDims d;
+  int rc = pair_dims(p, d);
+  if (rc) return rc;
+  const int64_t need = qamd_pair_dot_workspace_bytes(p);
+  if (need <= 0) return QAMD_EINVAL;
+  if (!ws || ws_bytes < need) return QAMD_EWORKSPACE;
+  int tiles = 0;
+  rc = launch_gemmk(p, d, A, B, nullptr, nullptr, stream, T, ws, &tiles);
+  if (rc) return rc;
+  return qamd_gemmk_dot_finish(out_dev, ws, tiles, ep ? ep->scale_a : nullptr, ep ? ep->scale_b : nullptr, scale_t,
+                               ep ? ep->absmax_out : nullptr, stream);
 }
 
 extern "C" int qamd_contract_pair_ex(const qamd_pair_plan* p, const void* A, const void* B, void* C,

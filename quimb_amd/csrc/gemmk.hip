@@ -85,7 +85,10 @@ __device__ __forceinline__ int kmap(int t, int i) {
   else return 32 * t + i;
 }
 
-template <int TA, int TB, int NS, int MINW>
+// DOT: the result tile is not stored -- it is multiplied element by element with the tensor `C` points at (same layout as
+// the result would have had) and summed: `absmax_out` then receives ONE double per workgroup (the partial inner product,
+// unscaled), finished by gemmk_dot_finish_kernel.
+template <int TA, int TB, int NS, int MINW, bool DOT = false>
 __global__ __launch_bounds__(256, MINW) void gemmk_kernel(const GettArgs p, const float* __restrict__ A,
                                                           const float* __restrict__ B, float* __restrict__ C,
                                                           const float* __restrict__ scale_a,
@@ -291,9 +294,48 @@ __global__ __launch_bounds__(256, MINW) void gemmk_kernel(const GettArgs p, cons
 
   // ---- epilogue ---------------------------------------------------------------------------------
   float* Cb = C + boffC;
+  const bool vecn = p.vec_c >= TB && (TB == 2 || TB == 4);   // TB consecutive n are contiguous and aligned in C
+  if constexpr (DOT) {
+    __shared__ double dred[4];
+    float dsum = 0.0f;
+#pragma unroll
+    for (int i = 0; i < TA; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int ml = wm * (32 * TA) + kmap<TA>(i, (r & 3) + 8 * (r >> 2) + 4 * kh);
+        if (m0 + ml >= p.M) continue;
+        const int64_t orow = offCm[ml];
+        if (vecn) {
+          const int nl = wn * (32 * TB) + TB * l31;
+          if (n0 + nl < p.N) {
+            const float* src = Cb + orow + offCn[nl];
+            if constexpr (TB == 4) {
+              const f4 t = *reinterpret_cast<const f4*>(src);
+              dsum += acc[i][0][r] * t[0] + acc[i][1][r] * t[1] + acc[i][2][r] * t[2] + acc[i][3][r] * t[3];
+            } else if constexpr (TB == 2) {
+              const f2 t = *reinterpret_cast<const f2*>(src);
+              dsum += acc[i][0][r] * t[0] + acc[i][1][r] * t[1];
+            }
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < TB; ++j) {
+            const int nl = wn * (32 * TB) + kmap<TB>(j, l31);
+            if (n0 + nl < p.N) dsum += acc[i][j][r] * Cb[orow + offCn[nl]];
+          }
+        }
+      }
+    }
+    double ds = (double)dsum;
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) ds += __shfl_down(ds, d, 64);
+    if (lane == 0) dred[wave] = ds;
+    __syncthreads();
+    if (tid == 0) reinterpret_cast<double*>(absmax_out)[blockIdx.x] = (dred[0] + dred[1]) + (dred[2] + dred[3]);
+    return;
+  }
   const float alpha = 1.0f / (kread_scale(scale_a) * kread_scale(scale_b));
   float vmax = 0.0f;
-  const bool vecn = p.vec_c >= TB && (TB == 2 || TB == 4);   // TB consecutive n are contiguous and aligned in C
 #pragma unroll
   for (int i = 0; i < TA; ++i) {
 #pragma unroll
@@ -337,18 +379,41 @@ __global__ __launch_bounds__(256, MINW) void gemmk_kernel(const GettArgs p, cons
   }
 }
 
-template <int TA, int TB, int NS, int MINW>
+// the workgroups' partial inner products in a fixed order, scaled like a stored result would have been
+__global__ __launch_bounds__(256) void gemmk_dot_finish_kernel(float* __restrict__ out, const double* __restrict__ partial,
+                                                               int n, const float* __restrict__ scale_a,
+                                                               const float* __restrict__ scale_b,
+                                                               const float* __restrict__ scale_t,
+                                                               float* __restrict__ absmax_out) {
+  __shared__ double red[4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  double s = 0.0;
+  for (int i = tid; i < n; i += 256) s += partial[i];
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) s += __shfl_down(s, d, 64);
+  if (lane == 0) red[wave] = s;
+  __syncthreads();
+  if (tid == 0) {
+    const double z = ((red[0] + red[1]) + (red[2] + red[3])) /
+                     ((double)kread_scale(scale_a) * (double)kread_scale(scale_b) * (double)kread_scale(scale_t));
+    out[0] = (float)z;
+    if (absmax_out) absmax_out[0] = (float)(z < 0.0 ? -z : z);
+  }
+}
+
+template <int TA, int TB, int NS, int MINW, bool DOT = false>
 static int launch_one(const GettArgs& a, const void* A, const void* B, void* C, const void* sa, const void* sb, void* amax,
                       hipStream_t st) {
   constexpr int BM = 64 * TA, BN = 64 * TB;
   const size_t lds = (size_t)NS * 16 * (BM + BN) * sizeof(float) + (size_t)(BM + BN) * sizeof(int64_t);
   static bool attr_done = false;
   if (!attr_done && lds > 64 * 1024) {
-    (void)hipFuncSetAttribute((const void*)gemmk_kernel<TA, TB, NS, MINW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)gemmk_kernel<TA, TB, NS, MINW, DOT>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)lds);
     attr_done = true;
   }
   const unsigned grid = a.tiles_m * a.tiles_n * a.B;
-  QAMD_LAUNCH((gemmk_kernel<TA, TB, NS, MINW>), dim3(grid), dim3(256), lds, st, a, (const float*)A, (const float*)B,
+  QAMD_LAUNCH((gemmk_kernel<TA, TB, NS, MINW, DOT>), dim3(grid), dim3(256), lds, st, a, (const float*)A, (const float*)B,
               (float*)C, (const float*)sa, (const float*)sb, (float*)amax);
   return hipGetLastError() == hipSuccess ? 0 : -4;
 }
@@ -371,4 +436,27 @@ extern "C" int qamd_gemmk_launch(int ta, int tb, const GettArgs* a, const void* 
   QK_CASE(4, 2, 1) QK_CASE(2, 4, 1) QK_CASE(3, 2, 2) QK_CASE(2, 3, 2) QK_CASE(2, 2, 2)
 #undef QK_CASE
   return -2;
+}
+
+// The same product, consumed by ONE inner product with T (laid out as the result would have been) instead of stored:
+// partial[0 .. tiles) receives one double per workgroup; qamd_gemmk_dot_finish sums them in a fixed order and applies the
+// operands' scales.  Same preconditions as qamd_gemmk_launch; T 16-byte aligned where a->vec_c says so.
+extern "C" int qamd_gemmk_dot_launch(int ta, int tb, const GettArgs* a, const void* A, const void* B, const void* T,
+                                     void* partial, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (a->K < 48 || a->K % 8 || a->M < 4 || a->N < 4 || a->M % 4 || a->N % 4) return -2;
+#define QK_CASE(TA_, TB_, MINW_) \
+  if (ta == TA_ && tb == TB_)    \
+    return launch_one<TA_, TB_, 3, MINW_, true>(*a, A, B, const_cast<void*>(T), nullptr, nullptr, partial, st);
+  QK_CASE(4, 4, 1) QK_CASE(4, 3, 1) QK_CASE(3, 4, 1) QK_CASE(3, 3, 1)
+  QK_CASE(4, 2, 1) QK_CASE(2, 4, 1) QK_CASE(3, 2, 2) QK_CASE(2, 3, 2) QK_CASE(2, 2, 2)
+#undef QK_CASE
+  return -2;
+}
+
+extern "C" int qamd_gemmk_dot_finish(void* out, const void* partial, int n, const void* scale_a, const void* scale_b,
+                                     const void* scale_t, void* absmax_out, void* stream) {
+  QAMD_LAUNCH(gemmk_dot_finish_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (float*)out, (const double*)partial, n,
+              (const float*)scale_a, (const float*)scale_b, (const float*)scale_t, (float*)absmax_out);
+  return hipGetLastError() == hipSuccess ? 0 : -4;
 }

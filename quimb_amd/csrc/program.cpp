@@ -104,6 +104,16 @@ int qamdp_rec_pair(const qamd_pair_plan* p, const void* A, const void* B, void* 
   o.iv[1] = ep ? 1 : 0;
   return QAMD_OK;
 }
+int qamdp_rec_pair_dot(const qamd_pair_plan* p, const void* A, const void* B, const void* T, void* out, void* ws,
+                       int64_t ws_bytes, const qamd_epilogue* ep, const void* scale_t) {
+  if (!p) return QAMD_EINVAL;
+  Op& o = push(QP_PAIRDOT, {A, B, T, out, ws, ep ? ep->scale_a : nullptr, ep ? ep->scale_b : nullptr,
+                           ep ? ep->absmax_out : nullptr, scale_t});
+  put_blob(o, p);
+  o.iv[0] = ws_bytes;
+  o.iv[1] = ep ? 1 : 0;
+  return QAMD_OK;
+}
 int qamdp_rec_chain2(const qamd_chain2_plan* p, const void* A, const void* W1, const void* W2, void* C, const void* k1,
                      const void* co, const void* sa, const void* s1, const void* s2, void* amax) {
   if (!p) return QAMD_EINVAL;
@@ -263,6 +273,11 @@ static int run_op(const Op& o, const void* const* q, void* st) {
       qamd_epilogue ep{q[5], q[6], P0(7)};
       return qamd_contract_pair_ex((const qamd_pair_plan*)o.blob.data(), q[0], q[1], P0(2), q[3], P0(4), o.iv[0],
                                    o.iv[1] ? &ep : nullptr, st);
+    }
+    case QP_PAIRDOT: {
+      qamd_epilogue ep{q[5], q[6], P0(7)};
+      return qamd_contract_pair_dot((const qamd_pair_plan*)o.blob.data(), q[0], q[1], q[2], P0(3), P0(4), o.iv[0],
+                                    o.iv[1] ? &ep : nullptr, q[8], st);
     }
     case QP_CHAIN2:
       return qamd_contract_chain2((const qamd_chain2_plan*)o.blob.data(), q[0], q[1], q[2], P0(3), q[4], q[5], q[6],

@@ -261,6 +261,45 @@ class HipDevice:
             prof.append((spec, np.dtype(dtype), self.describe_pair(cp), cp.struct.split_k, e0, e1))
         self.release_temp(ws_keep)
 
+    def contract_pair_dot(self, spec, dtype, a, b, t, out, ep=None):
+        """``out[0] = sum((A . B) * T)`` with the product never stored (gemmk.hip, DOT variant): a join whose result is
+        only consumed by one inner product with ``t``, a tensor of the layout the result would have had.  ``ep`` =
+        (slots_a, slots_b, slots_t, slots_out) or None.  Returns False -- nothing launched -- when the planner did not put
+        this contraction on the kernel that can do it; the caller then issues the two steps."""
+        if np.dtype(dtype) != np.dtype("float32"):
+            return False
+        pa, pb, pt = a.data_ptr(), b.data_ptr(), t.data_ptr()
+        cp = self.compile_pair(spec, dtype, min(pa & -pa, 16), min(pb & -pb, 16), min(pt & -pt, 16))
+        if cp.struct.kernel != 5:
+            return False
+        nws = int(self.lib.qamd_pair_dot_workspace_bytes(C.byref(cp.struct)))
+        if nws <= 0:
+            return False
+        ws_keep, ws, wsn = self._workspace(nws)
+        ptr = lambda x: (x.data_ptr() if x is not None else None)
+        epp, st = None, None
+        if ep is not None:
+            e = _lib.Epilogue()
+            e.scale_a, e.scale_b, e.absmax_out = ptr(ep[0]), ptr(ep[1]), ptr(ep[3])
+            epp, st = C.byref(e), ptr(ep[2])
+        prof = self.profile
+        if prof is not None and getattr(spec, "mults", self.profile_min_mults) < self.profile_min_mults:
+            prof = None
+        name = lambda: self.describe_pair(cp) + " + dot"
+        if self.record is not None:
+            prof = None
+            self.record.maybe_mark(spec, np.dtype(dtype), lambda: (name(), 1))
+        if prof is not None:
+            e0, e1 = self.torch.cuda.Event(enable_timing=True), self.torch.cuda.Event(enable_timing=True)
+            e0.record()
+        _lib.check(self.lib.qamd_contract_pair_dot(C.byref(cp.struct), pa, pb, pt, out.data_ptr(), ws, wsn, epp, st,
+                                                   self.stream()), "qamd_contract_pair_dot")
+        if prof is not None:
+            e1.record()
+            prof.append((spec, np.dtype(dtype), name(), 1, e0, e1))
+        self.release_temp(ws_keep)
+        return True
+
     # ---- fused pair of streaming steps ---------------------------------------------
     def contract_chain2(self, c2, dtype, a, w1, w2, c, ep=None):
         """C = (A . W1) . W2 in one pass (chain2r.hip / chain2.hip).  ``c2``: pairwise.Chain2Spec;

@@ -18,6 +18,7 @@ This is the MI355X replacement for the per-step python loop inside
 
 import os
 
+import numpy as np
 
 from .array import Array, asarray, _coerce_dtype
 from .ops import _einsum_single, run_pair_step
@@ -114,6 +115,7 @@ class TreeExecutor:
         self.layout = layout
         self.dep = dep
         self._fuse_pairs(size)
+        self._fuse_join_dot()
         self._assign_lanes()
         if len(tree.remaining) != 1:
             raise ValueError("contraction path does not reduce the network to a single tensor")
@@ -181,6 +183,32 @@ class TreeExecutor:
                 i += 1
         self.plan, self.info = new_plan, new_info
 
+    def _fuse_join_dot(self):
+        """The closing two steps of a two-sided contraction -- a GEMM-shaped join whose result then meets a tensor of the
+        SAME layout in one inner product over all indices (the quadrant tree: B = BL.BR, then sum(T * B)) -- become one
+        plan entry: the device multiplies every result tile with the matching tile of ``t`` and sums, so the join's result
+        is never written or read back (``qamd_contract_pair_dot``; fp32 joins on the k-outer MFMA kernel, anything else is
+        executed as the two steps it was).  ``QAMD_JOIN_DOT=0`` keeps the steps apart."""
+        if self.dtype != np.dtype("float32") or self.tree.nslices != 1 or len(self.plan) < 2 \
+                or os.environ.get("QAMD_JOIN_DOT", "1") == "0":
+            return
+        last, prev = self.plan[-1], self.plan[-2]
+        if last[0] != "pair" or prev[0] != "pair":
+            return
+        _, da, db, dres, dstep = last
+        _, ja, jb, jres, jstep = prev
+        if dstep.kind != "gett" or jstep.kind != "gett" or any(dstep.pre) or any(jstep.pre) or jres not in (da, db) or da == db:
+            return
+        t = db if da == jres else da
+        g, gd = jstep.spec, dstep.spec
+        if gd.B * gd.M * gd.N != 1 or self.layout[t] != self.layout[jres] or len(g.k) != 1 or g.K < 64 \
+                or g.B * g.M * g.N < (1 << 20) or g.b:
+            return
+        isz = self.dtype.itemsize
+        self.plan[-2:] = [("pairdot", ja, jb, t, dres, jstep, dstep, jres, da == jres)]
+        self.info[-2:] = [StepInfo("gett", jstep.mults + dstep.mults,
+                                   isz * g.B * (g.M * g.K + g.K * g.N + g.M * g.N), (g.B, g.M, g.N, g.K), False)]
+
     @staticmethod
     def _entry_io(entry):
         """(operand ssa ids, result ssa id) of a plan entry"""
@@ -191,6 +219,8 @@ class TreeExecutor:
             return (entry[1], entry[2], entry[3]), entry[4]
         if k == "chain3":
             return (entry[1], entry[2], entry[3], entry[4]), entry[5]
+        if k == "pairdot":
+            return (entry[1], entry[2], entry[3]), entry[4]
         return (entry[1], entry[2]), entry[3]
 
     def _assign_lanes(self, max_lanes=8, min_steps=4):
@@ -229,7 +259,7 @@ class TreeExecutor:
                 for c in (reversed(big) if self.join_order else big):
                     if len(big_kids(c)) >= 2 or nxt[0] >= max_lanes:
                         stack.append((c, ln))          # a join below a join / out of lanes: same lane
-                    elif ln == 0 and not home_taken[0]:
+                    elif ln == 0 and not home_taken[0] and not (self.join_order and any(len(big_kids(c_)) >= 2 for c_ in big)):
                         home_taken[0] = True           # ONE chain runs ahead of the joins on the caller's stream:
                         stack.append((c, 0))           # four corner sweeps = four streams = the default HW queues
                     else:
@@ -434,11 +464,35 @@ class TreeExecutor:
                 return (entry[1], entry[2], entry[3])
             if entry[0] == "chain3":
                 return (entry[1], entry[2], entry[3], entry[4])
+            if entry[0] == "pairdot":
+                return (entry[1], entry[2], entry[3])
             return (entry[1], entry[2])
 
         for entry in self.plan:
             for s in operands(entry):
                 uses[s] = uses.get(s, 0) + 1
+        def run_pair(a, b, res, step):
+            """one pairwise step on the live operands (with the fused exponent epilogue where the kernels have one)"""
+            if exponent is not None and step.kind == "gett" and self.dtype.kind != "c":
+                ep = (
+                    dev.slots_row(slots, a) if a in has_scale else None,
+                    dev.slots_row(slots, b) if b in has_scale else None,
+                    dev.slots_row(slots, res),
+                )
+                x = run_pair_step(step, live[a], live[b], ep=ep)
+                has_scale.add(res)
+                return x
+            xa, xb = live[a], live[b]
+            if exponent is not None:
+                # operands with a pending (deferred) division: apply it now
+                for s_, x_ in ((a, xa), (b, xb)):
+                    if s_ in has_scale:
+                        dev.div_by_absmax(x_._buf, x_.size, dev.slots_row(slots, s_), x_.dtype)
+            x = run_pair_step(step, xa, xb)
+            if exponent is not None and x.size:
+                dev.strip_exponent(x._buf, x.size, x.dtype, exponent)
+            return x
+
         for pi, entry in enumerate(self.plan):
             if laned:
                 for o in self._entry_io(entry)[0]:
@@ -517,6 +571,26 @@ class TreeExecutor:
                     if independent and cache is not None:
                         cache[res] = x
                 ids = (a, w1, w2, w3)
+            elif entry[0] == "pairdot":
+                _, a, b, t, res, jstep, dstep, jres, join_first = entry
+                x = Array.empty(dstep.out_shape, self.dtype, dev)
+                ka, kb = (b, a) if jstep.swapped else (a, b)
+                ep = None
+                if exponent is not None:
+                    ep = tuple(dev.slots_row(slots, s_) if s_ in has_scale else None for s_ in (ka, kb, t))
+                    ep = ep + (dev.slots_row(slots, res),)
+                fused = getattr(dev, "contract_pair_dot", None)
+                if fused is not None and fused(jstep.spec, self.dtype, live[ka]._buf, live[kb]._buf, live[t]._buf, x._buf, ep):
+                    if exponent is not None:
+                        has_scale.add(res)
+                else:           # not a contraction the device fuses: the two steps it was
+                    live[jres] = run_pair(a, b, jres, jstep)
+                    x = run_pair(*((jres, t) if join_first else (t, jres)), res, dstep)
+                    gone = live.pop(jres, None)
+                    if rec is not None and gone is not None:
+                        rec.release(gone._buf)
+                live[res] = x
+                ids = (a, b, t)
             else:
                 _, a, b, res, step = entry
                 independent = not self.dep[res]
@@ -525,24 +599,7 @@ class TreeExecutor:
                 elif only_independent and not independent:
                     continue
                 else:
-                    if exponent is not None and step.kind == "gett" and self.dtype.kind != "c":
-                        ep = (
-                            dev.slots_row(slots, a) if a in has_scale else None,
-                            dev.slots_row(slots, b) if b in has_scale else None,
-                            dev.slots_row(slots, res),
-                        )
-                        x = run_pair_step(step, live[a], live[b], ep=ep)
-                        has_scale.add(res)
-                    else:
-                        xa, xb = live[a], live[b]
-                        if exponent is not None:
-                            # operands with a pending (deferred) division: apply it now
-                            for s_, x_ in ((a, xa), (b, xb)):
-                                if s_ in has_scale:
-                                    dev.div_by_absmax(x_._buf, x_.size, dev.slots_row(slots, s_), x_.dtype)
-                        x = run_pair_step(step, xa, xb)
-                        if exponent is not None and x.size:
-                            dev.strip_exponent(x._buf, x.size, x.dtype, exponent)
+                    x = run_pair(a, b, res, step)
                     live[res] = x
                     if independent and cache is not None:
                         cache[res] = x

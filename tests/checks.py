@@ -601,6 +601,50 @@ def check_gemmd(seed=31, tiles=(None,)):
     assert np.max(np.abs(m.to_numpy())) == pytest.approx(1.0, rel=1e-12)
 
 
+def check_join_dot(cases=((1024, 1024, 64), (1100, 1180, 96), (2048, 1536, 200)), expect_fused=True):
+    """A join whose result meets a tensor of the same layout in one inner product (the closing steps of a two-sided /
+    four-quadrant contraction): Z = sum_{l,r} (TL^T TR)[l, r] (BL^T BR)[l, r].  The executor hands the second join and
+    the sum to the device as ONE launch (``qamd_contract_pair_dot``: the join's result is never stored); checked
+    against fp64 numpy and against the same tree executed with the two steps apart (``QAMD_JOIN_DOT=0``), plain and with
+    strip_exponent, on tile-aligned and ragged shapes."""
+    import os
+
+    rng = np.random.default_rng(77)
+    for (L, R, H) in cases:
+        tl, tr = rand(rng, (H, L), "float32"), rand(rng, (H, R), "float32")
+        bl, br = rand(rng, (H, L), "float32") * 3e4, rand(rng, (H, R), "float32") * 1e-3
+        want = float(np.sum((tl.astype(np.float64).T @ tr.astype(np.float64)) * (bl.astype(np.float64).T @ br.astype(np.float64))))
+        inputs = [("h", "l"), ("h", "r"), ("g", "l"), ("g", "r")]
+        size = dict(h=H, g=H, l=L, r=R)
+        tree = qa.ContractionTree(inputs, (), size, path=[(0, 1), (0, 1), (0, 1)])
+        xs = [qa.asarray(x) for x in (tl, tr, bl, br)]
+        ex = qa.TreeExecutor(tree, "float32")
+        assert (ex.plan[-1][0] == "pairdot") == expect_fused, ex.plan[-1][0]
+        got = ex(xs).to_numpy().item()
+        m, e = ex(xs, strip_exponent=True)
+        got_s = m.to_numpy().item() * 10.0 ** e
+        os.environ["QAMD_JOIN_DOT"] = "0"
+        try:
+            ex0 = qa.TreeExecutor(tree, "float32")
+        finally:
+            del os.environ["QAMD_JOIN_DOT"]
+        assert ex0.plan[-1][0] == "pair" and ex0.flops() == ex.flops()
+        ref = ex0(xs).to_numpy().item()
+        for val in (got, got_s, ref):
+            assert abs(val - want) <= 1e-5 * abs(want), ((L, R, H), val, want)
+        assert abs(abs(m.to_numpy().item()) - 1.0) <= 1e-6
+        # T first, the join second; T an INPUT (in the layout the executor gives the join's result), not a product
+        t_host = (tl.astype(np.float64).T @ tr.astype(np.float64)).astype(np.float32)
+        lay = ex0.plan[-2][4].out_inds
+        tree2 = qa.ContractionTree([lay, ("g", "l"), ("g", "r")], (), size, path=[(1, 2), (0, 1)])
+        ex2 = qa.TreeExecutor(tree2, "float32")
+        assert (ex2.plan[-1][0] == "pairdot") == expect_fused and (not expect_fused or ex2.plan[-1][8] is False)
+        want2 = float(np.sum(t_host.astype(np.float64) * (bl.astype(np.float64).T @ br.astype(np.float64))))
+        t_in = t_host if lay == ("l", "r") else np.ascontiguousarray(t_host.T)
+        got2 = ex2([qa.asarray(t_in), xs[2], xs[3]]).to_numpy().item()
+        assert abs(got2 - want2) <= 1e-5 * abs(want2)
+
+
 # ---------------------------------------------------------------------------
 # golden vectors generated by the real quimb (tests/golden/make_golden.py)
 # ---------------------------------------------------------------------------

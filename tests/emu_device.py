@@ -66,6 +66,25 @@ class EmuDevice:
         assert len(np.unique(idx)) == idx.size, "output offsets collide"
         c[idx] = C
 
+    def contract_pair_dot(self, spec, dtype, a, b, t, out, ep=None):
+        """Semantics of qamd_contract_pair_dot (include/quimb_amd.h): the join's result meets ``t`` element by element and
+        is summed; nothing but the scalar is written.  (The interpreter takes it for fp32 GEMM-shaped joins -- one K group,
+        K >= 64 -- which is where the library's planner uses the kernel that supports it.)"""
+        if np.dtype(dtype) != np.float32 or len(spec.k) != 1 or spec.K < 64:
+            return False
+        self.calls["pair_dot"] = self.calls.get("pair_dot", 0) + 1
+        tmp = np.zeros(max(int(spec.B * spec.M * spec.N), 1), np.dtype(dtype))       # the result, C-contiguous like t
+        self.contract_pair(spec, dtype, a, b, tmp, None)
+        z = float(np.dot(tmp.astype(np.float64), t[: tmp.size].astype(np.float64)))
+        if ep is not None:
+            for sl in ep[:3]:
+                m = float(sl.max()) if sl is not None else 0.0
+                z /= m if m > 0 else 1.0
+            if ep[3] is not None:
+                ep[3][0] = abs(z)
+        out[0] = z
+        return True
+
     def contract_chain2(self, c2, dtype, a, w1, w2, c, ep=None):
         """Semantics of qamd_contract_chain2 (see include/quimb_amd.h); the small tensors arrive in
         their own layouts and are gathered as ``c2.w1_pack`` / ``w2_pack`` describe."""

@@ -323,6 +323,21 @@ def test_krylov_step(hip, dtype):
     checks.check_krylov_step(dtype)
 
 
+def test_join_dot(hip):
+    """the second join + closing inner product as one launch: fused, unfused and fp64 numpy agree.  The first two cases are
+    joins the planner keeps off the k-outer kernel (the device declines, the two steps run); the others take its DOT
+    variant on four different tiles, with ragged edges in both directions"""
+    hip.profile, hip.profile_min_mults = [], 0
+    try:
+        checks.check_join_dot(cases=((1024, 1024, 64), (1100, 1180, 96), (2048, 1536, 200), (2500, 3100, 136),
+                                     (4100, 1900, 264), (3000, 3000, 72)))
+        names = [r[2] for r in hip.profile]
+    finally:
+        hip.profile = None
+    fused = [n for n in names if n.startswith("gemmk_kernel<") and n.endswith("+ dot")]
+    assert len(fused) == 12 and len(set(fused)) >= 3, names
+
+
 @pytest.mark.parametrize("dtype", ["complex64", "complex128"])
 def test_microtree(hip, dtype):
     checks.check_microtree(dtype)

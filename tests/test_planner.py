@@ -107,3 +107,21 @@ def test_what_gemmd_does_not_cover():
     assert k6("muk", (2048, 24, 32), "kun", (32, 24, 2048), "mn")                          # ... 32: fine, the outer group is free
     name, p = _describe("mk", (128, 512), "kn", (512, 128), "mn", dtype="float64", env={"QAMD_GEMMD_TILE": "21"})
     assert p.kernel == 6 and name.startswith("gemmd_kernel<2, 1, true, false, false>")     # pinning overrides the floors
+
+
+def test_join_dot_workspace_follows_the_gemmk_tiles():
+    """qamd_contract_pair_dot (the second join + closing inner product in one launch) needs one double per workgroup of
+    the k-outer kernel; plans on other kernels report 0 = not supported."""
+    from quimb_amd import _lib
+
+    lib = _lib.load()
+    name, p = _describe("km", (7776, 7776), "kn", (7776, 7776), "mn")
+    assert name == "gemmk_kernel<3, 4, 3, 1>"
+    assert lib.qamd_pair_dot_workspace_bytes(C.byref(p)) == 8 * 41 * 31
+    name, p = _describe("km", (7776, 3888), "kn", (7776, 1944), "mn")          # one rank of eight: 128 x 256 tiles
+    assert lib.qamd_pair_dot_workspace_bytes(C.byref(p)) == 8 * 31 * 8
+    name, p = _describe("km", (512, 2048), "kn", (512, 2048), "mn", dtype="float64")
+    assert p.kernel != 5 and lib.qamd_pair_dot_workspace_bytes(C.byref(p)) == 0
+    # without a device nothing can be launched, but the refusal of an unsupported plan is host logic
+    one = (C.c_float * 4)()
+    assert lib.qamd_contract_pair_dot(C.byref(p), one, one, one, one, None, 0, None, None, None) == -2      # QAMD_EUNSUPPORTED
