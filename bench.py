@@ -513,17 +513,20 @@ def main():
         agg = {}
         for spec, dt_, name, sk, e0, e1 in prof:
             shape, nbytes, nflops = _launch_work(spec)
-            key = (name, tuple(sorted(shape.items())))
-            a = agg.setdefault(key, [0.0, 0, shape, nbytes, nflops])
+            # (the second join carries the closing inner product in its epilogue -- "<name> + dot", the DOT instantiation of
+            # the same kernel on the same GEMM: one class with the plain launches)
+            key = (name[:-len(" + dot")] if name.endswith(" + dot") else name, tuple(sorted(shape.items())))
+            a = agg.setdefault(key, [0.0, 0, shape, nbytes, nflops, 0])
             a[0] += e0.elapsed_time(e1) * 1e-3
             a[1] += 1
+            a[5] += name.endswith(" + dot")
         if os.environ.get("QAMD_BENCH_KERNELS"):   # per-kernel table of the timed region (stderr)
-            for (name, shp), (tsum, cnt, _, nb, nf) in sorted(agg.items(), key=lambda kv: -kv[1][0]):
+            for (name, shp), (tsum, cnt, _, nb, nf, _nd) in sorted(agg.items(), key=lambda kv: -kv[1][0]):
                 print(f"  {tsum / args.steps * 1e3:8.3f} ms/step  {cnt // args.steps:4d} x {tsum / cnt * 1e3:7.3f} ms  "
                       f"{nb / (tsum / cnt) / 1e9:7.0f} GB/s {nf / (tsum / cnt) / 1e12:6.1f} TF  {name}  {dict(shp)}", file=sys.stderr)
         roof = None
         if agg:
-            key, (tsum, cnt, shape, bytes_launch, flops_launch) = max(agg.items(), key=lambda kv: kv[1][0])
+            key, (tsum, cnt, shape, bytes_launch, flops_launch, ndot) = max(agg.items(), key=lambda kv: kv[1][0])
             cfg = key[0]
             avg = tsum / cnt
             ai = flops_launch / bytes_launch
@@ -553,6 +556,8 @@ def main():
             roof["tflops"] = flops_launch / avg / 1e12
             roof["avg_launch_ms"] = avg * 1e3
             roof["launches_timed"] = cnt
+            if ndot:
+                roof["launches_with_fused_inner_product"] = ndot     # rocprofv3 lists them as the <..., true> instantiation
             roof["timed_in"] = ("one untimed launch-by-launch pass after the timed region (the timed region replays hipGraphs)"
                                 if graphed else "the timed region (HIP events on the launch stream, launches >= 1e9 multiplications)")
             roof["share_of_step_time"] = tsum / (dt / args.steps * (1 if graphed else args.steps))

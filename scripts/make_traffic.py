@@ -29,13 +29,19 @@ _, pf = rows(f"{out}/{tag}_bench_fetch.txt")
 _, pw = rows(f"{out}/{tag}_bench_write.txt")
 
 
+def norm(name):
+    """rocprofv3 prints every template argument; qamd_pair_describe leaves out gemmk's trailing DOT flag: the plain
+    instantiation <..., false> is the kernel the roofline names"""
+    return name[:-len(", false>")] + ">" if name.endswith(", false>") else name
+
+
 def pick(d, counter=None):
     best = None
     for k, v in d.items():
         name = k[0] if counter else k
         if counter and k[1] != counter:
             continue
-        if name.split(" grid=")[0] == kern and (best is None or v[1] > best[1][1]):
+        if norm(name.split(" grid=")[0]) == kern and (best is None or v[1] > best[1][1]):
             best = (k, v)
     return best
 
@@ -46,8 +52,9 @@ _, pr = rows(f"{out}/{tag}_bench_rdreq.txt")
 rq = {c: pick(pr, c) for c in ("TCC_EA0_RDREQ_sum", "TCC_EA0_RDREQ_128B_sum", "TCC_EA0_RDREQ_32B_sum")}
 # the counters are per (dispatch, XCD-instance) samples: sum / launches = per-launch total
 launches = kd[1][0]
-fetch_kb = kf[1][1] / launches
-write_kb = kw[1][1] / launches
+# (each counter pass counts its own launches: a --pmc run of the same command need not see as many as the timing pass)
+fetch_kb = kf[1][1] / kf[1][0]
+write_kb = kw[1][1] / kw[1][0]
 # (a counter that stayed at zero may have dropped off the bottom of the summary)
 n_all, n128, n32 = ((rq[c][1][1] / rq[c][1][0]) if rq[c] else 0.0
                     for c in ("TCC_EA0_RDREQ_sum", "TCC_EA0_RDREQ_128B_sum", "TCC_EA0_RDREQ_32B_sum"))
