@@ -26,6 +26,11 @@ from .pairwise import plan_chain2, plan_chain3, plan_pair, prod
 from .tree import ContractionTree
 
 
+#: a first join of at least this many multiplications is long enough for the later joins' chains to run beside it
+#: (``TreeExecutor._order_for_joins``): between the 2.35e11 of a rank of two (loses) and the 4.7e11 of the whole network (gains)
+HOLD_LATE_MIN_MULTS = 3.5e11
+
+
 class StepInfo:
     __slots__ = ("kind", "mults", "bytes", "M", "N", "K", "B", "sliced_dep")
 
@@ -334,6 +339,20 @@ class TreeExecutor:
             for i in range(n):
                 if need[i] == first:
                     self.lane_priority[self.lanes[i]] = -1
+        # HOLD: the chains of the LATER joins wait until the first join's own chains are done, i.e. they run beside the
+        # first join, not beside its chains.  Beside a join a sweep crawls (an eighth of its speed: the join holds every
+        # CU's LDS and matrix pipe) and ends shortly after it, so this pays only when the join is long: the 7 ms joins of the
+        # whole 10x10 D=6 network (4.96 rounds of tiles) gain 0.2 ms per step (two corner sweeps in 1.03 ms instead of four
+        # in 1.85 ms, the join 0.25 ms slower), the 3.5 / 1.8 / 0.95 ms joins of a rank of 2 / 4 / 8 LOSE 0.2-0.35 ms
+        # (measured, round 4).  QAMD_HOLD_LATE=0 / 1 forces it off / on.
+        self.hold_late = None
+        hold = os.environ.get("QAMD_HOLD_LATE", "auto")
+        if len(anchors) > 1 and hold != "0" and (hold == "1" or self.info[anchors[0]].mults >= HOLD_LATE_MIN_MULTS):
+            first = anchors[0]
+            early = sorted({self.lanes[i] for i in range(n) if need[i] == first and i != first})
+            late = sorted({self.lanes[i] for i in range(n) if need[i] is not None and need[i] != first} - set(early) - {0})
+            if late:
+                self.hold_late = (order.index(first), late, early)      # (position of the first join in the issue order, ...)
         self.plan = [self.plan[i] for i in order]
         self.info = [self.info[i] for i in order]
         self.lanes = [self.lanes[i] for i in order]
@@ -493,7 +512,17 @@ class TreeExecutor:
                 dev.strip_exponent(x._buf, x.size, x.dtype, exponent)
             return x
 
+        held = getattr(self, "hold_late", None)
         for pi, entry in enumerate(self.plan):
+            if laned and held is not None and pi == held[0]:
+                # right before the first join is issued: the later joins' chains wait for what its chains have been
+                # given so far (= all of them), not for the join itself
+                for late_ in held[1]:
+                    for early_ in held[2]:
+                        if rec is not None:
+                            rec.wait(late_, early_)
+                        else:
+                            streams[late_].wait_stream(streams[early_])
             if laned:
                 for o in self._entry_io(entry)[0]:
                     pj = self._producer.get(o)
@@ -641,7 +670,8 @@ class TreeExecutor:
         # join takes 1.8 ms beside a corner sweep -- the sweeps evict its operand panels from the L2), and a program's
         # host side is no bottleneck: record the plain order -- every chain side by side, then the joins
         ex = self
-        if self.join_order and self.nlanes > 1 and os.environ.get("QAMD_PROGRAM_JOIN_ORDER", "0") != "1":
+        if self.join_order and self.nlanes > 1 and getattr(self, "hold_late", None) is None \
+                and os.environ.get("QAMD_PROGRAM_JOIN_ORDER", "0") != "1":
             ex = getattr(self, "_plain_order_twin", None)
             if ex is None:
                 ex = self._plain_order_twin = TreeExecutor(self.tree, self.dtype, join_order=False)

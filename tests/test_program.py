@@ -76,6 +76,42 @@ def test_recording_the_quadrant_tree(recdev, dtype, strip):
     assert all(p in [x._buf.data_ptr() for x in xs] for p in prog._in_ptrs0)
 
 
+def test_later_chains_are_held_behind_the_first_joins_chains(recdev, monkeypatch):
+    """A long first join (the 7 ms joins of the whole 10x10 D=6 network) has the later join's corner sweeps run BESIDE it:
+    they wait for the first join's own chains, not for the join.  A rank's shorter joins do not (measured: they lose).
+    The rule, its override, and the waits a recorded program carries for it."""
+    import quimb_amd.executor as qe
+    from bench import build_network
+    from quimb_amd.quadrants import QuadrantRank, QuadrantSharding
+
+    arrays, inputs, size = build_network(10, 10, 6, 7, "float32")
+    ex = qa.TreeExecutor(qa.ContractionTree(inputs, (), size, path=qa.quadrant_path_2d(10, 10)), "float32")
+    pos, late, early = ex.hold_late
+    assert ex.plan[pos][0] == "pair" and ex.info[pos].mults == 7776**3 and ex.lanes[pos] == 0
+    assert len(late) == 2 and len(early) == 2 and not set(late) & set(early) and 0 in early
+    # everything the first join needs is issued before it, nothing of the late lanes is
+    assert all(ex.lanes[i] in early for i in range(pos)) and all(ex.lanes[i] in late + [0] for i in range(pos + 1, len(ex.plan)))
+    for w in (2, 4, 8):
+        sh = QuadrantSharding(inputs, size, 10, 10, w)
+        assert QuadrantRank(sh, 0, "float32").executor.hold_late is None
+    monkeypatch.setenv("QAMD_HOLD_LATE", "0")
+    assert qa.TreeExecutor(ex.tree, "float32").hold_late is None
+    # a small network with the rule forced on: the program records one wait per (late lane, early lane) on top of the
+    # fork and the cross-lane hand-overs, and stays in join order (no plain-order twin)
+    monkeypatch.setenv("QAMD_HOLD_LATE", "1")
+    arrays, inputs, size = _network(6, 3, "float32")
+    ex = qa.TreeExecutor(qa.ContractionTree(inputs, (), size, path=qa.quadrant_path_2d(6, 6)), "float32")
+    assert ex.hold_late is not None
+    prog = ex.program([qa.asarray(a) for a in arrays], strip_exponent=True)
+    assert prog.executor is ex
+    cross = sum(1 for i, e in enumerate(ex.plan) for o in ex._entry_io(e)[0]
+                if o in ex._producer and ex.lanes[ex._producer[o]] != ex.lanes[i])
+    assert prog.num_ops - prog.num_launches == (ex.nlanes - 1) + cross + len(ex.hold_late[1]) * len(ex.hold_late[2])
+    monkeypatch.setattr(qe, "HOLD_LATE_MIN_MULTS", 1.0)
+    monkeypatch.delenv("QAMD_HOLD_LATE")
+    assert qa.TreeExecutor(ex.tree, "float32").hold_late is not None
+
+
 def test_pool_reuse_stays_on_the_lane(recdev):
     """A block goes back to the lane that used it last and is handed out again only there; buffers that cross lanes are
     never released."""
