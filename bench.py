@@ -32,6 +32,8 @@ import numpy as np
 # four corner sweeps + the caller's stream want five hardware queues (HIP's default is four: a fifth stream would share
 # one and serialise behind it); must be set before the HIP runtime initialises
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# the host driver of this pool only supports dmabuf IPC: without this RCCL (N > 1) fails in hipIpcGetMemHandle
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
