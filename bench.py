@@ -321,7 +321,7 @@ def main():
         xs = sharding.shard(xs, r_)
         if args.graph:
             qrank.capture(xs)
-        elif args.launch == "program" or (args.launch == "auto" and world > 1):
+        elif args.launch == "program" or (args.launch == "auto" and (world > 1 or emulate)):      # (the emulation runs what a rank runs)
             qrank.program(xs, mark_min_mults=10**9)
         tree, tree_name = quad_tree, "four quadrants + two joins"
     elif args.tree == "auto":
