@@ -135,6 +135,9 @@ def array_contract_path(*args, **kwargs):
     return array_contract_tree(*args, **kwargs).get_path()
 
 
+_PROGRAM_POOL = [0]          # bytes of device memory held by the launch programs of live expressions
+
+
 class ContractExpression:
     """Callable ``expr(*arrays, backend=None)`` bound to one tree + dtype."""
 
@@ -143,6 +146,7 @@ class ContractExpression:
         self.constants = dict(constants or {})
         self._const_dev = {k: asarray(v).astype(dtype) for k, v in self.constants.items()}
         self._ninputs = len(tree.inputs)
+        self._program, self._ncalls = None, 0      # launch program of repeated calls (``_auto_program``)
         self._order = None          # position in the caller's input list -> position in the executed tree's
         if self._const_dev and not strip_exponent and tree.nslices == 1 and os.environ.get("QAMD_FOLD_CONSTANTS", "1") != "0":
             tree = self._fold_constants(tree, dtype)
@@ -224,6 +228,49 @@ class ContractExpression:
             return [self._const_dev[i] if i in self._const_dev else next(it) for i in range(n)], where
         return arrays, list(range(len(arrays)))
 
+    # ---- launch programs for repeated calls ---------------------------------------------------------------------------
+    def _auto_program(self, arrays):
+        """The reference re-runs cotengra's per-step Python loop on every call of a cached expression
+        (quimb/tensor/contraction.py:285; the cache: tests/test_tensor/test_contract.py:155-172); here that loop costs
+        ~15 us of host time per launch.  From the THIRD call with device-resident arrays on, an unsliced expression is
+        recorded once as a launch program (quimb_amd/program.py) and every later call is one C call that replays it on the
+        caller's arrays, read in place.  Returns the program or None (not eligible / recording refused: then never again).
+        ``QAMD_AUTO_PROGRAM=0`` opts out; ``QAMD_AUTO_PROGRAM_MAX_BYTES`` (default 4 GiB) bounds the intermediates one
+        program may keep allocated, ``QAMD_AUTO_PROGRAM_TOTAL_BYTES`` (16 GiB) those of all live expressions together."""
+        prog = self._program
+        if prog is not None or prog is False:
+            return prog or None
+        self._ncalls += 1
+        if self._ncalls < 3:
+            return None
+        self._program = False
+        ex = self.executor
+        if (os.environ.get("QAMD_AUTO_PROGRAM", "1") == "0" or self.tree.nslices != 1 or len(ex.plan) < 4
+                or not all(isinstance(a, Array) for a in arrays)):
+            return None
+        dev = arrays[0]._dev
+        if not hasattr(dev, "lib") or not hasattr(dev, "torch") or getattr(dev, "record", None) is not None \
+                or dev.torch.cuda.is_current_stream_capturing():
+            self._program = None if getattr(dev, "record", None) is not None else False      # (busy: try again later)
+            return None
+        limit = int(os.environ.get("QAMD_AUTO_PROGRAM_MAX_BYTES", str(4 << 30)))
+        budget = int(os.environ.get("QAMD_AUTO_PROGRAM_TOTAL_BYTES", str(16 << 30)))
+        if sum(inf.bytes for inf in ex.info) > min(limit, budget - _PROGRAM_POOL[0]):
+            return None                    # (a program keeps its intermediates allocated: all programs together stay bounded)
+        try:
+            prog = ex.program(list(arrays), strip_exponent=self.strip_exponent)
+            prog.forget_inputs()
+        except Exception:
+            return None
+        self._program = prog
+        _PROGRAM_POOL[0] += prog.pool_bytes
+        return prog
+
+    def __del__(self):
+        prog = getattr(self, "_program", None)
+        if prog:
+            _PROGRAM_POOL[0] -= prog.pool_bytes
+
     def __call__(self, *arrays, backend=None, slices=None):
         _check_backend(backend)
         if self._const_dev:
@@ -232,6 +279,13 @@ class ContractExpression:
         if self._micro is not None and slices is None:
             out = self._micro(arrays)
             return out.to_numpy() if host_in else out
+        if slices is None and not host_in:
+            prog = self._auto_program(arrays)
+            if prog is not None:
+                out = prog(list(arrays))              # the program's own buffers: handed out as copies
+                if self.strip_exponent:
+                    return out[0].copy(), out[1]
+                return out.copy()
         out = self.executor(arrays, strip_exponent=self.strip_exponent, slices=slices)
         if self.strip_exponent:
             out, e = out

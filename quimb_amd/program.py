@@ -162,6 +162,12 @@ class ContractionProgram:
                 pass
             self._dev.lib.qamd_program_destroy(prog)
 
+    def forget_inputs(self):
+        """Drop the references to the arrays recorded on (a program that is always called WITH arrays need not keep the
+        first call's alive); ``program()`` without arrays is not possible afterwards."""
+        self.inputs = [None] * len(self.inputs)
+        self._ptrs0 = None
+
     @property
     def pool_bytes(self):
         return self._pool.bytes_total
@@ -175,6 +181,8 @@ class ContractionProgram:
         if timing_slot is None:
             timing_slot = getattr(self, "_timing_slot", None)
         if arrays is None:
+            if self._ptrs0 is None:
+                raise ValueError("this program has forgotten the arrays it was recorded on: pass arrays")
             ptrs = self._ptrs0
         elif self._keep is not None and len(arrays) == len(self._keep_src) and all(a is b for a, b in zip(arrays, self._keep_src)):
             ptrs = self._keep_ptrs                            # the same array objects as last time: nothing to check again

@@ -601,6 +601,47 @@ def check_gemmd(seed=31, tiles=(None,)):
     assert np.max(np.abs(m.to_numpy())) == pytest.approx(1.0, rel=1e-12)
 
 
+def check_auto_program(dtype="float32"):
+    """A cached expression called repeatedly with device arrays switches to a launch program at its third call (the
+    reference re-runs cotengra's Python loop every time, quimb/tensor/contraction.py:285): same values bit for bit as the
+    launch-by-launch executor, results that do not alias each other, with and without strip_exponent, other inputs of
+    the same shapes read in place; ``QAMD_AUTO_PROGRAM=0`` keeps the loop."""
+    import os
+
+    from quimb_amd.program import ContractionProgram
+
+    rng = np.random.default_rng(3)
+    arrays, inputs, output = rand_reg_network(10, 3, 4, rng, dtype, n_out=2)
+    shapes = [a.shape for a in arrays]
+    for strip in (False, True):
+        expr = qa.array_contract_expression(inputs, output, shapes=shapes, optimize="greedy", dtype=dtype,
+                                            strip_exponent=strip, cache=False)
+        outs = []
+        for call in range(6):
+            xs = [qa.asarray(rand(rng, sh, dtype)) for sh in shapes]
+            got = expr(*xs)
+            ref = expr.executor(xs, strip_exponent=strip)
+            if strip:
+                assert np.array_equal(got[0].to_numpy(), ref[0].to_numpy()) and got[1] == ref[1], (dtype, strip, call)
+                got = got[0]
+            else:
+                assert np.array_equal(got.to_numpy(), ref.to_numpy()), (dtype, call)
+            outs.append((got, got.to_numpy().copy()))
+            want = ContractionProgram if (call >= 2 and hasattr(xs[0]._dev, "lib")) else (type(None), bool)
+            assert isinstance(expr._program, want), (call, expr._program)
+        for got, snap in outs:                       # earlier results were not overwritten by later replays
+            assert np.array_equal(got.to_numpy(), snap)
+    os.environ["QAMD_AUTO_PROGRAM"] = "0"
+    try:
+        expr = qa.array_contract_expression(inputs, output, shapes=shapes, optimize="greedy", dtype=dtype, cache=False)
+        xs = [qa.asarray(a) for a in arrays]
+        for _ in range(4):
+            expr(*xs)
+        assert not expr._program
+    finally:
+        del os.environ["QAMD_AUTO_PROGRAM"]
+
+
 def check_join_dot(cases=((1024, 1024, 64), (1100, 1180, 96), (2048, 1536, 200)), expect_fused=True):
     """A join whose result meets a tensor of the same layout in one inner product (the closing steps of a two-sided /
     four-quadrant contraction): Z = sum_{l,r} (TL^T TR)[l, r] (BL^T BR)[l, r].  The executor hands the second join and

@@ -323,6 +323,11 @@ def test_krylov_step(hip, dtype):
     checks.check_krylov_step(dtype)
 
 
+@pytest.mark.parametrize("dtype", ["float32", "float64", "complex64"])
+def test_expression_switches_to_a_launch_program(hip, dtype):
+    checks.check_auto_program(dtype)
+
+
 def test_join_dot(hip):
     """the second join + closing inner product as one launch: fused, unfused and fp64 numpy agree.  The first two cases are
     joins the planner keeps off the k-outer kernel (the device declines, the two steps run); the others take its DOT

@@ -77,6 +77,10 @@ def test_krylov_step_on_the_interpreter(emu, dtype):
     checks.check_krylov_step(dtype)
 
 
+def test_repeated_expression_calls_on_the_interpreter(emu):
+    checks.check_auto_program("float64")           # (no recorder on the interpreter: the loop stays, values agree)
+
+
 def test_join_dot_on_the_interpreter(emu):
     checks.check_join_dot(cases=((1024, 1024, 64), (1100, 1180, 96)))
     assert emu.calls.get("pair_dot", 0) == 6            # plain + strip_exponent + the input-T tree, per case
