@@ -281,6 +281,8 @@ class ContractExpression:
             return out.to_numpy() if host_in else out
         if slices is None and not host_in:
             prog = self._auto_program(arrays)
+            if prog is not None and prog._dev.torch.cuda.is_current_stream_capturing():
+                prog = None                       # inside someone's hipGraph capture: the plain loop captures cleanly
             if prog is not None:
                 out = prog(list(arrays))              # the program's own buffers: handed out as copies
                 if self.strip_exponent:
