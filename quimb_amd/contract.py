@@ -250,7 +250,7 @@ class ContractExpression:
             return None
         dev = arrays[0]._dev
         if not hasattr(dev, "lib") or not hasattr(dev, "torch") or getattr(dev, "record", None) is not None \
-                or dev.torch.cuda.is_current_stream_capturing():
+                or dev.is_capturing():
             self._program = None if getattr(dev, "record", None) is not None else False      # (busy: try again later)
             return None
         limit = int(os.environ.get("QAMD_AUTO_PROGRAM_MAX_BYTES", str(4 << 30)))
@@ -281,7 +281,7 @@ class ContractExpression:
             return out.to_numpy() if host_in else out
         if slices is None and not host_in:
             prog = self._auto_program(arrays)
-            if prog is not None and prog._dev.torch.cuda.is_current_stream_capturing():
+            if prog is not None and prog._dev.is_capturing():
                 prog = None                       # inside someone's hipGraph capture: the plain loop captures cleanly
             if prog is not None:
                 out = prog(list(arrays))              # the program's own buffers: handed out as copies

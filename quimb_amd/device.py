@@ -576,6 +576,13 @@ class HipDevice:
     def buffer_address(self, buf):
         return buf.data_ptr()
 
+    def is_capturing(self):
+        """Is the current stream inside a hipGraph capture?"""
+        try:
+            return bool(self.torch.cuda.is_current_stream_capturing())
+        except Exception:
+            return False
+
     def shares_storage(self, a, b):
         """Do two buffers (views included) live in the same allocation?"""
         return a.untyped_storage().data_ptr() == b.untyped_storage().data_ptr()

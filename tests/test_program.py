@@ -112,6 +112,43 @@ def test_later_chains_are_held_behind_the_first_joins_chains(recdev, monkeypatch
     assert qa.TreeExecutor(ex.tree, "float32").hold_late is not None
 
 
+def test_expressions_record_their_own_program(recdev, monkeypatch):
+    """``ContractExpression._auto_program``: nothing before the third call, then one recording; the pool bytes of live
+    programs are accounted and given back; budgets and the opt-out are honoured.  (Replay is a ``-m gpu`` test.)"""
+    import gc
+
+    import quimb_amd.contract as qc
+    from quimb_amd.program import ContractionProgram
+
+    arrays, inputs, size = _network(4, 3, "float32")
+    shapes = [a.shape for a in arrays]
+    xs = [qa.asarray(a) for a in arrays]
+    mk = lambda: qa.array_contract_expression(inputs, (), shapes=shapes, optimize="greedy", dtype="float32", cache=False)
+    base = qc._PROGRAM_POOL[0]
+    expr = mk()
+    assert expr._auto_program(xs) is None and expr._auto_program(xs) is None and expr._program is None
+    prog = expr._auto_program(xs)
+    assert isinstance(prog, ContractionProgram) and expr._auto_program(xs) is prog
+    assert prog.inputs == [None] * len(xs)                        # the recorded-on arrays are not kept alive
+    with pytest.raises(ValueError):
+        prog()
+    assert qc._PROGRAM_POOL[0] == base + prog.pool_bytes > base
+    del expr, prog
+    gc.collect()
+    assert qc._PROGRAM_POOL[0] == base
+    for env, val in (("QAMD_AUTO_PROGRAM", "0"), ("QAMD_AUTO_PROGRAM_MAX_BYTES", "1000"), ("QAMD_AUTO_PROGRAM_TOTAL_BYTES", "1000")):
+        monkeypatch.setenv(env, val)
+        expr = mk()
+        assert [expr._auto_program(xs) for _ in range(4)] == [None] * 4 and expr._program is False
+        monkeypatch.delenv(env)
+    # host arrays never start one; a tree of fewer than four launches is not worth one
+    expr = mk()
+    assert [expr._auto_program(arrays) for _ in range(4)] == [None] * 4
+    small = qa.array_contract_expression([("a", "b"), ("b", "c")], ("a", "c"), shapes=[(8, 8), (8, 8)], dtype="float32", cache=False)
+    two = [qa.asarray(np.ones((8, 8), np.float32))] * 2
+    assert [small._auto_program(two) for _ in range(4)] == [None] * 4
+
+
 def test_pool_reuse_stays_on_the_lane(recdev):
     """A block goes back to the lane that used it last and is handed out again only there; buffers that cross lanes are
     never released."""
