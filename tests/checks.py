@@ -1137,6 +1137,15 @@ def check_lanczos(dtype, chi=6):
         assert np.linalg.norm(M.astype(np.float64) @ v - w[0] * v) <= 2e3 * tol * max(1.0, abs(want))
     w2 = qa.eigh_lanczos(qa.asarray(M), k=2, which="SA", ncv=40, tol=tol, return_vecs=False)
     assert np.allclose(w2, ref[:2], atol=1e3 * tol * max(1.0, abs(ref[0])))
+    # a basis of more than 64 rows (the update kernel takes 64 coefficients per launch) and a whole cycle without a
+    # residual test (miniter = ncv: alpha / beta are read from the device table once)
+    w3 = qa.eigh_lanczos(qa.asarray(M), k=1, which="SA", ncv=80, tol=tol, miniter=80, return_vecs=False)
+    assert abs(w3[0] - ref[0]) <= 50 * tol * max(1.0, abs(ref[0]))
+    # breakdown inside the deferred part of a cycle: a rank-3 operator exhausts its Krylov space after three steps
+    U = np.linalg.qr(rng.normal(size=(n, 3)))[0]
+    low = ((U * np.array([5.0, -2.0, 1.0])) @ U.T).astype(dtype)
+    w4 = qa.eigh_lanczos(qa.asarray(low), k=1, which="LA", ncv=12, tol=tol, miniter=12, return_vecs=False)
+    assert abs(w4[0] - 5.0) <= 200 * tol * 5.0
     # symmetric 2-site effective Hamiltonian as a TNLinearOperator
     tensors, left, right = dmrg_effective_ham(chi, dtype=dtype)
     (L, li), (W1, w1i), (W2, w2i), (R, ri) = tensors
