@@ -611,9 +611,27 @@ def check_auto_program(dtype="float32"):
     from quimb_amd.program import ContractionProgram
 
     rng = np.random.default_rng(3)
+    for (nn_, dd_, no_, strips) in ((10, 4, 2, (False, True)), (14, 2, 0, (False,)), (8, 3, 3, (True,))):
+        arrays, inputs, output = rand_reg_network(nn_, 3, dd_, rng, dtype, n_out=no_)
+        _check_auto_program_on(arrays, inputs, output, dtype, strips, rng)
     arrays, inputs, output = rand_reg_network(10, 3, 4, rng, dtype, n_out=2)
     shapes = [a.shape for a in arrays]
-    for strip in (False, True):
+    os.environ["QAMD_AUTO_PROGRAM"] = "0"
+    try:
+        expr = qa.array_contract_expression(inputs, output, shapes=shapes, optimize="greedy", dtype=dtype, cache=False)
+        xs = [qa.asarray(a) for a in arrays]
+        for _ in range(4):
+            expr(*xs)
+        assert not expr._program
+    finally:
+        del os.environ["QAMD_AUTO_PROGRAM"]
+
+
+def _check_auto_program_on(arrays, inputs, output, dtype, strips, rng):
+    from quimb_amd.program import ContractionProgram
+
+    shapes = [a.shape for a in arrays]
+    for strip in strips:
         expr = qa.array_contract_expression(inputs, output, shapes=shapes, optimize="greedy", dtype=dtype,
                                             strip_exponent=strip, cache=False)
         outs = []
@@ -631,15 +649,6 @@ def check_auto_program(dtype="float32"):
             assert isinstance(expr._program, want), (call, expr._program)
         for got, snap in outs:                       # earlier results were not overwritten by later replays
             assert np.array_equal(got.to_numpy(), snap)
-    os.environ["QAMD_AUTO_PROGRAM"] = "0"
-    try:
-        expr = qa.array_contract_expression(inputs, output, shapes=shapes, optimize="greedy", dtype=dtype, cache=False)
-        xs = [qa.asarray(a) for a in arrays]
-        for _ in range(4):
-            expr(*xs)
-        assert not expr._program
-    finally:
-        del os.environ["QAMD_AUTO_PROGRAM"]
 
 
 def check_join_dot(cases=((1024, 1024, 64), (1100, 1180, 96), (2048, 1536, 200)), expect_fused=True):
