@@ -1072,7 +1072,9 @@ static bool chain2_uses_registers(const qamd_chain2_plan* p, const void* C) {
 }
 
 // the 4x4x1 multi-block variant (chain2q.hip): fp32, D in {4, 6}, innermost m group a whole number of 64-m chunks,
-// and enough chunks to give every wave of the persistent grid a few (QAMD_CHAIN2Q=0 off, =2 no size threshold)
+// and at least one chunk for every wave of the persistent grid (QAMD_CHAIN2Q=0 off, =2 no size threshold).  The bar was
+// four chunks per wave until round 4: the range-sliced last rows of a rank of 4 / 8 (M = 139968 / 69984: 2187 / 1093
+// chunks) sat on chain2r below it, and chain2q runs them faster (a rank's step 5.27 -> 5.04 ms / 3.46 -> 3.35 ms)
 static bool chain2_uses_quad(const qamd_chain2_plan* p, const void* C) {
   const char* e = getenv("QAMD_CHAIN2Q");
   if (e && e[0] == '0') return false;
@@ -1080,7 +1082,7 @@ static bool chain2_uses_quad(const qamd_chain2_plan* p, const void* C) {
   if (p->nm < 1 || p->dim_m[p->nm - 1] % 64) return false;
   int64_t M = 1;
   for (int i = 0; i < p->nm; ++i) M *= p->dim_m[i];
-  return (e && e[0] == '2') || M / 64 >= 4096;
+  return (e && e[0] == '2') || M / 64 >= 1024;
 }
 
 // the two-waves-per-SIMD variant of it (chain2h.hip: 32-m chunks, v pairs / x pairs in the lane halves): opt-in
