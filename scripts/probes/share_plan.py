@@ -36,6 +36,24 @@ def describe(spec):
     return buf.value.decode()
 
 
+def describe_chain2(c2):
+    """the fused-pair kernel the library would launch (16-byte aligned result assumed)"""
+    pl = _lib.Chain2PlanStruct()
+    pl.dtype, pl.D, pl.nm = 0, c2.D, len(c2.m)
+    for i, (d, sa, sc) in enumerate(c2.m):
+        pl.dim_m[i], pl.sa_m[i], pl.sc_m[i] = d, sa, sc
+    pl.sa_v = c2.sa_v
+    if all(o % 4 == 0 for o in c2.off_co) and all(sc % 4 == 0 for (_, _, sc) in c2.m[:-1]):
+        pl.flags = 1
+    if c2.k1_single:
+        pl.flags |= 2
+    if c2.no_n2out:
+        pl.flags |= 4
+    buf = C.create_string_buffer(128)
+    lib.qamd_chain2_describe(C.byref(pl), buf, 128)
+    return buf.value.decode()
+
+
 tot = {}
 for i, (e, info) in enumerate(zip(ex.plan, ex.info)):
     lane = ex.lanes[i] if hasattr(ex, "lanes") else 0
@@ -47,7 +65,7 @@ for i, (e, info) in enumerate(zip(ex.plan, ex.info)):
         pre = "pre" if st.kind == "gett" and any(st.pre) else ""
     elif e[0] == "chain2":
         c2 = e[5]
-        name, dims, pre = f"chain2 {getattr(c2, 'kernel', '')} D={c2.D} M={c2.M}", (info.B, info.M, info.N, info.K), ""
+        name, dims, pre = f"{describe_chain2(c2)} M={c2.M}", (info.B, info.M, info.N, info.K), ""
     else:
         name, dims, pre = e[0], (info.B, info.M, info.N, info.K), ""
     us = info.bytes / 4.5e6
