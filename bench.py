@@ -225,6 +225,68 @@ def _time_steps(fn, n, sync):
     return (time.perf_counter() - t0) / n, r
 
 
+def _free_port():
+    import socket
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _self_launch(ngpus):
+    """``python bench.py --gpus N`` with N > 1 and no launcher environment (WORLD_SIZE unset): start the N ranks
+    ourselves -- the same command line under ``python -m torch.distributed.run``, one rank per GPU, rendezvous on
+    127.0.0.1 -- and pass the ranks' output through (rank 0 prints the one JSON line).  A launcher that already set
+    RANK / WORLD_SIZE (the driver's torchrun) never gets here.  Refuses, loudly, when the box has fewer GPUs than ranks:
+    RCCL does not share a device between ranks, and a silent N = 1 run would be recorded as an N-GPU number."""
+    import subprocess
+
+    dry = os.environ.get("QAMD_BENCH_DRYRUN") == "1"
+    if not dry and os.environ.get("QAMD_BENCH_BACKEND", "nccl") == "nccl":
+        import torch
+
+        have = torch.cuda.device_count()
+        if have < ngpus:
+            print(f"bench.py: --gpus {ngpus} needs {ngpus} visible GPUs, this box has {have} (RCCL does not share a device "
+                  f"between ranks; QAMD_BENCH_BACKEND=gloo lets ranks share one GPU as a debugging aid)", file=sys.stderr)
+            return 2
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={ngpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("OMP_NUM_THREADS", "8")      # (torchrun would set 1 and say so on stderr)
+    return subprocess.run(cmd, env=env).returncode
+
+
+def _dry_run_setup():
+    """``QAMD_BENCH_DRYRUN=1``: the script's control flow without a GPU -- the numpy plan interpreter of the test suite
+    (tests/emu_device.py) stands in for the device, the few ``torch.cuda`` calls made here are stubbed, ranks talk over
+    gloo.  Timings mean nothing; the printed line says ``"dry_run": true`` and can not be mistaken for a measurement.
+    Used by tests/test_bench_contract.py to run ``python bench.py --gpus 2`` exactly as a driver without a launcher
+    would."""
+    import contextlib
+
+    import torch
+
+    class _Stream:
+        def wait_stream(self, other):
+            pass
+
+    torch.cuda.set_device = lambda *a, **k: None
+    torch.cuda.synchronize = lambda *a, **k: None
+    torch.cuda.device_count = lambda: 1
+    torch.cuda.Stream = lambda *a, **k: _Stream()
+    torch.cuda.current_stream = lambda *a, **k: _Stream()
+    torch.cuda.stream = lambda s: contextlib.nullcontext()
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import quimb_amd.device as qd
+    from emu_device import EmuDevice
+
+    dev = EmuDevice()
+    dev.tdev, dev.profile, dev.profile_min_mults = "cpu", None, 0
+    qd.set_default_device(dev)
+    os.environ["QAMD_BENCH_BACKEND"] = "gloo"
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -254,6 +316,12 @@ def main():
     ap.add_argument("--emulate-world", type=int, default=0,
                     help="one GPU times ONE rank's share (the busiest) of a job over this many ranks -- no collective")
     args = ap.parse_args()
+
+    dry_run = os.environ.get("QAMD_BENCH_DRYRUN") == "1"
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not args.emulate_world:
+        sys.exit(_self_launch(args.gpus))
+    if dry_run:
+        _dry_run_setup()
 
     import torch
     import torch.distributed as dist
@@ -633,7 +701,7 @@ def main():
             "scaling": "strong",
             "vs_baseline": None,
             "dtype": "f32",
-            "data": "synthetic",
+            "data": "synthetic" if not dry_run else "synthetic (DRY RUN on the numpy plan interpreter: no GPU, timings void)",
             "config": {
                 "workload": f"{args.Lx}x{args.Ly} D={args.D} PEPS amplitude (single-layer TN), exact, " + workload,
                 "tree": tree_name,
@@ -660,6 +728,8 @@ def main():
             "roofline": roof,
             "cpu_baseline": cpu,
         }
+        if dry_run:
+            out["dry_run"] = True
         if secondary is not None:
             out["secondary"] = secondary
         if projection is not None:

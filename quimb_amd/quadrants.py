@@ -216,7 +216,8 @@ def contract_quadrants(rank_plan, local_arrays, strip_exponent=False, group=None
     import torch.distributed as dist
 
     m, e = rank_plan(local_arrays, defer=True)
-    world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+    grouped = dist.is_available() and dist.is_initialized()
+    world = dist.get_world_size(group) if grouped else 1
     dev = m._dev
     buf = m._buf
     if isinstance(buf, torch.Tensor) and isinstance(e, torch.Tensor):
@@ -233,7 +234,7 @@ def contract_quadrants(rank_plan, local_arrays, strip_exponent=False, group=None
         ev = dev.read_exponent(e) if hasattr(e, "cpu") or not isinstance(e, float) else e
         m0 = complex(np.asarray(m.to_numpy()).reshape(-1)[0])
         mine = torch.tensor([m0.real, m0.imag, ev], dtype=torch.float64)
-    if world > 1:
+    if grouped:     # (a group of ONE rank gathers too: the same RCCL call a one-GPU box can execute, tests/test_gpu_parity.py)
         gathered = [torch.empty_like(mine) for _ in range(world)]
         dist.all_gather(gathered, mine, group=group)          # THE collective of the job
         trip = torch.stack(gathered).cpu().numpy()

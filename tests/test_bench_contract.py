@@ -149,6 +149,48 @@ def test_bench_multi_rank_line(tmp_path, world):
     assert d["result"]["mantissa"] * 10.0 ** d["result"]["exponent_log10"] == pytest.approx(want, rel=1e-4)
 
 
+def test_bench_launches_its_own_ranks():
+    """``python bench.py --gpus 2`` with NO launcher environment (a driver that runs exactly that
+    got an N = 1 line): the script re-executes itself under ``torch.distributed.run`` with two ranks, rank 0 prints the one
+    line and it says ``n_gpus: 2``.  Dry run: plan interpreter + gloo (``QAMD_BENCH_DRYRUN=1``), which the line records."""
+    import subprocess
+
+    from oracle import np_oracle as orc
+
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "QAMD_BENCH_BACKEND")}
+    env["QAMD_BENCH_DRYRUN"] = "1"
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--Lx", "4", "--Ly", "4", "--D", "4",
+           "--steps", "2", "--warmup", "1"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert CONTRACT_KEYS <= set(d) and d["n_gpus"] == 2 and d["dry_run"] is True and "DRY RUN" in d["data"]
+    assert d["config"]["parallelism"] == "blocks2x1" and d["scaling"] == "strong"
+    assert len(d["strong_scaling_report"]["per_rank_ms_without_collective"]) == 2
+    arrays, inputs = orc.tn2d_rand(4, 4, 4, seed=7, dtype="float64")
+    want = orc.oracle_array_contract(arrays, inputs, ()).item()
+    assert d["result"]["mantissa"] * 10.0 ** d["result"]["exponent_log10"] == pytest.approx(want, rel=1e-4)
+
+
+def test_bench_refuses_more_ranks_than_gpus():
+    """... and WITHOUT the dry-run switch the self-launcher refuses to start more RCCL ranks than the box has GPUs
+    (here: none) instead of recording an N = 1 run as an N-GPU number."""
+    import subprocess
+
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "QAMD_BENCH_BACKEND", "QAMD_BENCH_DRYRUN")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=300, cwd=ROOT)
+    import torch
+
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("this box could run it")
+    assert r.returncode == 2 and "needs 2 visible GPUs" in r.stderr and not r.stdout.strip()
+
+
 def test_roofline_classes_table():
     """``roofline.classes`` (achieved per step class): launches grouped by kernel instantiation, tiny launches
     lumped as latency-bound, each class priced against min(MFMA peak, AI x HBM peak)."""

@@ -236,9 +236,10 @@ def test_quadrant_sharding_costs():
 
 
 # ---------------------------------------------------------------------------------------------------------
-# RCCL itself: opt-in (QAMD_TEST_NCCL=1) on a box with >= 2 GPUs, so that the first multi-GPU bench run is not the
-# first execution of the nccl branches (the one-GPU box of the test tiers cannot run it: RCCL refuses two ranks on
-# one device)
+# RCCL itself.  Two ranks: runs by default wherever >= 2 GPUs are visible (RCCL refuses two ranks on one device, so the
+# one-GPU boxes of the test tier skip it).  ONE rank: runs on every GPU box -- RCCL initialises, and the job's closing
+# all-gather (quadrants.contract_quadrants) plus an all-reduce execute on device buffers in a group of one, so the first
+# multi-GPU bench run is not the first time this process environment (HSA_ENABLE_IPC_MODE_LEGACY=0) meets the library.
 # ---------------------------------------------------------------------------------------------------------
 def _worker_nccl(rank, world, port, outdir):
     sys.path.insert(0, ROOT)
@@ -272,8 +273,8 @@ def _worker_nccl(rank, world, port, outdir):
 def test_nccl_two_ranks_smoke(tmp_path):
     import torch
 
-    if os.environ.get("QAMD_TEST_NCCL") != "1" or torch.cuda.device_count() < 2:
-        pytest.skip("set QAMD_TEST_NCCL=1 on a box with >= 2 GPUs")
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs >= 2 GPUs (RCCL does not share a device between ranks); the one-rank RCCL test covers this box")
     import torch.multiprocessing as mp
 
     from oracle import np_oracle as orc
@@ -285,6 +286,52 @@ def test_nccl_two_ranks_smoke(tmp_path):
     for r in range(2):
         got = np.load(tmp_path / f"r{r}.npy")
         assert got[0] == pytest.approx(want, rel=2e-6) and got[1] == pytest.approx(want, rel=2e-6)
+
+
+def _worker_nccl_one(rank, world, port, outdir):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import torch
+    import torch.distributed as dist
+
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        import quimb_amd as qa
+        from oracle import np_oracle as orc
+        from quimb_amd.quadrants import QuadrantRank, QuadrantSharding, contract_quadrants
+
+        assert dist.get_backend() == "nccl"
+        arrays, inputs = orc.tn2d_rand(6, 6, 6, seed=4, dtype="float32")
+        size = {ix: 6 for t in inputs for ix in t}
+        sh = QuadrantSharding(inputs, size, 6, 6, 1)
+        plan = QuadrantRank(sh, 0, "float32")
+        local = sh.shard([qa.asarray(a) for a in arrays], 0)
+        m, e = contract_quadrants(plan, local, strip_exponent=True)      # ends in dist.all_gather on device doubles
+        t = torch.arange(4, dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        mx = torch.tensor([3.5], dtype=torch.float64, device="cuda")
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        dist.barrier()
+        np.save(os.path.join(outdir, "r0.npy"), np.asarray([m * 10.0**e, float(t.sum().cpu()), float(mx.cpu()[0])]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_nccl_one_rank_collectives(tmp_path):
+    """RCCL on the one-GPU box: process group of one rank, the job's closing all-gather on device buffers."""
+    import torch.multiprocessing as mp
+
+    from oracle import np_oracle as orc
+
+    mp.spawn(_worker_nccl_one, args=(1, _free_port(), str(tmp_path)), nprocs=1, join=True)
+    arrays, inputs = orc.tn2d_rand(6, 6, 6, seed=4, dtype="float64")
+    want = np.asarray(orc.oracle_array_contract(arrays, inputs, (), path=None)).item()
+    got = np.load(tmp_path / "r0.npy")
+    assert got[0] == pytest.approx(want, rel=2e-6) and got[1] == 6.0 and got[2] == 3.5
 
 
 def _worker_sliced_complex(rank, world, port, outdir):
