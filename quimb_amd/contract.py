@@ -260,7 +260,12 @@ class ContractExpression:
         try:
             prog = ex.program(list(arrays), strip_exponent=self.strip_exponent)
             prog.forget_inputs()
-        except Exception:
+        except Exception as err:
+            if os.environ.get("QAMD_DEBUG"):
+                import sys
+
+                print(f"[quimb_amd] launch program refused for an expression of {len(ex.plan)} launches: "
+                      f"{type(err).__name__}: {err}", file=sys.stderr)
             return None
         self._program = prog
         _PROGRAM_POOL[0] += prog.pool_bytes
@@ -281,8 +286,10 @@ class ContractExpression:
             return out.to_numpy() if host_in else out
         if slices is None and not host_in:
             prog = self._auto_program(arrays)
-            if prog is not None and prog._dev.is_capturing():
-                prog = None                       # inside someone's hipGraph capture: the plain loop captures cleanly
+            if prog is not None and (prog._dev.is_capturing() or prog._dev.profile is not None):
+                # inside someone's hipGraph capture the plain loop captures cleanly; with per-kernel profiling on
+                # (``dev.profile``) the launch-by-launch path is the one that fills the profile list
+                prog = None
             if prog is not None:
                 out = prog(list(arrays))              # the program's own buffers: handed out as copies
                 if self.strip_exponent:

@@ -229,6 +229,14 @@ extern "C" int qamd_program_record_end(qamd_program* P) {
 
 extern "C" int qamd_program_bind_inputs(qamd_program* P, int32_t n, const void* const* ptrs, const int64_t* nbytes) {
   if (!P || P->recording || n < 0 || (n && (!ptrs || !nbytes))) return QAMD_EINVAL;
+  // the ranges must be disjoint: a recorded pointer is re-based onto THE input that contained it, and with overlapping
+  // inputs (the same array passed twice, overlapping views) that is ambiguous -- a replay on distinct arrays would read
+  // the wrong one.  The caller records on private copies instead (quimb_amd/program.py).
+  for (int i = 0; i < n; ++i)
+    for (int j = i + 1; j < n; ++j) {
+      const char *a = (const char*)ptrs[i], *b = (const char*)ptrs[j];
+      if (a && b && nbytes[i] > 0 && nbytes[j] > 0 && a < b + nbytes[j] && b < a + nbytes[i]) return QAMD_EINVAL;
+    }
   for (Op& o : P->ops)
     for (int i = 0; i < o.nptr; ++i) {
       o.in_idx[i] = -1;

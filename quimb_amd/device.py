@@ -10,6 +10,8 @@ default device without the HIP library or without a GPU raises.
 import ctypes as C
 import os
 
+import threading
+
 import numpy as np
 
 from . import _lib
@@ -63,6 +65,21 @@ class HipDevice:
 
     name = "hip"
 
+    @property
+    def record(self):
+        """The launch-program recorder of THIS thread (or None).  The C recorder is thread-local (csrc/program.cpp: ``g_rec``),
+        so the Python side must be too: while one thread records, the launches and allocations of every other thread
+        using this device go to the GPU and the caching allocator as usual -- not into the recorder's pool."""
+        tls = self.__dict__.get("_rec_tls")
+        return getattr(tls, "rec", None) if tls is not None else None
+
+    @record.setter
+    def record(self, rec):
+        tls = self.__dict__.get("_rec_tls")
+        if tls is None:                      # (a subclass that skips __init__: the record-only device of the CPU tests)
+            tls = self.__dict__["_rec_tls"] = threading.local()
+        tls.rec = rec
+
     def __init__(self, index=None):
         self.lib = _lib.load()
         import torch
@@ -87,6 +104,7 @@ class HipDevice:
         self._pairs = {}
         #: the active launch-program recorder (quimb_amd/program.py) or None: while set, every allocation of this
         #: device comes from the recorder's pool and the library appends launches to its program instead of issuing them
+        self._rec_tls = threading.local()
         self.record = None
         #: set to a list to collect (spec, dtype, tile_cfg, split_k, start_event, end_event)
         #: per qamd_contract_pair launch (HIP events on the launch stream)

@@ -22,11 +22,15 @@ from .array import Array, asarray
 
 
 def _matvec(A, x):
-    if hasattr(A, "matvec_borrow"):          # the product is consumed (in place) before the next one is asked for
-        return asarray(A.matvec_borrow(x))
+    """``(A x, owned)``.  ``owned``: the solver may update the product IN PLACE.  Only ``matvec_borrow`` is that
+    contract (the operator lends a buffer that is consumed before the next product is asked for); whatever a plain
+    ``.matvec`` returns may be a buffer the operator keeps -- a stored array, a cached result, its own argument -- and
+    is copied before the first write."""
+    if hasattr(A, "matvec_borrow"):
+        return asarray(A.matvec_borrow(x)), True
     if hasattr(A, "matvec"):
-        return asarray(A.matvec(x))
-    return ops.matmul(A, x)
+        return asarray(A.matvec(x)), False
+    return ops.matmul(A, x), True            # a fresh array by construction (ops are pure)
 
 
 def eigh_lanczos(A, k=1, which="SA", v0=None, ncv=None, tol=1e-10, maxiter=None, return_vecs=True, miniter=0):
@@ -87,12 +91,14 @@ def eigh_lanczos(A, k=1, which="SA", v0=None, ncv=None, tol=1e-10, maxiter=None,
         j_done = 0
         for j in range(m):
             qj = Array(dev, Q._buf[j * n:], (n,), dtype)
-            w = _matvec(A, qj)
+            w, owned = _matvec(A, qj)
             nmv += 1
-            if w.dtype != dtype or w.size != n:
-                w = w.astype(dtype).reshape(n)
-            if dev.shares_storage(w._buf, Q._buf):
-                w = w.copy()                            # an operator that hands its argument back: w is updated in place
+            if w.dtype != dtype:
+                w, owned = w.astype(dtype), True        # (a converted copy is ours)
+            if w.size != n or w.ndim != 1:
+                w = w.reshape(n)
+            if not owned or dev.shares_storage(w._buf, Q._buf):
+                w = w.copy()                            # w is updated in place below: never in somebody else's buffer
             # full re-orthogonalisation against the basis so far: h = Q^H w ; w -= Q^T h ; Q[j+1] = w / |w|
             for ps in range(passes):
                 dev.krylov_project(h, h_sum, Q._buf, n, j + 1, w._buf, n, ps > 0, dtype, ws)

@@ -116,10 +116,24 @@ class ContractionProgram:
         if executor.tree.nslices != 1:
             raise ValueError("launch programs record unsliced trees")
         self.executor, self.strip_exponent = executor, bool(strip_exponent)
-        xs = executor.check_inputs(arrays)
+        xs = list(executor.check_inputs(arrays))
         dev = xs[0]._dev
         if not hasattr(dev, "lib") or not hasattr(dev, "torch"):
             raise RuntimeError("launch programs need the HIP device")
+        # Replay re-bases every recorded operand pointer onto "the input whose address range contained it".  That is only
+        # well defined when the ranges of the recording's inputs are DISJOINT: record ``expr(A, A)`` (or <psi|psi> with
+        # ``conj()`` returning self for real data, or overlapping views) and every read of the second input would be
+        # re-based onto the first at replay -- ``expr(A, B)`` would silently return the value for (A, A).  An input that
+        # overlaps an earlier one is therefore recorded on a private copy (replays may alias freely: inputs are only read).
+        spans = []
+        for i, x in enumerate(xs):
+            lo = x._buf.data_ptr()
+            hi = lo + max(x.size, 1) * x.dtype.itemsize
+            if any(lo < h and l < hi for l, h in spans):
+                x = xs[i] = x.copy()
+                lo = x._buf.data_ptr()
+                hi = lo + max(x.size, 1) * x.dtype.itemsize
+            spans.append((lo, hi))
         if dev.record is not None:
             raise RuntimeError("a launch program is already being recorded on this device")
         self._dev = dev
@@ -184,8 +198,9 @@ class ContractionProgram:
             if self._ptrs0 is None:
                 raise ValueError("this program has forgotten the arrays it was recorded on: pass arrays")
             ptrs = self._ptrs0
-        elif self._keep is not None and len(arrays) == len(self._keep_src) and all(a is b for a, b in zip(arrays, self._keep_src)):
-            ptrs = self._keep_ptrs                            # the same array objects as last time: nothing to check again
+        elif (self._keep_src is not None and len(arrays) == len(self._keep_src)
+              and all(a is b for a, b in zip(arrays, self._keep_src))):
+            ptrs = self._keep_ptrs                            # the same DEVICE array objects as last time: nothing to check again
         else:
             if len(arrays) != len(self.inputs):
                 raise ValueError(f"expected {len(self.inputs)} arrays, got {len(arrays)}")
@@ -201,12 +216,21 @@ class ContractionProgram:
                 xs.append(x)
             ptrs = (C.c_void_p * max(len(xs), 1))(*[x._buf.data_ptr() for x in xs])
             self._keep = xs                                  # until the next run: the launches are asynchronous
-            self._keep_src, self._keep_ptrs = list(arrays), ptrs
+            # the identity shortcut above is for device arrays only: a host (numpy) input was uploaded just now, and the
+            # same ndarray object may have been written to by the next call -- it is uploaded again every time
+            device_in = all(isinstance(a, Array) and a is x for a, x in zip(arrays, xs))
+            self._keep_src, self._keep_ptrs = (list(arrays), ptrs) if device_in else (None, None)
         # lane 0 = the caller's stream (as in launch-by-launch execution); QAMD_PROGRAM_OWN_LANE0=1: a pool stream of its
         # own, forked from / joined to the caller's (what lane priorities need)
         own0 = os.environ.get("QAMD_PROGRAM_OWN_LANE0", "0") == "1"
         streams = dev.lane_streams(self.nlanes, self._priorities, own_lane0=own0)
         caller = dev.torch.cuda.current_stream(dev.tdev)
+        # consecutive replays share the pool and the output buffer: stream order protects them on ONE caller stream; a
+        # caller that moved to another stream first waits for the previous replay's lane 0
+        last = getattr(self, "_last_caller", None)
+        if last is not None and last != caller:
+            caller.wait_stream(last)
+        self._last_caller = caller
         if own0:
             streams[0].wait_stream(caller)
         sarr = (C.c_void_p * self.nlanes)(*[s.cuda_stream for s in streams])

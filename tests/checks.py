@@ -2085,6 +2085,44 @@ def check_program_replay(L, D, dtype, strip, tree_kind="quadrant", seeds=(1, 2))
     return prog
 
 
+def check_program_aliasing(dtype, seed=5):
+    """a program recorded on ALIASED inputs -- ``expr(A, A, ...)`` -- replayed on distinct arrays must
+    read each of them.  Directly (``TreeExecutor.program``) and through the default-on route (``ContractExpression``
+    records silently on the third call of a cached expression: three calls on (A, A, A, A, A), then (A, B, C, D, E))."""
+    rng = np.random.default_rng(seed)
+    n = 24
+    inputs = [("a", "b"), ("b", "c"), ("c", "d"), ("d", "e"), ("e", "f")]
+    size = {ix: n for t in inputs for ix in t}
+    mats = [rand(rng, (n, n), dtype) / np.sqrt(n) for _ in inputs]
+    chain = lambda ms: np.linalg.multi_dot([m.astype(np.float64) for m in ms])
+    tree = qa.find_path(inputs, ("a", "f"), size, "greedy")
+    ex = qa.TreeExecutor(tree, dtype)
+    A = qa.asarray(mats[0])
+    prog = ex.program([A] * 5, strip_exponent=False)
+    assert_close(prog().to_numpy(), chain([mats[0]] * 5), dtype)
+    xs = [qa.asarray(m) for m in mats]
+    assert_close(prog(xs).to_numpy(), chain(mats), dtype)
+    assert_close(prog([xs[1], xs[1], xs[2], xs[2], xs[0]]).to_numpy(), chain([mats[1], mats[1], mats[2], mats[2], mats[0]]), dtype)
+    # overlapping views of one buffer
+    both = qa.asarray(np.stack([mats[3], mats[4]]))
+    v0 = qa.Array(both._dev, both._buf, (n, n), np.dtype(dtype))
+    v1 = qa.Array(both._dev, both._buf[n * n // 2:], (n, n), np.dtype(dtype))        # overlaps v0 half way
+    prog2 = ex.program([v0, v0, v1, v1, v0], strip_exponent=False)
+    assert_close(prog2(xs).to_numpy(), chain(mats), dtype)
+    # the expression route
+    expr = qa.array_contract_expression(inputs, ("a", "f"), shapes=[(n, n)] * 5, optimize="greedy", dtype=dtype, cache=False)
+    for _ in range(4):
+        assert_close(expr(A, A, A, A, A).to_numpy(), chain([mats[0]] * 5), dtype)
+    assert expr._program, "the expression should have recorded its program by now"
+    assert_close(expr(*xs).to_numpy(), chain(mats), dtype)
+    assert_close(expr(A, A, A, A, A).to_numpy(), chain([mats[0]] * 5), dtype)
+    # a host input is uploaded again on every call, also when the SAME ndarray object comes back modified (ADVICE, low)
+    host = [m.copy() for m in mats]
+    got1 = prog(host).to_numpy().copy()
+    host[2] *= 2.0
+    assert_close(prog(host).to_numpy(), 2.0 * got1, dtype)
+
+
 def check_program_on_general_trees(dtype, seed=11):
     """Launch programs on the GENERAL path: random regular networks with open indices (greedy trees: single-operand
     steps, outer products, permuted outputs), a hyper-index network (batched steps, elementwise products), an MPS

@@ -48,6 +48,11 @@ def test_c_recorder_counts_and_binding():
     assert (lib.qamd_program_num_ops(P), lib.qamd_program_num_launches(P), lib.qamd_program_num_marks(P)) == (4, 3, 1)
     ptrs, nb = (C.c_void_p * 1)(0x2000), (C.c_int64 * 1)(40)
     assert lib.qamd_program_bind_inputs(P, 1, ptrs, nb) == 0
+    # overlapping input ranges are refused: a recorded pointer could be re-based onto either
+    p2, n2 = (C.c_void_p * 2)(0x2000, 0x2010), (C.c_int64 * 2)(40, 40)
+    assert lib.qamd_program_bind_inputs(P, 2, p2, n2) != 0
+    p2 = (C.c_void_p * 2)(0x2000, 0x2028)
+    assert lib.qamd_program_bind_inputs(P, 2, p2, n2) == 0
     assert lib.qamd_fill(0x1000, 10, 0.0, 0.0, 0, None) != 0 or True    # (outside a recording the call launches: no GPU here)
     lib.qamd_program_destroy(P)
 
@@ -149,6 +154,24 @@ def test_expressions_record_their_own_program(recdev, monkeypatch):
     assert [small._auto_program(two) for _ in range(4)] == [None] * 4
 
 
+def test_aliased_inputs_are_recorded_on_private_copies(recdev):
+    """Recording on aliased inputs -- the same array twice (``expr(A, A)``, <psi|psi> with a real ``conj()``), overlapping
+    views -- must not bind two inputs to one address range: the later one is recorded on a private copy, so every input
+    of the program has a range of its own and a replay on DISTINCT arrays reads each of them (ADVICE round 4, high;
+    the replay itself: ``test_program_aliased_recording_replays_on_distinct_inputs`` on the GPU)."""
+    inputs = [("a", "b"), ("b", "c"), ("c", "d"), ("d", "e"), ("e", "f")]
+    size = {ix: 8 for t in inputs for ix in t}
+    ex = qa.TreeExecutor(qa.find_path(inputs, ("a", "f"), size, "greedy"), "float32")
+    A = qa.asarray(np.ones((8, 8), np.float32))
+    big = qa.asarray(np.ones((2, 8, 8), np.float32))
+    view = qa.Array(recdev, big._buf[32:], (8, 8), np.dtype("float32"))       # overlaps the next one half way
+    view2 = qa.Array(recdev, big._buf[64:], (8, 8), np.dtype("float32"))
+    prog = ex.program([A, A, A, view, view2], strip_exponent=False)
+    spans = sorted((x._buf.data_ptr(), x._buf.data_ptr() + x.size * 4) for x in prog.inputs)
+    assert all(a[1] <= b[0] for a, b in zip(spans, spans[1:])), spans
+    assert prog.inputs[0] is A and prog.inputs[1] is not A and prog.inputs[2] is not A
+
+
 def test_pool_reuse_stays_on_the_lane(recdev):
     """A block goes back to the lane that used it last and is handed out again only there; buffers that cross lanes are
     never released."""
@@ -205,6 +228,12 @@ def test_program_refuses_what_it_cannot_record(recdev):
                                               ("complex128", False, "quadrant")])
 def test_program_replay_matches_launch_by_launch(hip, dtype, strip, kind):
     checks.check_program_replay(6, 4 if np.dtype(dtype).kind == "c" else 6, dtype, strip, kind)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", ["float32", "float64"])
+def test_program_aliased_recording_replays_on_distinct_inputs(hip, dtype):
+    checks.check_program_aliasing(dtype)
 
 
 @pytest.mark.gpu
