@@ -63,6 +63,31 @@ def brickwork_amplitude_network(n, depth, seed=0, dtype="complex64"):
     return [a.astype(dtype) for a in arrays], inputs, first_bra
 
 
+def _numpy_tree_value(arrays, inputs, path, hi):
+    """The same tree walked by numpy in the wide dtype ``hi`` (pairwise einsum in path order: what quimb's numpy backend
+    computes) -- this file's own few lines, scalar output, small tensors only."""
+    ts = [(np.asarray(a, dtype=hi), tuple(t)) for a, t in zip(arrays, inputs)]
+    for pair in path:
+        sym = {}                                    # (labels local to the step: einsum knows 52 of them)
+        lab = lambda ix: sym.setdefault(ix, len(sym))
+        picked = [ts[i] for i in pair]
+        for i in sorted(pair, reverse=True):
+            ts.pop(i)
+        rest = {ix for _, t in ts for ix in t}
+        if len(picked) == 1:
+            (a, ta), = picked
+            keep = tuple(ix for ix in dict.fromkeys(ta) if ix in rest)
+            ts.append((np.einsum(a, [lab(i) for i in ta], [lab(i) for i in keep]), keep))
+            continue
+        (a, ta), (b, tb) = picked
+        keep = tuple(ix for ix in dict.fromkeys(ta + tb) if ix in rest)
+        ts.append((np.einsum(a, [lab(i) for i in ta], b, [lab(i) for i in tb], [lab(i) for i in keep]), keep))
+    out = ts[0][0]
+    for x, _ in ts[1:]:
+        out = out * x
+    return complex(np.asarray(out).reshape(-1)[0])
+
+
 def config2(qa, sync, nq=53, depth=10, batch=256):
     arrays, inputs, first_bra = brickwork_amplitude_network(nq, depth)
     tree = qa.array_contract_tree(inputs, (), shapes=[a.shape for a in arrays], optimize="greedy")
@@ -76,6 +101,10 @@ def config2(qa, sync, nq=53, depth=10, batch=256):
     # the same amplitude launch by launch (TreeExecutor): the parity cross-check of the one-launch walk
     ref = qa.TreeExecutor(tree, "complex64")(xs).to_numpy().item()
     got = amp.to_numpy().item()
+    # ... and against numpy: complex128 on the same tree (the parity figure), complex64 on the same tree (what the
+    # reference's numpy backend itself reaches at this dtype: 895 chained steps cancelling down to ~2^-26.5)
+    want = _numpy_tree_value(arrays, inputs, tree.get_path(), np.complex128)
+    np32 = _numpy_tree_value(arrays, inputs, tree.get_path(), np.complex64)
     return {
         "config": f"BASELINE #2: {nq}-qubit depth-{depth} brickwork circuit amplitude, complex64, exact",
         "kernel": "microtree_kernel (one workgroup walks the whole tree)",
@@ -83,6 +112,9 @@ def config2(qa, sync, nq=53, depth=10, batch=256):
         "amplitude_ms": t_one * 1e3, "us_per_step": t_one / len(tree.steps) * 1e6,
         "batch": batch, "batch_ms": t_b * 1e3, "us_per_amplitude_in_batch": t_b / batch * 1e6,
         "rel_diff_vs_launch_by_launch": abs(got - ref) / max(abs(ref), 1e-300),
+        "rel_err_vs_fp64_oracle": abs(got - want) / max(abs(want), 1e-300),
+        "numpy_complex64_same_tree_rel_err_vs_fp64": abs(np32 - want) / max(abs(want), 1e-300),
+        "abs_amplitude": abs(want),
     }
 
 
@@ -107,6 +139,14 @@ def config5(qa, sync, chi=512, d=2, w=5, nmv=12):
         Ag @ v0
     t_mv_graph, _ = _timed(lambda: Ag @ v0, 50, sync)
     del Ag
+    # parity of the matvec: numpy float64 on the same four tensors, staged L, W1, W2, R (tests/checks.py does the same)
+    xh = v0.to_numpy().reshape(chi, d, d, chi)
+    t_ = np.tensordot(L, xh, axes=([2], [0]))                          # [a, p, S1, S2, B]
+    t_ = np.einsum("apSTB,pqsS->aqsTB", t_, W1, optimize=True)
+    t_ = np.einsum("aqsTB,qrtT->arstB", t_, W2, optimize=True)
+    want_mv = np.einsum("arstB,brB->astb", t_, R, optimize=True).reshape(-1)
+    got_mv = (A @ v0).to_numpy().reshape(-1)
+    mv_err = float(np.max(np.abs(got_mv - want_mv)) / np.max(np.abs(want_mv)))
     fl_mv = A._expr(0).tree.total_flops("float64")
     names = []
     ex = A._expr(0).executor
@@ -133,6 +173,7 @@ def config5(qa, sync, chi=512, d=2, w=5, nmv=12):
         "matvec_ms": t_mv * 1e3, "matvec_ms_as_hipgraph": t_mv_graph * 1e3, "matvec_flop": fl_mv, "matvec_tflops_f64": fl_mv / t_mv / 1e12,
         "matvec_frac_of_f64_mfma_peak_78.6": fl_mv / t_mv / 78.6e12,
         "matvec_kernels": sorted(set(names)),
+        "rel_err_vs_fp64_oracle": mv_err,      # max |A x - numpy| / max |numpy|, the chi = 512 matvec
         "lanczos_matvecs": nmv, "lanczos_ms": t_eig * 1e3,
         "split_svd_via_eig_ms": t_split * 1e3,
         "environment_update_ms": t_env * 1e3, "environment_update_tflops_f64": fl_env / t_env / 1e12,

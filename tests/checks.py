@@ -16,8 +16,12 @@ from oracle import np_oracle as orc
 #: max |got - want| / max |want| over a whole result, and 2e-6 there is what a k-ordered fp32 fma chain meets on the
 #: mostly-positive fills of these checks with K up to 4096 and a few chained steps (round 2 used 2e-5).  The full-size
 #: lattice tests and the smoke assert 1e-6 on the VALUE of the network itself.
-RTOL = {np.dtype("float32"): 2e-6, np.dtype("float64"): 1e-12,
-        np.dtype("complex64"): 2e-6, np.dtype("complex128"): 1e-12}
+RTOL = {np.dtype("float32"): 1e-6, np.dtype("float64"): 1e-12,
+        np.dtype("complex64"): 1e-6, np.dtype("complex128"): 1e-12}
+
+#: worst relative error every ``assert_close`` of this process has seen, per dtype (printed by conftest's terminal
+#: summary: the ACHIEVED figures next to the bars)
+WORST = {}
 
 
 def rand(rng, shape, dtype):
@@ -28,13 +32,19 @@ def rand(rng, shape, dtype):
     return x.astype(dtype)
 
 
-def assert_close(got, want, dtype, scale=None):
+def assert_close(got, want, dtype, scale=None, tol=None):
+    """max |got - want| / max |want| <= RTOL[dtype] (``tol`` overrides the bar where a check states why)."""
     got, want = np.asarray(got), np.asarray(want)
     assert got.shape == want.shape, (got.shape, want.shape)
-    tol = RTOL[np.dtype(dtype)]
+    tol = RTOL[np.dtype(dtype)] if tol is None else tol
     ref = np.max(np.abs(want)) if scale is None else scale
     ref = max(float(ref), 1e-300)
     err = float(np.max(np.abs(got.astype(np.complex128) - want.astype(np.complex128)))) / ref if got.size else 0.0
+    key = np.dtype(dtype).name
+    if err > WORST.get(key, (0.0, ""))[0]:
+        import inspect
+
+        WORST[key] = (err, inspect.stack()[1].function)
     assert err <= tol, f"rel err {err:.3e} > {tol:.1e}"
 
 
@@ -882,9 +892,18 @@ def check_microtree_config2():
     assert len(tree.steps) == 895 and tree.contraction_width() <= 12
     hi = [a.astype(np.complex128) for a in arrays]
     ref = orc.oracle_array_contract(hi, inputs, (), path=tree.get_path())
+    # what "quimb's numpy backend" itself achieves in complex64 on this tree: 895 chained steps whose partial sums
+    # cancel down to |amplitude| ~ 2^-26.5 -- 0.7e-6 ... 2.1e-6 relative over the six amplitudes checked here (measured;
+    # an error of ~6e-8 per step accumulating over the ~30 steps on the deepest root-to-leaf chain and the final
+    # cancellation).  north_star's 1e-6 is therefore not reachable by ANY complex64 evaluation of this network; the bar
+    # is 1e-5 (round 4: 1e-4), the achieved figures are printed and recorded in checks.WORST
+    lo = orc.oracle_array_contract(arrays, inputs, (), path=tree.get_path())
     bm = qa.MicroTree(tree, "complex64").bind(arrays)
     got = bm().to_numpy().item()
-    assert abs(got - ref) <= 1e-4 * abs(ref)
+    err, err_np = abs(got - ref) / abs(ref), abs(lo - ref) / abs(ref)
+    print(f"config #2 amplitude: device complex64 vs fp64 oracle {err:.2e}; numpy complex64 on the same tree {err_np:.2e}")
+    WORST["config2 complex64 amplitude (895 steps)"] = (err, "check_microtree_config2")
+    assert err <= 1e-5, (err, err_np)
     e = [np.array([1, 0], np.complex64), np.array([0, 1], np.complex64)]
     bits = np.random.default_rng(3).integers(0, 2, size=(5, 53))
     n_in = len(arrays)
@@ -894,7 +913,9 @@ def check_microtree_config2():
         for q in range(53):
             hi_i[n_in - 53 + q] = e[bits[i, q]].astype(np.complex128)
         want = orc.oracle_array_contract(hi_i, inputs, (), path=tree.get_path())
-        assert abs(res[i] - want) <= 1e-4 * abs(want) + 1e-12
+        err = abs(res[i] - want) / abs(want)
+        print(f"  bitstring {i}: {err:.2e}")
+        assert err <= 1e-5, (i, err)
 
 
 def check_circuit_amplitude(dtype, n=10, depth=6, seed=17):
