@@ -43,6 +43,13 @@ def register():
         decomp.qr_stabilized.register("quimb_amd")(qr_stabilized)
         if hasattr(decomp, "svd_via_eig_truncated"):
             decomp.svd_via_eig_truncated.register("quimb_amd")(svd_via_eig_truncated)
+        # the GEMM-shaped drivers (decomp.py:2359 qr_via_cholesky, :2262 cholesky_regularized, :1689 svd_rand_truncated,
+        # :2538 rsvd): Gram / sketch products on this library's kernels, potrf / syevd of the reduced size on rocSOLVER
+        for name, fn in (("qr_via_cholesky", qr_via_cholesky), ("cholesky_regularized", cholesky_regularized),
+                         ("svd_rand_truncated", svd_rand_truncated)):
+            drv = getattr(decomp, name, None)
+            if drv is not None and hasattr(drv, "register"):
+                drv.register("quimb_amd")(fn)
     except Exception:
         pass
     return "quimb_amd"
@@ -80,3 +87,27 @@ def qr_stabilized(x, absorb=1, stabilized=True, **_):
     from .split import array_split
 
     return array_split(x, "qr", _ABSORB_NAMES.get(absorb, absorb), None, 0.0, "rel", None, stabilized=stabilized)
+
+
+def qr_via_cholesky(x, absorb=-1, shift=True, solve_triangular=True, **_):
+    """Drop-in for ``quimb.tensor.decomp.qr_via_cholesky`` (decomp.py:2359-2420; default absorb there: "left")."""
+    from .split import array_split
+
+    return array_split(x, "qr:cholesky", _ABSORB_NAMES.get(absorb, absorb), None, 0.0, "rel", None, shift=shift)
+
+
+def cholesky_regularized(x, absorb=0, shift=True, **_):
+    """Drop-in for ``quimb.tensor.decomp.cholesky_regularized`` (decomp.py:2262-2322)."""
+    from .split import array_split
+
+    return array_split(x, "cholesky", _ABSORB_NAMES.get(absorb, absorb), None, 0.0, "rel", None, shift=shift)
+
+
+def svd_rand_truncated(x, max_bond, absorb=0, oversample=10, num_iterations=2, method_lorthog="qr", method_reduced="svd",
+                       right=None, lorthog_opts=None, reduced_opts=None, seed=None, **_):
+    """Drop-in for ``quimb.tensor.decomp.svd_rand_truncated`` (decomp.py:1689-1868)."""
+    from .split import array_split
+
+    return array_split(x, "svd:rand", _ABSORB_NAMES.get(absorb, absorb), max_bond if max_bond and max_bond > 0 else None, 0.0,
+                       "rel", None, oversample=oversample, num_iterations=num_iterations, method_lorthog=method_lorthog,
+                       method_reduced=method_reduced, right=right, seed=seed)

@@ -66,7 +66,8 @@ class DMRG2:
     value per sweep, the last one repeated (``_set_bond_dim_seq``, dmrg.py:596-604).  After ``solve``:
     ``energy``, ``energies`` (one per sweep), ``state`` (MPS arrays, reference order l, r, p)."""
 
-    def __init__(self, ham, bond_dims=None, cutoffs=1e-8, which="SA", p0=None, dtype=None, seed=0, split="svd"):
+    def __init__(self, ham, bond_dims=None, cutoffs=1e-8, which="SA", p0=None, dtype=None, seed=0, split="svd",
+                 canonize="qr", split_opts=None):
         if bond_dims is None:
             bond_dims = [8, 16, 32, 64, 128, 256, 512, 1024]        # DMRG2's default schedule, dmrg.py:1168
         ws = [asarray(w) for w in ham]
@@ -82,9 +83,20 @@ class DMRG2:
         self.phys = [w.shape[2] for w in ws]
         if which not in ("SA", "LA"):
             raise ValueError("which must be 'SA' or 'LA'")
-        if split not in ("svd", "eig"):
-            raise ValueError("split must be 'svd' or 'eig'")
-        self.which, self.split = which, split
+        if split not in ("svd", "eig", "rand"):
+            raise ValueError("split must be 'svd', 'eig' or 'rand'")
+        if canonize not in ("qr", "cholesky"):
+            raise ValueError("canonize must be 'qr' or 'cholesky'")
+        # split: "svd" -- rocSOLVER gesvd (the reference's default driver); "eig" -- the reference's ``svd:eig`` (Gram
+        # matrix + syevd of size chi d); "rand" -- the reference's ``svd:rand`` (decomp.py:1689): a sketch of ``max_bond +
+        # oversample`` columns, so the only LAPACK work is a potrf and a syevd of THAT size and everything O(n^3) runs on
+        # the contraction kernels.  ``split_opts`` go to ``linalg.svd_rand`` (default: no power iterations -- the sketch of
+        # a two-site tensor whose numerical rank is below max_bond + oversample is exact to the discarded tail, and plain
+        # power iterations would push the small Schmidt directions a sweep relies on below the rounding floor).
+        # canonize: "qr" -- geqrf/orgqr; "cholesky" -- the reference's ``qr:cholesky`` (decomp.py:2359) with one
+        # refinement pass, double precision only (cond^2 must stay below 1/eps), Householder QR as the fallback.
+        self.which, self.split, self.canonize = which, split, canonize
+        self.split_opts = dict(split_opts or {})
         self.opts = {"default_sweep_sequence": "R", "local_eig_tol": 1e-3, "local_eig_ncv": 4,
                      "local_eig_maxiter": None}
         self._set_seq(bond_dims, cutoffs)
@@ -149,18 +161,37 @@ class DMRG2:
     def _canonize_to(self, site):
         """Left-canonical left of ``site``, right-canonical right of it (QR sweeps from both ends)."""
         A = self._A
+        chol = self.canonize == "cholesky" and self.dtype.itemsize >= 8 and self.dtype.kind in "fc" \
+            and self.dtype not in (np.dtype("float32"), np.dtype("complex64"))
+
+        def qr_tall(m):
+            if chol and m.shape[0] >= m.shape[1]:
+                try:
+                    return linalg.qr_via_cholesky(m, shift=True, refine=True)
+                except np.linalg.LinAlgError:
+                    pass
+            return linalg.qr(m)
+
+        def lq_wide(m):                      # (lower factor, isometry with orthonormal rows)
+            if chol and m.shape[0] <= m.shape[1]:
+                try:
+                    return linalg.lq_via_cholesky(m, shift=True, refine=True)
+                except np.linalg.LinAlgError:
+                    pass
+            q, rr = linalg.qr(ops.transpose(m, (1, 0)))           # LQ through the QR of the transpose: A = (R^T)(Q^T)
+            return ops.transpose(rr, (1, 0)), ops.transpose(q, (1, 0))
+
         for i in range(site):
             l, p, r = A[i].shape
-            q, rr = linalg.qr(A[i].reshape((l * p, r)))
+            q, rr = qr_tall(A[i].reshape((l * p, r)))
             A[i] = q.reshape((l, p, q.shape[1]))
             A[i + 1] = ops.tensordot(rr, A[i + 1], axes=([1], [0]))
         for i in range(self.L - 1, site, -1):
             l, p, r = A[i].shape
-            # LQ through the QR of the transpose: A = (R^T)(Q^T)
-            q, rr = linalg.qr(ops.transpose(A[i].reshape((l, p * r)), (1, 0)))
-            k = q.shape[1]
-            A[i] = ops.transpose(q, (1, 0)).reshape((k, p, r))
-            A[i - 1] = ops.tensordot(A[i - 1], ops.transpose(rr, (1, 0)), axes=([2], [0]))
+            lo, q = lq_wide(A[i].reshape((l, p * r)))
+            k = q.shape[0]
+            A[i] = q.reshape((k, p, r))
+            A[i - 1] = ops.tensordot(A[i - 1], lo, axes=([2], [0]))
 
     def _grow_left(self, i):
         """_Lenv[i + 1] from _Lenv[i] and site i:  L'[A, W, B] = L[a, w, b] A[a, s, A] W[w, W, t, s] conj(A)[b, t, B]
@@ -200,7 +231,12 @@ class DMRG2:
                                        miniter=ncv)
             loc_en, gs = float(evals[0]), vecs.reshape((n,))
         m = gs.reshape((dims[0] * dims[1], dims[2] * dims[3]))
-        u, s, vh = (linalg.svd if self.split == "svd" else linalg.svd_via_eig)(m)
+        if self.split == "rand" and max_bond and 0 < max_bond + self.split_opts.get("oversample", 10) < min(m.shape):
+            so = dict(oversample=10, num_iterations=0, method_lorthog="qr:cholesky", method_reduced="svd:eig")
+            so.update(self.split_opts)
+            u, s, vh = linalg.svd_rand(m, max_bond, **so)
+        else:
+            u, s, vh = (linalg.svd if self.split == "svd" else linalg.svd_via_eig)(m)
         sh = s.to_numpy()
         k = svals_to_keep(sh, cutoff, "sum2", max_bond)          # bond_compress_cutoff_mode, dmrg.py:85
         sk = asarray(sh[:k].astype(u.dtype))

@@ -159,6 +159,180 @@ def cholesky(x):
     return _single("cholesky", x)
 
 
+def solve_triangular(a, b, lower=True, left=True):
+    """``X`` with ``a X = b`` (``left``) or ``X a = b`` for a triangular ``a`` (rocBLAS trsm through torch)."""
+    import torch
+
+    a, hook = _hook(a, "solve_triangular")
+    if hook is not None:
+        return hook(a, b, lower, left)
+    a, ta = _as_torch(a)
+    _, tb = _as_torch(b)
+    return _wrap(a, torch.linalg.solve_triangular(ta, tb, upper=not lower, left=left))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# GEMM-shaped decompositions: the O(n^3) part on this library's kernels, only an n x n factorisation on rocSOLVER.
+# An L = 100, chi = 512 DMRG2 sweep spent 0.8-1.7 s in geqrf/orgqr (canonisation) and 1.1-2.0 s in syevd of 1024 x 1024
+# Gram matrices (splits) against 0.22 s on the contraction path (profiles/r04_dmrg_sweep.txt); the reference ships the
+# GEMM-shaped alternatives as split drivers: ``qr:cholesky`` (quimb/tensor/decomp.py:2359-2420), ``cholesky``
+# (:2262-2322), ``svd:rand`` (:1689-1868), ``rsvd`` (:2538; quimb/linalg/rand_linalg.py:114-205).
+# ---------------------------------------------------------------------------------------------------------------------
+def cholesky_regularized(g, shift=True):
+    """Lower Cholesky factor of the Hermitian matrix ``g`` with the reference's regularisation (``_with_diag_shift``,
+    decomp.py:1866-1880): ``shift`` True / negative -> eps * trace(g) on the diagonal, a positive float -> that multiple
+    of the trace, False / 0 -> none, "auto" -> none first, eps * trace if the factorisation fails."""
+    import torch
+
+    g, hook = _hook(g, "cholesky")
+    if shift == "auto":
+        try:
+            return cholesky_regularized(g, shift=False)
+        except Exception:
+            return cholesky_regularized(g, shift=True)
+    sh = {False: 0.0, True: -1.0}.get(shift, shift)
+    sh = float(np.finfo(np.dtype(g.dtype)).eps) if sh < 0 else float(sh)
+    if hook is not None:
+        a = g.to_numpy()
+        if sh > 0:
+            a = a + sh * np.trace(a) * np.eye(a.shape[-1], dtype=a.dtype)
+        return hook(Array.from_numpy(a, dev=g._dev))
+    g, t = _as_torch(g)
+    if sh > 0:
+        t = t + (sh * torch.diagonal(t).sum()) * torch.eye(t.shape[-1], dtype=t.dtype, device=t.device)
+    L, info = torch.linalg.cholesky_ex(t)
+    if int(info.max()) != 0:          # (one host read: a failed factorisation must not hand back garbage)
+        raise np.linalg.LinAlgError("cholesky_regularized: matrix not positive definite")
+    return _wrap(g, L)
+
+
+def qr_via_cholesky(x, shift=True, refine=False):
+    """``(Q, R)`` of a tall 2-d array (m >= n) from the Cholesky factor of its Gram matrix -- the reference's
+    ``qr_via_cholesky`` (decomp.py:2359-2420): ``G = x^H x`` (one GETT launch), ``G = R^H R`` (potrf on n x n),
+    ``Q = x R^-1`` (a triangular solve).  Orthogonality of Q degrades as cond(x)^2 eps (and by the regularising shift);
+    ``refine`` repeats the step on Q (CholeskyQR2: orthogonal to eps for cond(x) < eps^-1/2) and folds the second
+    triangle into R.  R has a positive real diagonal by construction (no phase fix needed)."""
+    from . import ops
+
+    x = x if isinstance(x, Array) else Array.from_numpy(np.asarray(x))
+    g = ops.tensordot(x.conj(), x, axes=([0], [0]))            # x^H x, (n, n)
+    L = cholesky_regularized(g, shift=shift)                    # g = L L^H  ->  R = L^H
+    R = ops.transpose(L.conj(), (1, 0))
+    Q = solve_triangular(R, x, lower=False, left=False)         # Q R = x
+    if refine:
+        Q, R2 = qr_via_cholesky(Q, shift=shift, refine=False)
+        R = ops.tensordot(R2, R, axes=([1], [0]))
+    return Q, R
+
+
+def lq_via_cholesky(x, shift=True, refine=False):
+    """``(L, Q)`` of a wide 2-d array (m <= n): ``x x^H = L L^H``, ``Q = L^-1 x`` -- the form the Cholesky route yields
+    directly (decomp.py:2383-2386, ``transposed = False``)."""
+    from . import ops
+
+    x = x if isinstance(x, Array) else Array.from_numpy(np.asarray(x))
+    g = ops.tensordot(x, x.conj(), axes=([1], [1]))            # x x^H, (m, m)
+    L = cholesky_regularized(g, shift=shift)
+    Q = solve_triangular(L, x, lower=True, left=True)           # L Q = x
+    if refine:
+        L2, Q = lq_via_cholesky(Q, shift=shift, refine=False)
+        L = ops.tensordot(L, L2, axes=([1], [0]))
+    return L, Q
+
+
+def _randn(dev, shape, dtype, seed):
+    """Gaussian test matrix.  ``seed`` given: numpy's ``default_rng(seed).normal`` on the host (the stream the
+    reference draws from, decomp.py:1795-1799 -- results reproducible against it); None: drawn on the device."""
+    dtype = np.dtype(dtype)
+    if seed is not None or not hasattr(dev, "torch"):
+        rng = seed if isinstance(seed, np.random.Generator) else np.random.default_rng(seed)
+        return Array.from_numpy(rng.normal(size=shape).astype(dtype), dev=dev)      # (real draws for complex x too, as there)
+    torch = dev.torch
+    rdt = np.zeros(0, dtype).real.dtype
+    t = torch.randn(shape, dtype=dev._tdt[np.dtype(rdt)], device=dev.tdev).to(dev._tdt[dtype])
+    return Array(dev, t.reshape(-1), tuple(shape), dtype)
+
+
+def _orth(y, method):
+    if method in ("qr:cholesky", "cholesky"):
+        return qr_via_cholesky(y, shift=True, refine=True)[0]
+    if method == "qr":
+        return qr(y)[0]
+    if method in ("svd:eig", "eig", "svd"):
+        # as the reference: ``array_split(y, absorb="lorthog", method=...)`` with ITS defaults (decomp.py:1806), i.e. the
+        # basis is truncated at the relative cutoff 1e-10 ("rsum2") -- after power iterations that drops directions
+        from .split import array_split
+
+        return array_split(y, method, "lorthog")[0]
+    raise ValueError(f"unknown orthogonalisation method {method!r}")
+
+
+def svd_rand(x, k, oversample=10, num_iterations=2, method_lorthog="qr", method_reduced="svd", right=None,
+             stabilize=False, seed=None):
+    """Rank-``k`` randomised SVD ``(U, s, VH)`` by sketching -- the reference's ``svd_rand_truncated`` (decomp.py:1689-
+    1868) with ``absorb=None``: ``y = x w`` for a Gaussian ``w`` with ``k + oversample`` columns, ``num_iterations``
+    rounds of ``y <- x (x^H y)`` (plain, as the reference; ``stabilize`` re-orthogonalises y after every product -- what
+    quimb's other randomised driver does, rand_linalg.py:180-188 -- so that directions below eps^(1/(2q+1)) s_max
+    survive the powers), ``Q`` = an orthonormal basis of y (``method_lorthog``), the small factor ``B = Q^H x``
+    decomposed by ``method_reduced`` and truncated to k, ``U = Q U_B``.  ``right`` False sketches the row space instead
+    (default: the shorter side is reduced: ``right = m > n``).  Every product is a GETT launch of this library; with
+    ``method_lorthog="qr:cholesky"`` and ``method_reduced="svd:eig"`` the only LAPACK work left is a potrf and a syevd
+    of size k + oversample."""
+    from . import ops
+
+    x = x if isinstance(x, Array) else Array.from_numpy(np.asarray(x))
+    m, n = x.shape
+    k = min(m, n) if k is None or k < 0 else min(int(k), m, n)
+    ks = min(m, n, k + int(oversample))
+    if right is None:
+        right = m > n
+    mm = lambda a, b: ops.tensordot(a, b, axes=([1], [0]))
+    xh = None
+    if right:
+        y = mm(x, _randn(x._dev, (n, ks), x.dtype, seed))                     # (m, ks)
+        for _ in range(int(num_iterations)):
+            if stabilize:
+                y = _orth(y, method_lorthog)
+            y = ops.tensordot(x.conj(), y, axes=([0], [0]))                     # x^H y, (n, ks)
+            if stabilize:
+                y = _orth(y, method_lorthog)
+            y = mm(x, y)
+        Q = _orth(y, method_lorthog)                                             # (m, ks)
+        B = ops.tensordot(Q.conj(), x, axes=([0], [0]))                         # Q^H x, (ks, n)
+    else:
+        w = _randn(x._dev, (ks, m), x.dtype, seed)
+        y = mm(w, x)                                                             # (ks, n)
+        for _ in range(int(num_iterations)):
+            if stabilize:
+                y = ops.transpose(_orth(ops.transpose(y, (1, 0)), method_lorthog), (1, 0))
+            y = ops.tensordot(y, x.conj(), axes=([1], [1]))                     # y x^H, (ks, m)
+            if stabilize:
+                y = ops.transpose(_orth(ops.transpose(y, (1, 0)), method_lorthog), (1, 0))
+            y = mm(y, x)
+        Q = _orth(ops.transpose(y.conj(), (1, 0)), method_lorthog)              # (n, ks): basis of the row space
+        B = mm(x, Q)                                                             # (m, ks)
+    if method_reduced in ("svd:eig", "eig"):
+        ub, s, vbh = svd_via_eig(B)
+    elif method_reduced == "svd":
+        ub, s, vbh = svd(B)
+    else:
+        raise ValueError(f"unknown method_reduced {method_reduced!r}")
+    kk = min(k, s.shape[0])
+    ub, vbh = ub[:, :kk], vbh[:kk, :]
+    s = Array.from_numpy(s.to_numpy()[:kk], dev=x._dev)
+    if right:
+        return mm(Q, ub), s, vbh
+    return ub, s, ops.tensordot(vbh, Q.conj(), axes=([1], [1]))                  # VH = VH_B Q^H
+
+
+def rsvd(x, k, q=2, p=0, seed=None, method_lorthog="qr:cholesky", method_reduced="svd:eig"):
+    """Halko's randomised SVD with STABILISED power iterations (``rsvd_core``, quimb/linalg/rand_linalg.py:114-205: the
+    sketch is re-orthogonalised after every product; q = 2 power iterations, no oversampling by default) -- the engine of
+    the reference's ``rsvd`` split driver (decomp.py:2538) for a fixed target rank."""
+    return svd_rand(x, k, oversample=p, num_iterations=q, method_lorthog=method_lorthog, method_reduced=method_reduced,
+                    stabilize=True, seed=seed)
+
+
 def eigvalsh(x):
     w, _ = eigh(x)
     return w

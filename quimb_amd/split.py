@@ -76,10 +76,15 @@ def _scale_rows(v, vh):
 
 
 def array_split(x, method="svd", absorb="both", max_bond=None, cutoff=1e-10, cutoff_mode="rsum2", renorm=None,
-                stabilized=True):
+                stabilized=True, **opts):
     """``(left, s, right)`` of a 2-d device array, entries ``None`` where ``absorb`` does not ask for them.
 
-    ``method``: "svd" (rocSOLVER gesvd), "svd:eig" / "eig" (Gram matrix + syevd), "qr", "lq" (no truncation).
+    ``method``: "svd" (rocSOLVER gesvd), "svd:eig" / "eig" (Gram matrix + syevd), "qr", "lq" (no truncation), and the
+    GEMM-shaped drivers of the reference (``quimb_amd.linalg``): "qr:cholesky" (QR- or LQ-like by ``absorb``; options
+    ``shift``, ``refine``), "cholesky" (Hermitian positive definite input; ``absorb`` "both" / "lsqrt" / "rsqrt";
+    ``shift``), "svd:rand" (needs ``max_bond``; options ``oversample``, ``num_iterations``, ``method_lorthog``,
+    ``method_reduced``, ``right``, ``seed``, ``stabilize``) and "rsvd" (stabilised power iterations, then the cutoff
+    policy on the ``max_bond`` values found; options ``q``, ``p``, ``seed``).
     ``absorb``: None / "U,s,VH", "both", "left", "right", "lorthog", "rorthog", "lfactor", "rfactor", "lsqrt",
     "rsqrt", "s" (aliases as in decomp.py:264-298).  ``renorm``: True -> the power matching ``cutoff_mode``.
     ``stabilized`` (qr / lq only): fix the phases so the triangular factor has a non-negative real diagonal."""
@@ -113,10 +118,40 @@ def array_split(x, method="svd", absorb="both", max_bond=None, cutoff=1e-10, cut
                     left, right = _scale_cols(left, np.conj(phase)), _scale_rows(phase, right)
         return (left if mode in ("left", "right", "lfactor", "lorthog") else None, None,
                 right if mode in ("left", "right", "rfactor", "rorthog") else None)
+    if method == "qr:cholesky":
+        # QR-like ("right" family) or LQ-like ("left" family) from the Gram matrix's Cholesky factor (decomp.py:2359-2420)
+        if mode in ("right", "lorthog", "rfactor"):
+            left, right = linalg.qr_via_cholesky(x, **opts)
+        elif mode in ("left", "rorthog", "lfactor"):
+            left, right = linalg.lq_via_cholesky(x, **opts)
+        else:
+            raise ValueError(f"Invalid absorb mode for qr_via_cholesky: {absorb}")
+        return (left if mode in ("left", "right", "lfactor", "lorthog") else None, None,
+                right if mode in ("left", "right", "rfactor", "rorthog") else None)
+    if method == "cholesky":
+        if mode not in ("both", "lsqrt", "rsqrt"):
+            raise ValueError(f"Invalid absorb={absorb} in cholesky_regularized. Should be one of 'both', 'lsqrt' or 'rsqrt'.")
+        L = linalg.cholesky_regularized(x, **opts)
+        return (L if mode != "rsqrt" else None, None,
+                ops.transpose(L.conj(), (1, 0)) if mode != "lsqrt" else None)
     if method == "svd":
         u, s, vh = linalg.svd(x)
     elif method in ("svd:eig", "eig"):
         u, s, vh = linalg.svd_via_eig(x)
+    elif method == "svd:rand":
+        # static truncation (``max_bond`` only, decomp.py:1703-1706): the cutoff policy below still sees the k values found
+        if max_bond is None or max_bond < 0:
+            import warnings
+
+            warnings.warn("Using 'svd:rand' without `max_bond` is inefficient, consider simply using 'svd' or 'svd:eig' instead.")
+        if opts.get("right") is None and mode in ("right", "lorthog", "rfactor", "left", "rorthog", "lfactor"):
+            opts = dict(opts, right=mode in ("right", "lorthog", "rfactor"))
+        u, s, vh = linalg.svd_rand(x, max_bond, **opts)
+        cutoff = 0.0
+    elif method == "rsvd":
+        if max_bond is None or max_bond < 0:
+            raise ValueError("method 'rsvd' on the device needs a target rank (max_bond)")
+        u, s, vh = linalg.rsvd(x, max_bond, **opts)
     else:
         raise ValueError(f"unknown split method {method!r}")
     sh = s.to_numpy().astype(np.float64)
@@ -144,7 +179,7 @@ def array_split(x, method="svd", absorb="both", max_bond=None, cutoff=1e-10, cut
 
 
 def tensor_split(T, left_inds, method="svd", get=None, absorb="both", max_bond=None, cutoff=1e-10,
-                 cutoff_mode="rel", renorm=None, right_inds=None, bond_ind=None, ltags=None, rtags=None):
+                 cutoff_mode="rel", renorm=None, right_inds=None, bond_ind=None, ltags=None, rtags=None, **opts):
     """Split a ``quimb_amd.Tensor`` across ``left_inds | right_inds`` (reference ``tensor_split``,
     tensor_core.py:390-640: matricise with ``to_dense``-style fusing, ``array_split``, un-fuse, new bond last on
     the left factor and first on the right one).  ``get``: None -> (Tensor, Tensor) -- or (Tensor, s Tensor, Tensor)
@@ -165,7 +200,7 @@ def tensor_split(T, left_inds, method="svd", get=None, absorb="both", max_bond=N
     x = x.reshape((int(np.prod(ldims, dtype=np.int64)), int(np.prod(rdims, dtype=np.int64))))
     if get == "values":      # the whole spectrum, untruncated (``array_svals``, decomp.py:177-197)
         return array_split(x, method, "s", None, 0.0, cutoff_mode, None)[1]
-    left, s, right = array_split(x, method, absorb, max_bond, cutoff, cutoff_mode, renorm)
+    left, s, right = array_split(x, method, absorb, max_bond, cutoff, cutoff_mode, renorm, **opts)
     if left is not None:
         left = left.reshape(tuple(ldims) + (left.shape[1],))
     if right is not None:

@@ -2,7 +2,7 @@
 """BASELINE config #5 end to end: ``DMRG2(MPO_ham_heis(L), bond_dims=chi)`` sweeps on the device
 (quimb_amd.dmrg.DMRG2; reference quimb/tensor/tn1d/dmrg.py).  Prints wall time per sweep and the energy.
 
-    python scripts/dmrg_sweep.py [L] [chi] [sweeps] [split] [sweep sequence, e.g. RL]
+    python scripts/dmrg_sweep.py [L] [chi] [sweeps] [split: svd|eig|rand] [sweep sequence, e.g. RL] [canonize: qr|cholesky]
 """
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -16,6 +16,7 @@ chi = int(sys.argv[2]) if len(sys.argv) > 2 else 512
 nsweeps = int(sys.argv[3]) if len(sys.argv) > 3 else 2
 split = sys.argv[4] if len(sys.argv) > 4 else "eig"
 seq = sys.argv[5] if len(sys.argv) > 5 else "R"            # the reference's default sweeps rightwards every time
+canon = sys.argv[6] if len(sys.argv) > 6 else "qr"
 import quimb_amd.dmrg as qdm
 
 # where a sweep's wall time goes (device sync around every phase: slightly pessimistic)
@@ -40,13 +41,16 @@ if os.environ.get("QAMD_DMRG_PHASES", "1") != "0":
         svd = staticmethod(timed("split (gesvd)", qa.linalg.svd))
         svd_via_eig = staticmethod(timed("split (Gram eigh)", qa.linalg.svd_via_eig))
         qr = staticmethod(timed("canonize (QR)", qa.linalg.qr))
+        svd_rand = staticmethod(timed("split (sketch + reduced eigh)", qa.linalg.svd_rand))
+        qr_via_cholesky = staticmethod(timed("canonize (Cholesky QR)", qa.linalg.qr_via_cholesky))
+        lq_via_cholesky = staticmethod(timed("canonize (Cholesky QR)", qa.linalg.lq_via_cholesky))
     qdm.linalg = _L
     qdm.DMRG2._grow_left = timed("environment update", qdm.DMRG2._grow_left)
     qdm.DMRG2._grow_right = timed("environment update", qdm.DMRG2._grow_right)
     qdm.TNLinearOperator = timed("operator setup", qdm.TNLinearOperator)
 
-dm = DMRG2(mpo_ham_heis(L), bond_dims=[chi], cutoffs=1e-10, split=split)
-print(f"DMRG2 Heisenberg L={L} fp64, max bond {chi}, split={split}; start bond {dm.max_bond()}")
+dm = DMRG2(mpo_ham_heis(L), bond_dims=[chi], cutoffs=1e-10, split=split, canonize=canon)
+print(f"DMRG2 Heisenberg L={L} fp64, max bond {chi}, split={split}, canonize={canon}; start bond {dm.max_bond()}")
 prev = "0"
 for k in range(nsweeps):
     torch.cuda.synchronize()

@@ -1355,6 +1355,16 @@ def check_dmrg(dtype="float64"):
     else:
         assert dm.energy == pytest.approx(e0, rel=2e-5)
     assert {np.dtype(t.dtype) for t in dm.state} == {np.dtype(dtype)}
+    # the GEMM-shaped decompositions (canonisation by "qr:cholesky", splits by "svd:rand" wherever the two-site tensor is
+    # larger than max_bond + oversample): the same fixed point as the real quimb's run with its LAPACK drivers
+    dmf = DMRG2(ham, bond_dims=[8, 16, 32], cutoffs=1e-10, dtype=dtype, split="rand", canonize="cholesky",
+                split_opts={"oversample": 4})
+    assert dmf.solve(tol=1e-9 if f64 else 1e-5, max_sweeps=8)
+    if f64:
+        assert dmf.energy == pytest.approx(ref[-1], abs=1e-8) and abs(dmf.energy - e0) < 1e-8
+        assert dmf.max_bond() == int(g["heis10_max_bond"])
+    else:
+        assert dmf.energy == pytest.approx(e0, rel=2e-5)
     # the reference's own accuracy test: n=6, bond_dims [4, 8, 12], rtol 1e-4 on energy, norm and overlap
     h6 = mpo_ham_heis(6)
     dm = DMRG2(h6, bond_dims=[4, 8, 12], dtype=dtype)
@@ -1396,6 +1406,78 @@ def check_dmrg(dtype="float64"):
 # ---------------------------------------------------------------------------------------------------------
 # truncated splits (tensor_split / array_split policy; golden values from the real quimb)
 # ---------------------------------------------------------------------------------------------------------
+def check_decomp_drivers(dtype="float64"):
+    """The GEMM-shaped split drivers -- "qr:cholesky", "cholesky", "svd:rand", "rsvd" -- against the REAL quimb's results
+    on the same inputs (tests/golden/decomp.npz, made by tests/golden/make_golden_decomp.py): the Cholesky-route factors
+    are unique (positive diagonal) and compared entry by entry; the seeded sketches draw the reference's own random
+    stream, so singular values and the (sign-independent) factor products are compared; "rsvd" on an exactly rank-6
+    input does not depend on the stream.  fp32 runs compare at the accuracy the SQUARED condition of the Gram route
+    leaves in single precision."""
+    import json as _json
+    import os as _os
+
+    g = np.load(_os.path.join(GOLDEN, "decomp.npz"))
+    cases = _json.loads(str(g["cases"]))
+    lo = np.dtype(dtype).itemsize == 4 or np.dtype(dtype) == np.dtype("complex64")
+    tol = 2e-4 if lo else 1e-10
+    for ci, c in enumerate(cases):
+        x = g[f"x{ci}"]
+        xd = x.astype(np.result_type(x.dtype, np.complex64 if lo else np.complex128) if np.iscomplexobj(x)
+                      else (np.float32 if lo else np.float64))
+        kw = dict(c["kw"])
+        left, sv, right = qa.array_split(qa.asarray(xd), method=c["method"], **kw)
+        L = None if left is None else left.to_numpy()
+        R = None if right is None else right.to_numpy()
+        S = None if sv is None else sv.to_numpy()
+        want = {t: (g[f"{t}{ci}"] if f"{t}{ci}" in g.files else None) for t in "lsr"}
+        assert (L is None) == (want["l"] is None) and (R is None) == (want["r"] is None) and (S is None) == (want["s"] is None), c
+        scale = np.max(np.abs(x))
+        if c["method"] in ("qr:cholesky", "cholesky"):
+            for got, w in ((L, want["l"]), (R, want["r"])):
+                if w is not None:
+                    assert got.shape == w.shape and np.max(np.abs(got - w)) <= tol * max(scale, np.max(np.abs(w))), (c, np.max(np.abs(got - w)))
+            if L is not None and R is not None:
+                assert np.max(np.abs(L @ R - x)) <= tol * scale * 10
+            continue
+        if S is not None:
+            assert S.shape == want["s"].shape and np.max(np.abs(S - want["s"])) <= tol * want["s"][0], (c, S, want["s"])
+            got_p, want_p = (L * S) @ R, (want["l"] * want["s"]) @ want["r"]
+        else:
+            got_p, want_p = L @ R, want["l"] @ want["r"]
+        # the sketch's k-th direction is the least converged one: the factor PRODUCT agrees to the accuracy the trailing
+        # kept value is resolved to (both sides ran the same arithmetic on the same random matrix)
+        assert np.max(np.abs(got_p - want_p)) <= (5e-3 if lo else 1e-8) * scale, (c, np.max(np.abs(got_p - want_p)))
+    # orthogonality and the refinement step: an ill-conditioned tall matrix (cond 1e5)
+    rng = np.random.default_rng(9)
+    u, _ = np.linalg.qr(rng.normal(size=(96, 24)))
+    v, _ = np.linalg.qr(rng.normal(size=(24, 24)))
+    bad = ((u * np.logspace(0, -5 if not lo else -2, 24)) @ v.T).astype(np.float32 if lo else np.float64)
+    eps = np.finfo(bad.dtype).eps
+    for refine in (False, True):
+        q, r = qa.linalg.qr_via_cholesky(qa.asarray(bad), refine=refine)
+        q, r = q.to_numpy(), r.to_numpy()
+        assert np.max(np.abs(q @ r - bad)) <= 100 * eps
+        orth = np.max(np.abs(q.T @ q - np.eye(24)))
+        cond = 1e2 if lo else 1e5
+        assert orth <= (50 * eps if refine else 100 * cond**2 * eps), (refine, orth)     # one pass: cond^2 eps; two: eps
+        assert np.all(np.diag(r) > 0) and np.allclose(r, np.triu(r))
+    l_, q_ = qa.linalg.lq_via_cholesky(qa.asarray(bad.T.copy()), refine=True)
+    assert np.max(np.abs(l_.to_numpy() @ q_.to_numpy() - bad.T)) <= 100 * eps
+    assert np.max(np.abs(q_.to_numpy() @ q_.to_numpy().T - np.eye(24))) <= 50 * eps
+    # the stabilised randomised SVD resolves a spectrum spanning many decades (plain power iterations would not)
+    spec = np.logspace(0, -9 if not lo else -3, 20)
+    u, _ = np.linalg.qr(rng.normal(size=(64, 20)))
+    v, _ = np.linalg.qr(rng.normal(size=(48, 20)))
+    m = ((u * spec) @ v.T).astype(bad.dtype)
+    U, S, VH = qa.linalg.rsvd(qa.asarray(m), 20, q=2)
+    S = S.to_numpy()
+    exact = np.linalg.svd(m.astype(np.float64), compute_uv=False)[:20]
+    nk = int(np.count_nonzero(exact > (1e-6 if not lo else 1e-2) * exact[0]))     # the Gram route inside: ~sqrt(eps) floor,
+    assert len(S) >= nk, (len(S), nk)                                               # below it directions are DROPPED
+    assert np.max(np.abs(S[:nk] / exact[:nk] - 1.0)) <= (1e-4 if not lo else 5e-2), S[:nk] / exact[:nk]
+    assert np.max(np.abs((U.to_numpy() * S) @ VH.to_numpy() - m)) <= (1e-7 if not lo else 1e-2) * exact[0]
+
+
 def check_split(dtype="float64"):
     import json
 

@@ -328,3 +328,11 @@ class EmuDevice:
 
     def linalg_cholesky(self, x):
         return self._wrap_np(np.linalg.cholesky(x.to_numpy()))
+
+    def linalg_solve_triangular(self, a, b, lower=True, left=True):
+        import scipy.linalg as sla
+
+        A, B = a.to_numpy(), np.asarray(b.to_numpy() if hasattr(b, "to_numpy") else b)
+        if left:
+            return self._wrap_np(sla.solve_triangular(A, B, lower=lower))
+        return self._wrap_np(sla.solve_triangular(A.T, B.T, lower=not lower).T)        # X A = B  <=>  A^T X^T = B^T

@@ -31,6 +31,9 @@ def register_function(backend, name, fn, wrap=False):
 def _np_fn(name):
     if (("numpy", name)) in _REGISTRY:
         return _REGISTRY["numpy", name]
+    if name.startswith("scipy."):          # autoray resolves ``scipy.linalg.*`` for the numpy backend from scipy itself
+        obj = importlib.import_module(name.rsplit(".", 1)[0])
+        return getattr(obj, name.rsplit(".", 1)[1])
     obj = np
     for part in name.split("."):
         obj = getattr(obj, part)
@@ -75,8 +78,8 @@ class _Namespace:
         self._backend = backend
 
     def __getattr__(self, name):
-        if name == "linalg":
-            return _SubNamespace(self._backend, "linalg")
+        if name in ("linalg", "scipy", "random"):
+            return _SubNamespace(self._backend, name)
         return get_lib_fn(self._backend, name)
 
 
@@ -85,6 +88,8 @@ class _SubNamespace:
         self._backend, self._prefix = backend, prefix
 
     def __getattr__(self, name):
+        if self._prefix == "scipy" and name == "linalg":
+            return _SubNamespace(self._backend, "scipy.linalg")
         return get_lib_fn(self._backend, f"{self._prefix}.{name}")
 
 

@@ -95,6 +95,17 @@ def test_split_hip_matches_real_quimb(hip, dtype):
     checks.check_split(dtype)
 
 
+def test_decomp_drivers_match_real_quimb(emu):
+    """"qr:cholesky" / "cholesky" / "svd:rand" / "rsvd" (host logic on the plan interpreter) vs the real quimb's drivers."""
+    checks.check_decomp_drivers("float64")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+def test_decomp_drivers_hip_match_real_quimb(hip, dtype):
+    checks.check_decomp_drivers(dtype)
+
+
 def test_circuits_host_logic_match_real_quimb(emu):
     """``Circuit`` (dense state, amplitudes, batched amplitudes) and ``CircuitMPS`` (exact, truncated to chi = 4,
     non-local gates through swaps) reproduce the real quimb's states on the same gate lists."""
