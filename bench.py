@@ -169,9 +169,6 @@ def _launch_work(spec):
     if hasattr(spec, "off_k1") and hasattr(spec, "K1"):  # fused pair of steps (Chain2Spec)
         shape = {"fused_steps": 2, "M": spec.M, "D": spec.D, "K": spec.K1, "N": spec.NO * spec.D}
         return shape, 4 * (spec.a_size + spec.c_size + spec.K1 * spec.D**2 + spec.D**3 * spec.NO), 2 * spec.mults
-    if hasattr(spec, "off_k1"):  # fused triple of steps (Chain3Spec)
-        shape = {"fused_steps": 3, "M": spec.a_size // spec.D**4, "D": spec.D, "K": spec.D**2, "N": spec.D**2}
-        return shape, 4 * (spec.a_size + spec.c_size + 3 * spec.D**4), 2 * spec.mults
     shape = {"B": spec.B, "M": spec.M, "N": spec.N, "K": spec.K}
     return (shape, 4 * spec.B * (spec.M * spec.K + spec.K * spec.N + spec.M * spec.N),
             2 * spec.B * spec.M * spec.N * spec.K)
@@ -499,38 +496,36 @@ def main():
         prog_obj._timing_slot = None
         prof = [rec for k in range(args.steps) for rec in prog_obj.timings(k)]
     if graphed:
-        os.environ["QAMD_SLICE_GRAPH"] = "0"
+        # (per-call arguments of the executor, not process state: slices / the share launch by launch for this one pass)
         if rank == 0:
             dev.profile_min_mults = 10**9
             dev.profile = []
         if mode == "quadrants":
             qrank.executor(xs, strip_exponent=True)      # launch by launch, this rank alone (no collective)
+        elif mode == "sliced":
+            if world > 1:
+                contract_sliced(ex, xs, strip_exponent=True, slice_graph=False)
+            else:
+                ex(xs, strip_exponent=True, slices=my, slice_graph=False)
         else:
             step()
         fence()
         prof, dev.profile = dev.profile, None
-        del os.environ["QAMD_SLICE_GRAPH"]
     # one more UNTIMED launch-by-launch pass with an event pair around EVERY pairwise launch: the per-class roofline
     # table (``roofline.achieved`` per step class).  Kept out of the timed region because an event pair costs
     # each of the ~60 tiny first-row launches ~10 us of queue time.
     prof_all = None
     if rank == 0 and mode in ("single", "quadrants"):
-        # ... and on ONE stream (QAMD_LANES=0): with the four corner sweeps overlapping, an event pair brackets a launch's
-        # share of a contended machine, not the kernel -- the table prices every class with the chip to itself
-        os.environ["QAMD_SLICE_GRAPH"] = "0"
-        os.environ["QAMD_LANES"] = "0"
+        # ... and on ONE stream (``lanes=False``, a per-call argument): with the four corner sweeps overlapping, an event pair
+        # brackets a launch's share of a contended machine, not the kernel -- the table prices every class with the chip to
+        # itself
         dev.profile_min_mults = 0
         dev.profile = []
         try:
-            if mode == "quadrants":
-                qrank.executor(xs, strip_exponent=True)
-            else:
-                ex(xs, strip_exponent=True)
+            (qrank.executor if mode == "quadrants" else ex)(xs, strip_exponent=True, lanes=False, slice_graph=False)
             torch.cuda.synchronize()
         finally:
             prof_all, dev.profile = dev.profile, None
-            del os.environ["QAMD_SLICE_GRAPH"]
-            del os.environ["QAMD_LANES"]
     scaling_report = None
     if mode == "quadrants":
         # what the ranks executed and how evenly: every rank's own time for its share without the collective

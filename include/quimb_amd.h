@@ -74,7 +74,7 @@ typedef struct {
   int32_t dtype;     /* qamd_dtype                                       */
   int32_t nb, nm, nn, nk;
   int32_t conj_a, conj_b; /* complex only                                */
-  int32_t kernel;    /* filled by finalize: 0 tiled GETT, 1 streaming (big x small), 2 streaming with LDS-transposed stores, 4 few-rows x long-vector reduction (split_k slabs of workspace), 5 k-outer MFMA GETT (gemmk.hip: GEMM-shaped joins, fp32, both free bundles stride-1; tile_cfg = 16 ta + tb names the (64 ta) x (64 tb) workgroup tile; env QAMD_GEMMK=0 keeps 0, QAMD_GEMMK_TILE=<ta><tb> pins the tile), 6 fp64 MFMA GETT on an LDS-DMA ring (gemmd.hip: GEMM-shaped fp64 contractions with either operand free- or k-contiguous; tile_cfg = 16 ta + tb names the (32 ta) x (64 tb) workgroup tile, split_k the number of k slabs; env QAMD_GEMMD=0 keeps 0, QAMD_GEMMD_TILE=<ta><tb> pins the tile); set -1 to force 0 */
+  int32_t kernel;    /* filled by finalize: 0 tiled GETT, 1 streaming (big x small), 2 streaming with LDS-transposed stores, 4 few-rows x long-vector reduction (split_k slabs of workspace), 5 k-outer MFMA GETT (gemmk.hip: GEMM-shaped joins, fp32, both free bundles stride-1; tile_cfg = 16 ta + tb names the (64 ta) x (64 tb) workgroup tile; pinned on input with kernel = -5 and tile_cfg = 16 ta + tb), 6 fp64 MFMA GETT on an LDS-DMA ring (gemmd.hip: GEMM-shaped fp64 contractions with either operand free- or k-contiguous; tile_cfg = 16 ta + tb names the (32 ta) x (64 tb) workgroup tile, split_k the number of k slabs; pinned on input with kernel = -6 and tile_cfg = 16 ta + tb).  ON INPUT: 0 automatic, -1 force 0, -2 automatic without kernels 5 / 6, -5 / -6 as above -- the library reads no environment variable, these fields are the only way to steer the choice */
   int64_t dim_b[QAMD_MAX_GROUPS], sa_b[QAMD_MAX_GROUPS], sb_b[QAMD_MAX_GROUPS], sc_b[QAMD_MAX_GROUPS];
   int64_t dim_m[QAMD_MAX_GROUPS], sa_m[QAMD_MAX_GROUPS], sc_m[QAMD_MAX_GROUPS];
   int64_t dim_n[QAMD_MAX_GROUPS], sb_n[QAMD_MAX_GROUPS], sc_n[QAMD_MAX_GROUPS];
@@ -141,10 +141,10 @@ int qamd_contract_pair_ex(const qamd_pair_plan* plan, const void* A, const void*
  * stride D*D and is followed by the contiguous block [x][n2_in]; n2_out at element
  * offset offCo_dev[n2_out].  scale_* / absmax_out: slots as described for the epilogue struct above; any may be NULL.
  *
- * Which kernel runs is decided inside (qamd_chain2_describe names it): chain2q (fp32, D = 6 / 4, innermost m group a
- * multiple of 64, >= 4096 chunks: v_mfma_f32_4x4x1_16b, one wave per SIMD), chain2h (opt-in QAMD_CHAIN2H=1: the same
- * on 32-m half chunks, two waves per SIMD), chain2r (fp32, D <= 6: v_mfma_f32_16x16x4, 16-m chunks) or chain2
- * (LDS tile; fp64, D = 7).  QAMD_CHAIN2Q=0 / QAMD_CHAIN2R=0 step down that list.
+ * Which kernel runs is decided inside, from the plan alone (qamd_chain2_describe names it): chain2q (fp32, D = 6 / 4,
+ * innermost m group a multiple of 64, >= 1024 chunks: v_mfma_f32_4x4x1_16b, one wave per SIMD), chain2r (fp32, D <= 6:
+ * v_mfma_f32_16x16x4, 16-m chunks) or chain2 (LDS tile: fp64, D = 7, results that are not 16-byte aligned).  The
+ * QAMD_CHAIN2_FORCE_* flag bits pin one of them for a shape another would take; no environment variable is read.
  */
 #define QAMD_CHAIN2_C_ALIGNED16 1
 /* row-start shape: k1 is ONE index of size D (offK1_dev has D entries, W1p is [D][D*D]) */
@@ -154,6 +154,10 @@ int qamd_contract_pair_ex(const qamd_pair_plan* plan, const void* A, const void*
 /* W1p / W2p are the ORIGINAL small tensors, addressed with w1_strides (k1 groups outermost first, x, y) and
  * w2_strides (y, v, n2_out, n2_in) in elements -- no packed copies (register kernel only) */
 #define QAMD_CHAIN2_W_STRIDED 8
+/* explicit kernel pins (tests, measurements): the LDS-tile kernel / never the quad kernel / the quad kernel at any size */
+#define QAMD_CHAIN2_FORCE_LDS 16
+#define QAMD_CHAIN2_FORCE_REG 32
+#define QAMD_CHAIN2_FORCE_QUAD 64
 typedef struct {
   int32_t dtype, D, nm;
   int32_t flags;   /* QAMD_CHAIN2_C_ALIGNED16: every offCo_dev entry and every sc_m of the outer m groups is a multiple of 4
@@ -169,38 +173,6 @@ int qamd_chain2_describe(const qamd_chain2_plan* plan, char* buf, int32_t buflen
 int qamd_contract_chain2(const qamd_chain2_plan* plan, const void* A, const void* W1p, const void* W2p, void* C,
                          const void* offK1_dev, const void* offCo_dev, const void* scale_a, const void* scale_1,
                          const void* scale_2, void* absmax_out, void* stream);
-
-/*
- * Fused TRIPLE of streaming contractions (three adjacent interior site absorptions of a boundary
- * sweep, quimb/tensor/tn2d/core.py:1393-1402 three times) -- neither intermediate touches HBM; the
- * chunk state is exchanged through LDS between the stages (chain3.hip):
- *
- *   X1[h1, x, b, c, m] = sum_{h, a}   W1[h, a, h1, x]  * A[(h, a), b, c, m]
- *   X2[h2, y, x, c, m] = sum_{h1, b}  W2[h1, b, h2, y] * X1[h1, x, b, c, m]
- *   C[h3, m, x, y, z]  = sum_{h2, c}  W3[h2, c, h3, z] * X2[h2, y, x, c, m]
- *
- * every index has size D (fp32, D in {2, 4, 6}).  A: element offset of row (h, a) from
- * offK1_dev[h*D + a], b / c at strides sa_b / sa_c, m over the bundle (dim_m, sa_m) with the innermost
- * group stride-1 and a multiple of qamd_chain3_chunk().  W1 / W2 / W3 are the ORIGINAL site tensors,
- * addressed in place with w*_strides = element strides of (bond in, carried index, bond out, new index).
- * C (16-byte aligned): the innermost m group has stride D^3 and is followed by the contiguous block
- * [x][y][z]; h3 at element offset offCo_dev[h3]; every offCo entry and every outer sc_m is a multiple
- * of 4 elements.  scale_* / absmax_out: absmax slots as for the epilogue struct above; any may be NULL.
- */
-typedef struct {
-  int32_t dtype, D, nm, flags;   /* flags: reserved, 0 */
-  int64_t dim_m[QAMD_MAX_GROUPS], sa_m[QAMD_MAX_GROUPS], sc_m[QAMD_MAX_GROUPS];
-  int64_t sa_b, sa_c;
-  int64_t w1_strides[4], w2_strides[4], w3_strides[4];
-} qamd_chain3_plan;
-/* m-chunk the fused triple works in for (dtype, D); 0 = combination not supported */
-int qamd_chain3_chunk(int32_t dtype, int32_t D);
-/* kernel instantiation the fused triple would run (matches rocprofv3's kernel names) */
-int qamd_chain3_describe(const qamd_chain3_plan* plan, char* buf, int32_t buflen);
-int qamd_contract_chain3(const qamd_chain3_plan* plan, const void* A, const void* W1, const void* W2, const void* W3,
-                         void* C, const void* offK1_dev, const void* offCo_dev, const void* scale_a,
-                         const void* scale_1, const void* scale_2, const void* scale_3, void* absmax_out,
-                         void* stream);
 
 /*
  * slots: n_tensors x QAMD_ABSMAX_SLOTS values (float for F32/C64, double
@@ -355,7 +327,7 @@ int qamd_microtree_run(int32_t dtype, const qamd_micro_step* steps_dev, int32_t 
  *                                                        re-based onto input_ptrs[i] at every run)
  *   qamd_program_run(P, lane_streams, input_ptrs, timing);   (lane 0 = the caller's stream: forked from / joined to)
  *
- * Recorded are: qamd_contract_pair(_ex), qamd_contract_pair_dot, qamd_contract_chain2 / chain3, qamd_permute, qamd_reduce_sum, qamd_binary,
+ * Recorded are: qamd_contract_pair(_ex), qamd_contract_pair_dot, qamd_contract_chain2, qamd_permute, qamd_reduce_sum, qamd_binary,
  * qamd_scale, qamd_axpby(_exp), qamd_conj, qamd_cast, qamd_fill, qamd_complex_expand, qamd_strip_exponent,
  * qamd_absmax_log10_sum(_add), qamd_div_by_absmax, qamd_unary, qamd_minmax, qamd_absmax.  Plan compilation
  * (qamd_pair_build_ktab) and qamd_microtree_run execute immediately.  Every buffer a recorded call names -- other

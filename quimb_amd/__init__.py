@@ -26,6 +26,8 @@ from .contract import (  # noqa: F401
     set_tensor_linop_backend, tensor_contract, tensor_linop_backend,
 )
 from .executor import TreeExecutor
+from .options import Options, get_options, set_options
+from .options import options as exec_options
 from .linop import TNLinearOperator
 from .eigsolve import eigh_lanczos
 from .microtree import MicroTree

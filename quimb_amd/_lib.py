@@ -52,17 +52,6 @@ class Chain2PlanStruct(C.Structure):
     ]
 
 
-class Chain3PlanStruct(C.Structure):
-    """Mirror of ``qamd_chain3_plan``."""
-
-    _fields_ = [
-        ("dtype", C.c_int32), ("D", C.c_int32), ("nm", C.c_int32), ("flags", C.c_int32),
-        ("dim_m", _I64G), ("sa_m", _I64G), ("sc_m", _I64G),
-        ("sa_b", C.c_int64), ("sa_c", C.c_int64),
-        ("w1_strides", C.c_int64 * 4), ("w2_strides", C.c_int64 * 4), ("w3_strides", C.c_int64 * 4),
-    ]
-
-
 class Epilogue(C.Structure):
     """Mirror of ``qamd_epilogue``."""
 
@@ -88,9 +77,6 @@ SYMBOLS = [
     ("qamd_chain2_chunk", C.c_int, [_i32, _i32]),
     ("qamd_chain2_describe", C.c_int, [C.POINTER(Chain2PlanStruct), C.c_char_p, _i32]),
     ("qamd_contract_chain2", C.c_int, [C.POINTER(Chain2PlanStruct), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
-    ("qamd_chain3_chunk", C.c_int, [_i32, _i32]),
-    ("qamd_chain3_describe", C.c_int, [C.POINTER(Chain3PlanStruct), C.c_char_p, _i32]),
-    ("qamd_contract_chain3", C.c_int, [C.POINTER(Chain3PlanStruct)] + [_vp] * 13),
     ("qamd_absmax_log10_sum", C.c_int, [_vp, _i64, _i32, _vp, _vp]),
     ("qamd_div_by_absmax", C.c_int, [_vp, _i64, _vp, _i32, _vp]),
     ("qamd_permute", C.c_int, [_vp, _vp, _i32, _pi64, _pi64, _i64, _i32, _vp]),

@@ -23,6 +23,7 @@ import numpy as np
 
 from .array import Array, asarray
 from .executor import TreeExecutor
+from .options import get_options
 from .ops import einsum_pair
 from .pairwise import prod
 from .pathfind import find_path, find_slices
@@ -141,22 +142,24 @@ _PROGRAM_POOL = [0]          # bytes of device memory held by the launch program
 class ContractExpression:
     """Callable ``expr(*arrays, backend=None)`` bound to one tree + dtype."""
 
-    def __init__(self, tree, dtype, strip_exponent=False, constants=None):
+    def __init__(self, tree, dtype, strip_exponent=False, constants=None, options=None):
+        #: resolved once, here (quimb_amd/options.py): an expression never consults the environment
+        self.options = options if options is not None else get_options()
         self.strip_exponent = strip_exponent
         self.constants = dict(constants or {})
         self._const_dev = {k: asarray(v).astype(dtype) for k, v in self.constants.items()}
         self._ninputs = len(tree.inputs)
         self._program, self._ncalls = None, 0      # launch program of repeated calls (``_auto_program``)
         self._order = None          # position in the caller's input list -> position in the executed tree's
-        if self._const_dev and not strip_exponent and tree.nslices == 1 and os.environ.get("QAMD_FOLD_CONSTANTS", "1") != "0":
+        if self._const_dev and not strip_exponent and tree.nslices == 1 and self.options.fold_constants:
             tree = self._fold_constants(tree, dtype)
         self.tree = tree
-        self.executor = TreeExecutor(tree, dtype)
+        self.executor = TreeExecutor(tree, dtype, options=self.options)
         # trees of many small tensors (circuit amplitudes) are dispatch-bound step by step: let the device walk
-        # them in one launch (MicroTree) -- same plan, same arithmetic order per step; QAMD_MICROTREE=0 opts out
+        # them in one launch (MicroTree) -- same plan, same arithmetic order per step; options.microtree = False opts out
         self._micro = None
         if (not strip_exponent and tree.nslices == 1 and len(tree.steps) >= _MICRO_MIN_STEPS
-                and os.environ.get("QAMD_MICROTREE", "1") != "0"):
+                and self.options.microtree):
             try:
                 from .microtree import MicroTree
 
@@ -170,7 +173,7 @@ class ContractExpression:
         quimb/tensor/tensor_core.py:12378-12381): the product of two MPO tensors of a DMRG effective Hamiltonian is
         not recomputed per matvec.  Returns the reduced tree; ``self._const_dev`` / ``self._order`` are re-keyed to
         its inputs."""
-        if os.environ.get("QAMD_REGROUP", "1") != "0":
+        if self.options.regroup:
             tree = tree.regrouped()            # (the executor would do this anyway: it can create constant-only products)
         n = len(tree.inputs)
         const = set(self._const_dev)
@@ -235,8 +238,8 @@ class ContractExpression:
         ~15 us of host time per launch.  From the THIRD call with device-resident arrays on, an unsliced expression is
         recorded once as a launch program (quimb_amd/program.py) and every later call is one C call that replays it on the
         caller's arrays, read in place.  Returns the program or None (not eligible / recording refused: then never again).
-        ``QAMD_AUTO_PROGRAM=0`` opts out; ``QAMD_AUTO_PROGRAM_MAX_BYTES`` (default 4 GiB) bounds the intermediates one
-        program may keep allocated, ``QAMD_AUTO_PROGRAM_TOTAL_BYTES`` (16 GiB) those of all live expressions together."""
+        ``options.auto_program = False`` opts out; ``options.auto_program_max_bytes`` (default 4 GiB) bounds the intermediates
+        one program may keep allocated, ``auto_program_total_bytes`` (16 GiB) those of all live expressions together."""
         prog = self._program
         if prog is not None or prog is False:
             return prog or None
@@ -245,7 +248,7 @@ class ContractExpression:
             return None
         self._program = False
         ex = self.executor
-        if (os.environ.get("QAMD_AUTO_PROGRAM", "1") == "0" or self.tree.nslices != 1 or len(ex.plan) < 4
+        if (not self.options.auto_program or self.tree.nslices != 1 or len(ex.plan) < 4
                 or not all(isinstance(a, Array) for a in arrays)):
             return None
         dev = arrays[0]._dev
@@ -253,15 +256,15 @@ class ContractExpression:
                 or dev.is_capturing():
             self._program = None if getattr(dev, "record", None) is not None else False      # (busy: try again later)
             return None
-        limit = int(os.environ.get("QAMD_AUTO_PROGRAM_MAX_BYTES", str(4 << 30)))
-        budget = int(os.environ.get("QAMD_AUTO_PROGRAM_TOTAL_BYTES", str(16 << 30)))
+        limit = int(self.options.auto_program_max_bytes)
+        budget = int(self.options.auto_program_total_bytes)
         if sum(inf.bytes for inf in ex.info) > min(limit, budget - _PROGRAM_POOL[0]):
             return None                    # (a program keeps its intermediates allocated: all programs together stay bounded)
         try:
             prog = ex.program(list(arrays), strip_exponent=self.strip_exponent)
             prog.forget_inputs()
         except Exception as err:
-            if os.environ.get("QAMD_DEBUG"):
+            if self.options.debug:
                 import sys
 
                 print(f"[quimb_amd] launch program refused for an expression of {len(ex.plan)} launches: "
@@ -326,7 +329,7 @@ def array_contract_expression(
             okey = optimize if isinstance(optimize, str) else ("obj", optimize)
             hash(okey)
             key = (inputs, output, tuple(sorted(size_dict.items(), key=repr)), okey, np.dtype(dtype).name,
-                   bool(strip_exponent), repr(slicing))
+                   bool(strip_exponent), repr(slicing), get_options())      # (the options an expression is built with)
             hit = _EXPR_CACHE.get(key)
             if hit is not None:
                 return hit

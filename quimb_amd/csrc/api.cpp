@@ -141,10 +141,10 @@ static double gemmk_model(int64_t M, int64_t N, int64_t B, int ta, int tb, int64
   return (double)rounds * ta * tb / eff[ta * tb];
 }
 
+// ``pin``: 0 = the model's tile, else 10 ta + tb (a caller's explicit pin: qamd_pair_plan.kernel = -5 with tile_cfg = 16 ta + tb
+// on input; the grid-size floor is waived for a pinned tile)
 static bool gemmk_config(const qamd_pair_plan* p, const PairDims& d, int64_t align_a, int64_t align_b, int64_t align_c,
-                         int& ta, int& tb) {
-  const char* e = getenv("QAMD_GEMMK");
-  if (e && atoi(e) == 0) return false;
+                         int pin, int& ta, int& tb) {
   if (p->dtype != QAMD_F32 || p->nk != 1 || p->a_kcontig || p->b_kcontig || p->vec_a < 4 || p->vec_b < 4) return false;
   if (d.K % 8 || d.K < 64 || d.M < 128 || d.N < 128 || d.M % 4 || d.N % 4) return false;
   if ((align_a % 16) || (align_b % 16) || (align_c % 4)) return false;
@@ -155,12 +155,11 @@ static bool gemmk_config(const qamd_pair_plan* p, const PairDims& d, int64_t ali
     if (p->sa_b[i] % 4 || p->sb_b[i] % 4) return false;
   const bool swap = !p->c_ncontig;
   const int64_t M = swap ? d.N : d.M, N = swap ? d.M : d.N;
-  const char* te = getenv("QAMD_GEMMK_TILE");   // e.g. 43: pin (ta, tb)
   double best = 0;
   ta = tb = 0;
   for (int a = 2; a <= 4; ++a)
     for (int b = 2; b <= 4; ++b) {
-      if (te && atoi(te) != 10 * a + b) continue;
+      if (pin && pin != 10 * a + b) continue;
       int64_t tiles = 0;
       const double t = gemmk_model(M, N, d.B, a, b, &tiles);
       if (!ta || t < best) { best = t; ta = a; tb = b; }
@@ -169,7 +168,7 @@ static bool gemmk_config(const qamd_pair_plan* p, const PairDims& d, int64_t ali
   int64_t tiles = 0;
   gemmk_model(M, N, d.B, ta, tb, &tiles);
   // under-filled grids keep the split-K kernels
-  return tiles >= 96 || (te != nullptr);
+  return tiles >= 96 || pin != 0;
 }
 
 // ---- gemmd.hip eligibility and tile choice (fp64, LDS-DMA ring, either operand layout) -----------------------------
@@ -228,12 +227,12 @@ static void gemmd_order_for_stores(qamd_pair_plan* p) {
   p->c_ncontig = (n1 || !m1) ? 1 : 0;
 }
 
-static bool gemmd_config(const qamd_pair_plan* p, const PairDims& d, int64_t align_a, int64_t align_b, int& ta, int& tb,
-                         int& split) {
-  const char* e = getenv("QAMD_GEMMD");
-  if (e && atoi(e) == 0) return false;
+// ``pin``: 0 = the model's tile, else 10 ta + tb (qamd_pair_plan.kernel = -6 with tile_cfg = 16 ta + tb on input) -- and take
+// every shape the kernel can run
+static bool gemmd_config(const qamd_pair_plan* p, const PairDims& d, int64_t align_a, int64_t align_b, int pin, int& ta,
+                         int& tb, int& split) {
   if (p->dtype != QAMD_F64) return false;
-  const char* te = getenv("QAMD_GEMMD_TILE");   // e.g. 54: pin (ta, tb) -- and take every shape the kernel can run
+  const bool te = pin != 0;
   if (d.K % 16 || d.K < (te ? 16 : 64) || d.M < (te ? 2 : 64) || d.N < (te ? 2 : 64) || d.M % 2 || d.N % 2) return false;
   if (p->nk < 1 || p->dim_k[p->nk - 1] % 16) return false;     // a k-tile (16 rows) stays inside the innermost K group
   if ((align_a % 16) || (align_b % 16)) return false;
@@ -246,7 +245,7 @@ static bool gemmd_config(const qamd_pair_plan* p, const PairDims& d, int64_t ali
   split = 1;
   for (int a = 2; a <= 5; ++a)
     for (int b = 1; b <= 2; ++b) {
-      if (te && atoi(te) != 10 * a + b) continue;
+      if (pin && pin != 10 * a + b) continue;
       for (int s = 1; s <= 16; s *= 2) {
         if (s > 1 && (!compact || d.K / 16 / s < 8)) break;
         const double t = gemmd_model(d.M, d.N, d.K, d.B, a, b, s);
@@ -255,13 +254,27 @@ static bool gemmd_config(const qamd_pair_plan* p, const PairDims& d, int64_t ali
     }
   if (!ta) return false;
   const int64_t tiles = ((d.M + 32 * ta - 1) / (32 * ta)) * ((d.N + 64 * tb - 1) / (64 * tb)) * d.B * split;
-  return tiles >= 64 || te != nullptr;       // tiny grids keep the generic kernels
+  return tiles >= 64 || te;       // tiny grids keep the generic kernels
 }
 
 extern "C" int qamd_pair_plan_finalize(qamd_pair_plan* p, int64_t align_a, int64_t align_b, int64_t align_c) {
   PairDims d;
   int rc = pair_dims(p, d);
   if (rc) return rc;
+  // the caller's explicit pins (the ONLY way to steer the choice: nothing below reads the environment):
+  //   kernel  0 auto | -1 tiled GETT | -2 auto without the MFMA GEMM kernels | -5 / -6 gemmk / gemmd with the tile named by
+  //   tile_cfg = 16 ta + tb (where the kernel can run the shape at all; otherwise the automatic choice)
+  const int pin_kernel = p->kernel;
+  int pin_gemm = 0;
+  if (pin_kernel == -5 || pin_kernel == -6) {
+    if (p->tile_cfg > 0) pin_gemm = 10 * (p->tile_cfg / 16) + p->tile_cfg % 16;
+    p->tile_cfg = -1;
+    p->kernel = 0;
+  } else if (pin_kernel == -2) {
+    p->kernel = 0;
+  } else if (pin_kernel < -1 || pin_kernel > 0) {
+    p->kernel = 0;      // (a finalized plan handed in again: its output codes are not pins)
+  }
   if (p->dtype != QAMD_F32 && p->dtype != QAMD_F64) return QAMD_EUNSUPPORTED;
   const int es = kEsize[p->dtype];
 
@@ -346,9 +359,9 @@ extern "C" int qamd_pair_plan_finalize(qamd_pair_plan* p, int64_t align_a, int64
     if (p->kernel == -1) p->kernel = 0;  // caller forces the tiled kernel
     else p->kernel = kern;
     // kernel 5 (gemmk.hip): GEMM-shaped, both operands "k-outer" (free bundle stride-1), fp32
-    if (p->kernel == 0 && kern == 0 && p->tile_cfg < 0) {
+    if (p->kernel == 0 && kern == 0 && p->tile_cfg < 0 && pin_kernel != -2) {
       int ta = 0, tb = 0;
-      if (gemmk_config(p, d, align_a, align_b, align_c, ta, tb)) {
+      if (pin_kernel != -6 && gemmk_config(p, d, align_a, align_b, align_c, pin_kernel == -5 ? pin_gemm : 0, ta, tb)) {
         p->kernel = 5;
         p->tile_cfg = 16 * ta + tb;
         p->split_k = 1;
@@ -356,7 +369,7 @@ extern "C" int qamd_pair_plan_finalize(qamd_pair_plan* p, int64_t align_a, int64
       }
       // kernel 6 (gemmd.hip): fp64, GEMM-shaped, either operand layout
       int split = 1;
-      if (gemmd_config(p, d, align_a, align_b, ta, tb, split)) {
+      if (pin_kernel != -5 && gemmd_config(p, d, align_a, align_b, pin_kernel == -6 ? pin_gemm : 0, ta, tb, split)) {
         gemmd_order_for_stores(p);
         p->kernel = 6;
         p->tile_cfg = 16 * ta + tb;
@@ -383,10 +396,9 @@ extern "C" int qamd_pair_plan_finalize(qamd_pair_plan* p, int64_t align_a, int64
       // measured (profiles/r01_microbench.txt): the 64x64 tile (more workgroups in flight)
       // beats 128x128x16 and 128x128x32 at every size from 1024^3 to 8192^3, f32 and f64;
       // the compile-time 128x128 kernel (gettf.hip) beats both wherever its preconditions hold
-      const char* fe = getenv("QAMD_FAST_TILE");   // 0 disables the fast path, 6 / 7 pin a shape
-      const int want = fe ? atoi(fe) : -1;
+      const int want = -1;     // (a caller pins a shape with tile_cfg = 6 / 7 on input, or 1 to keep the 64 x 64 tile)
       cfg = 1;
-      if (want != 0) {
+      {
         // 128x128 once it fills the chip twice over, else 128x64 (more workgroups, split-K on top if needed)
         const bool big = (d.M / 128) * (d.N / 128) * d.B >= 2 * kNumCU;
         if ((want == kFastCfg || (want < 0 && big)) && fast_tile_ok(p, d, kFastCfg)) cfg = kFastCfg;
@@ -471,7 +483,7 @@ static bool sweep_config(const qamd_pair_plan* p, const StreamArgs& s, int V, in
   const int ev = 16 / es;
   int64_t kmax = 0;
   for (int i = 0; i < p->nk; ++i) kmax += (p->dim_k[i] - 1) * p->sa_k[i];
-  if (!(s.aligned && V == ev && s.KS <= 9 && (kmax + 16 * ev) * es < (1ll << 32)) || getenv("QAMD_NO_SWEEP"))
+  if (!(s.aligned && V == ev && s.KS <= 9 && (kmax + 16 * ev) * es < (1ll << 32)))
     return false;
   static const int kPS[6] = {1, 2, 3, 4, 6, 9};
   PS = 9;
@@ -901,10 +913,9 @@ extern "C" int qamd_permute(void* dst, const void* src, int32_t ndim, const int6
   if (d.empty()) d.push_back(Dim{1, 1, 1});
   const int n = (int)d.size();
   {
-    // the z-looping, offset-caching kernel first (QAMD_PERMUTE_STREAM=0 keeps the tile-per-workgroup one)
-    const char* e = getenv("QAMD_PERMUTE_STREAM");
+    // the z-looping, offset-caching kernel first; the tile-per-workgroup one takes what it cannot address
     PermArgs ps;
-    if (!(e && e[0] == '0') && plan_permute_stream(d, src_offset, kEsize[dtype] == 16 ? 2048 : 4096, ps)) {
+    if (plan_permute_stream(d, src_offset, kEsize[dtype] == 16 ? 2048 : 4096, ps)) {
       int rc = qamd_permute_stream_launch(kEsize[dtype], dst, src, &ps, stream);
       if (rc != -2) return rc;
     }
@@ -1062,45 +1073,30 @@ extern "C" int qamd_pair_describe(const qamd_pair_plan* p, char* buf, int32_t bu
 // ---------------------------------------------------------------------------
 // fused pair of streaming contractions
 // ---------------------------------------------------------------------------
-// the register-resident variant (chain2r.hip) serves fp32 D <= 6 at the 16-m chunk;
-// QAMD_CHAIN2R=0 keeps the LDS-tile kernel (chain2.hip)
+// the register-resident variant (chain2r.hip) serves fp32 D <= 6 at the 16-m chunk; the LDS-tile kernel (chain2.hip)
+// everything else the fused pair covers: fp64, D = 7, results that are not 16-byte aligned.  QAMD_CHAIN2_FORCE_LDS in
+// the plan's flags keeps the LDS-tile kernel for a shape the register kernels would take (tests, measurements)
 static bool chain2_uses_registers(const qamd_chain2_plan* p, const void* C) {
-  const char* e = getenv("QAMD_CHAIN2R");
-  if (e && e[0] == '0') return false;
+  if (p->flags & QAMD_CHAIN2_FORCE_LDS) return false;
   if (!(p->flags & QAMD_CHAIN2_C_ALIGNED16) || ((uintptr_t)C & 15)) return false;   // 16-byte stores
   return qamd_chain2r_supported(p->dtype, p->D) && qamd_chain2_chunk(p->dtype, p->D) == 16;
 }
 
 // the 4x4x1 multi-block variant (chain2q.hip): fp32, D in {4, 6}, innermost m group a whole number of 64-m chunks,
-// and at least one chunk for every wave of the persistent grid (QAMD_CHAIN2Q=0 off, =2 no size threshold).  The bar was
-// four chunks per wave until round 4: the range-sliced last rows of a rank of 4 / 8 (M = 139968 / 69984: 2187 / 1093
-// chunks) sat on chain2r below it, and chain2q runs them faster (a rank's step 5.27 -> 5.04 ms / 3.46 -> 3.35 ms)
+// and at least one chunk for every wave of the persistent grid (flags: QAMD_CHAIN2_FORCE_REG never, QAMD_CHAIN2_FORCE_QUAD
+// at any size).  The bar was four chunks per wave until round 4: the range-sliced last rows of a rank of 4 / 8
+// (M = 139968 / 69984: 2187 / 1093 chunks) sat on chain2r below it, and chain2q runs them faster
 static bool chain2_uses_quad(const qamd_chain2_plan* p, const void* C) {
-  const char* e = getenv("QAMD_CHAIN2Q");
-  if (e && e[0] == '0') return false;
+  if (p->flags & QAMD_CHAIN2_FORCE_REG) return false;
   if (!chain2_uses_registers(p, C) || !qamd_chain2q_supported(p->dtype, p->D)) return false;
   if (p->nm < 1 || p->dim_m[p->nm - 1] % 64) return false;
   int64_t M = 1;
   for (int i = 0; i < p->nm; ++i) M *= p->dim_m[i];
-  return (e && e[0] == '2') || M / 64 >= 1024;
-}
-
-// the two-waves-per-SIMD variant of it (chain2h.hip: 32-m chunks, v pairs / x pairs in the lane halves): opt-in
-// with QAMD_CHAIN2H=1 while it is being measured against chain2q
-static bool chain2_uses_half(const qamd_chain2_plan* p, const void* C) {
-  const char* e = getenv("QAMD_CHAIN2H");
-  if (!(e && e[0] == '1')) return false;
-  if (!chain2_uses_registers(p, C) || !qamd_chain2h_supported(p->dtype, p->D)) return false;
-  if (p->nm < 1 || p->dim_m[p->nm - 1] % 32) return false;
-  int64_t M = 1;
-  for (int i = 0; i < p->nm; ++i) M *= p->dim_m[i];
-  const char* q = getenv("QAMD_CHAIN2Q");
-  return (q && q[0] == '2') || M / 32 >= 8192;
+  return (p->flags & QAMD_CHAIN2_FORCE_QUAD) || M / 64 >= 1024;
 }
 
 // chunks per workgroup of the fused-pair kernels: the largest divisor of the innermost m group's chunk count
-// that still leaves ~12 workgroups per CU; ``sc``: the opt-in super-chunk variant (QAMD_C2R_SC=1: pairs of
-// adjacent chunks per wave, whole-line loads -- measured equal to the default, 0.762 vs 0.764 ms per pair)
+// that still leaves ~12 workgroups per CU (``sc``: the retired super-chunk variant, always false)
 static bool chain2_geometry(const qamd_chain2_plan* p, int ch, bool registers, uint32_t& chunks, uint32_t& cpb, bool& sc) {
   int64_t M = 1;
   for (int i = 0; i < p->nm; ++i) M *= p->dim_m[i];
@@ -1120,11 +1116,8 @@ static bool chain2_geometry(const qamd_chain2_plan* p, int ch, bool registers, u
   if (best < 1) return false;
   cpb = best;
   sc = false;
-  const char* e = getenv("QAMD_C2R_SC");
-  if (best_even >= 2 && e && e[0] == '1' && registers) {
-    cpb = best_even;
-    sc = true;
-  }
+  (void)best_even;
+  (void)registers;
   return true;
 }
 
@@ -1134,11 +1127,6 @@ extern "C" int qamd_chain2_describe(const qamd_chain2_plan* p, char* buf, int32_
   if (!ch) return QAMD_EUNSUPPORTED;
   const bool variant = (p->flags & (QAMD_CHAIN2_K1_SINGLE | QAMD_CHAIN2_NO_N2OUT)) != 0;
   if (variant && !chain2_uses_registers(p, nullptr)) return QAMD_EUNSUPPORTED;
-  if (chain2_uses_half(p, nullptr)) {
-    snprintf(buf, buflen, "chain2h_kernel<%d, %d, %d>", p->D, (p->flags & QAMD_CHAIN2_K1_SINGLE) ? 1 : 2,
-             (p->flags & QAMD_CHAIN2_NO_N2OUT) ? 0 : 1);
-    return QAMD_OK;
-  }
   if (chain2_uses_quad(p, nullptr)) {
     snprintf(buf, buflen, "chain2q_kernel<%d, %d, %d>", p->D, (p->flags & QAMD_CHAIN2_K1_SINGLE) ? 1 : 2,
              (p->flags & QAMD_CHAIN2_NO_N2OUT) ? 0 : 1);
@@ -1185,7 +1173,6 @@ extern "C" int qamd_contract_chain2(const qamd_chain2_plan* p, const void* A, co
     a.sc = sc ? 1 : 0;
   }
   a.grid = a.chunks / a.chunks_per_block;
-  if (const char* e = getenv("QAMD_CHAIN2_ABLATE")) a.ablate = (uint32_t)atoi(e);
   const int k1_single = (p->flags & QAMD_CHAIN2_K1_SINGLE) ? 1 : 0, no_n2out = (p->flags & QAMD_CHAIN2_NO_N2OUT) ? 1 : 0;
   if (k1_single && no_n2out) return QAMD_EUNSUPPORTED;
   if (p->flags & QAMD_CHAIN2_W_STRIDED) {
@@ -1195,13 +1182,6 @@ extern "C" int qamd_contract_chain2(const qamd_chain2_plan* p, const void* A, co
     const int64_t N2 = (no_n2out ? 1 : p->D) * (int64_t)p->D;
     a.w1s[0] = k1_single ? DD : (int64_t)p->D * DD; a.w1s[1] = DD; a.w1s[2] = p->D; a.w1s[3] = 1;
     a.w2s[0] = (int64_t)p->D * N2; a.w2s[1] = N2; a.w2s[2] = p->D; a.w2s[3] = 1;
-  }
-  if (chain2_uses_half(p, C)) {
-    a.chunks = (uint32_t)(M / 32);
-    a.chunks_per_block = 0;
-    a.grid = std::min<uint32_t>((a.chunks + 7) / 8, 256);   // persistent: one workgroup (8 waves, 2 per SIMD) per CU
-    return qamd_chain2h_launch(p->D, k1_single, no_n2out, &a, A, W1p, W2p, C, offK1_dev, offCo_dev, scale_a, scale_1,
-                               scale_2, absmax_out, stream);
   }
   if (chain2_uses_quad(p, C)) {
     a.chunks = (uint32_t)(M / 64);
@@ -1216,72 +1196,6 @@ extern "C" int qamd_contract_chain2(const qamd_chain2_plan* p, const void* A, co
   if (k1_single || no_n2out) return QAMD_EUNSUPPORTED;   // the row-start / row-end shapes exist in chain2r only
   return qamd_chain2_launch(p->dtype, p->D, &a, A, W1p, W2p, C, offK1_dev, offCo_dev, scale_a, scale_1, scale_2,
                             absmax_out, stream);
-}
-
-// ---------------------------------------------------------------------------
-// fused triple of streaming contractions (chain3.hip)
-// ---------------------------------------------------------------------------
-extern "C" int qamd_chain3_chunk(int32_t dtype, int32_t D) { return qamd_chain3_supported(dtype, D) ? 16 : 0; }
-
-// waves per workgroup of the triple kernel (QAMD_C3_NW = 4 | 8 | 12; one workgroup per CU)
-static int chain3_waves() {
-  const char* e = getenv("QAMD_C3_NW");
-  const int nw = e ? atoi(e) : 8;
-  return (nw == 4 || nw == 12) ? nw : 8;
-}
-
-static int chain3_check(const qamd_chain3_plan* p, int64_t& chunks) {
-  if (!p || p->nm < 1 || p->nm > QAMD_MAX_GROUPS) return QAMD_EINVAL;
-  if (!qamd_chain3_chunk(p->dtype, p->D)) return QAMD_EUNSUPPORTED;
-  const int64_t D3 = (int64_t)p->D * p->D * p->D;
-  int64_t M = 1;
-  for (int i = 0; i < p->nm; ++i) {
-    if (p->dim_m[i] <= 0) return QAMD_EINVAL;
-    M *= p->dim_m[i];
-    if (M >= (1ll << 31)) return QAMD_EUNSUPPORTED;
-    if (i < p->nm - 1 && (p->sc_m[i] & 3)) return QAMD_EUNSUPPORTED;   // 16-byte stores
-  }
-  const int64_t inner = p->dim_m[p->nm - 1];
-  if (p->sa_m[p->nm - 1] != 1 || p->sc_m[p->nm - 1] != D3 || inner % 16) return QAMD_EUNSUPPORTED;
-  chunks = M / 16;
-  return QAMD_OK;
-}
-
-extern "C" int qamd_chain3_describe(const qamd_chain3_plan* p, char* buf, int32_t buflen) {
-  int64_t chunks = 0;
-  if (!buf || buflen <= 0) return QAMD_EINVAL;
-  int rc = chain3_check(p, chunks);
-  if (rc) return rc;
-  snprintf(buf, buflen, "chain3_kernel<%d, %d>", p->D, chain3_waves());
-  return QAMD_OK;
-}
-
-extern "C" int qamd_contract_chain3(const qamd_chain3_plan* p, const void* A, const void* W1, const void* W2,
-                                    const void* W3, void* C, const void* offK1_dev, const void* offCo_dev,
-                                    const void* scale_a, const void* scale_1, const void* scale_2, const void* scale_3,
-                                    void* absmax_out, void* stream) {
-  if (qamdp_recording()) return qamdp_rec_chain3(p, A, W1, W2, W3, C, offK1_dev, offCo_dev, scale_a, scale_1, scale_2, scale_3, absmax_out);
-  if (!p || !A || !W1 || !W2 || !W3 || !C || !offK1_dev || !offCo_dev) return QAMD_EINVAL;
-  int64_t chunks = 0;
-  int rc = chain3_check(p, chunks);
-  if (rc) return rc;
-  if ((uintptr_t)C & 15) return QAMD_EUNSUPPORTED;
-  Chain3Args a;
-  memset(&a, 0, sizeof(a));
-  a.nm = p->nm;
-  for (int i = 0; i < p->nm; ++i) { a.dim_m[i] = (uint32_t)p->dim_m[i]; a.sa_m[i] = p->sa_m[i]; a.sc_m[i] = p->sc_m[i]; }
-  a.sa_b = p->sa_b;
-  a.sa_c = p->sa_c;
-  a.chunks = (uint32_t)chunks;
-  // one workgroup per CU (the chunk state takes 83 of the CU's 160 KB of LDS at D = 6), persistent over its chunks;
-  // QAMD_C3_GRID overrides the workgroup count (experiments)
-  int grid = 256;
-  if (const char* e = getenv("QAMD_C3_GRID")) grid = std::max(1, atoi(e));
-  a.grid = (uint32_t)std::min<int64_t>(grid, chunks);
-  for (int i = 0; i < 4; ++i) { a.w1s[i] = p->w1_strides[i]; a.w2s[i] = p->w2_strides[i]; a.w3s[i] = p->w3_strides[i]; }
-  rc = qamd_chain3_launch(p->D, chain3_waves(), &a, A, W1, W2, W3, C, offK1_dev, offCo_dev, scale_a, scale_1, scale_2,
-                          scale_3, absmax_out, stream);
-  return rc == 0 ? QAMD_OK : (rc == -2 ? QAMD_EUNSUPPORTED : QAMD_ELAUNCH);
 }
 
 // ---------------------------------------------------------------------------

@@ -363,9 +363,7 @@ static int launch_chain2_t(int D, int V, const Chain2Args& a, const void* A, con
 // chunk size the kernel uses for (dtype, D); 0 = unsupported
 extern "C" int qamd_chain2_chunk(int dtype, int D) {
   // 16-element chunks keep the LDS footprint at two workgroups per CU, which measured faster
-  // than 32 (0.94 vs 1.10 ms per 6^9 pair); QAMD_CHAIN2_V2=1 selects the 32-element variant.
-  if (dtype == 0 && getenv("QAMD_CHAIN2_V2") && getenv("QAMD_CHAIN2_V2")[0] == '1')
-    return (D >= 2 && D <= 6) ? 32 : (D == 7 ? 16 : 0);
+  // than 32 (0.94 vs 1.10 ms per 6^9 pair)
   if (dtype == 0) return (D >= 2 && D <= 7) ? 16 : 0;
   if (dtype == 1) return (D >= 2 && D <= 6) ? 16 : 0;
   return 0;

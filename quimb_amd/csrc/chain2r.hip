@@ -463,11 +463,7 @@ extern "C" int qamd_chain2r_launch(int D, int k1_single, int no_n2out, const Cha
   if (k1_single && no_n2out) return -2;
 #define QAMD_C2R(DD)                                                                                                 \
   case DD:                                                                                                           \
-    if (a->sc) {                                                                                                       \
-      if (k1_single) return launch_chain2r_d<DD, 1, 1, true>(*a, A, W1p, W2p, C, offK1, offCo, scale_a, scale_1, scale_2, absmax_out, st); \
-      if (no_n2out) return launch_chain2r_d<DD, 2, 0, true>(*a, A, W1p, W2p, C, offK1, offCo, scale_a, scale_1, scale_2, absmax_out, st);  \
-      return launch_chain2r_d<DD, 2, 1, true>(*a, A, W1p, W2p, C, offK1, offCo, scale_a, scale_1, scale_2, absmax_out, st);                \
-    }                                                                                                                  \
+    if (a->sc) return -2;   /* the super-chunk variant (measured equal to the default) is no longer instantiated */     \
     if (k1_single) return launch_chain2r_d<DD, 1, 1, false>(*a, A, W1p, W2p, C, offK1, offCo, scale_a, scale_1, scale_2, absmax_out, st); \
     if (no_n2out) return launch_chain2r_d<DD, 2, 0, false>(*a, A, W1p, W2p, C, offK1, offCo, scale_a, scale_1, scale_2, absmax_out, st);  \
     return launch_chain2r_d<DD, 2, 1, false>(*a, A, W1p, W2p, C, offK1, offCo, scale_a, scale_1, scale_2, absmax_out, st);

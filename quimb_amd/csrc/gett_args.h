@@ -61,18 +61,6 @@ struct Chain2Args {
   uint32_t ablate;  // debug/ablation bits (QAMD_CHAIN2_ABLATE): 1 no stores, 2 no stage-1 scatter, 4 no loads, 8 no stage 2
 };
 
-// fused triple of streaming contractions through an LDS-resident chunk state (chain3.hip)
-struct Chain3Args {
-  int32_t nm;
-  uint32_t dim_m[QAMD_G];
-  int64_t sa_m[QAMD_G], sc_m[QAMD_G];
-  int64_t sa_b, sa_c;   // A strides of the carried indices b (contracted in stage 2) and c (stage 3)
-  uint32_t chunks, grid;
-  int64_t w1s[4];       // W1 element strides of (h, a, h1, x)
-  int64_t w2s[4];       // W2 element strides of (h1, b, h2, y)
-  int64_t w3s[4];       // W3 element strides of (h2, c, h3, z)
-};
-
 // few rows x one long vector (dotm.hip)
 struct DotArgs {
   int32_t S;            // rows (<= 32)
@@ -118,14 +106,6 @@ int qamd_chain2q_supported(int dtype, int D);
 int qamd_chain2q_launch(int D, int k1_single, int no_n2out, const Chain2Args* a, const void* A, const void* W1p,
                         const void* W2p, void* C, const void* offK1, const void* offCo, const void* scale_a,
                         const void* scale_1, const void* scale_2, void* absmax_out, void* stream);
-int qamd_chain2h_supported(int dtype, int D);
-int qamd_chain2h_launch(int D, int k1_single, int no_n2out, const Chain2Args* a, const void* A, const void* W1p,
-                        const void* W2p, void* C, const void* offK1, const void* offCo, const void* scale_a,
-                        const void* scale_1, const void* scale_2, void* absmax_out, void* stream);
-int qamd_chain3_supported(int dtype, int D);
-int qamd_chain3_launch(int D, int nw, const Chain3Args* a, const void* A, const void* W1p, const void* W2p,
-                       const void* W3p, void* C, const void* offK1, const void* offCo, const void* scale_a,
-                       const void* scale_1, const void* scale_2, const void* scale_3, void* absmax_out, void* stream);
 void qamd_gett_tile_dims(int cfg, int* bm, int* bn, int* bk);
 int qamd_splitk_reduce_launch(int dtype, void* C, const void* ws, int64_t n, int split_k,
                               const void* scale_a, const void* scale_b, void* absmax_out, void* stream);

@@ -121,14 +121,6 @@ int qamdp_rec_chain2(const qamd_chain2_plan* p, const void* A, const void* W1, c
   put_blob(o, p);
   return QAMD_OK;
 }
-int qamdp_rec_chain3(const qamd_chain3_plan* p, const void* A, const void* W1, const void* W2, const void* W3, void* C,
-                     const void* k1, const void* co, const void* sa, const void* s1, const void* s2, const void* s3,
-                     void* amax) {
-  if (!p) return QAMD_EINVAL;
-  Op& o = push(QP_CHAIN3, {A, W1, W2, W3, C, k1, co, sa, s1, s2, s3, amax});
-  put_blob(o, p);
-  return QAMD_OK;
-}
 int qamdp_rec_permute(void* dst, const void* src, int32_t ndim, const int64_t* shape, const int64_t* strides,
                       int64_t offset, int32_t dtype) {
   if (ndim < 0 || ndim > QAMD_MAX_NDIM) return QAMD_EINVAL;
@@ -290,9 +282,6 @@ static int run_op(const Op& o, const void* const* q, void* st) {
     case QP_CHAIN2:
       return qamd_contract_chain2((const qamd_chain2_plan*)o.blob.data(), q[0], q[1], q[2], P0(3), q[4], q[5], q[6],
                                   q[7], q[8], P0(9), st);
-    case QP_CHAIN3:
-      return qamd_contract_chain3((const qamd_chain3_plan*)o.blob.data(), q[0], q[1], q[2], q[3], P0(4), q[5], q[6],
-                                  q[7], q[8], q[9], q[10], P0(11), st);
     case QP_PERMUTE: {
       const int nd = (int)o.iv[0];
       return qamd_permute(P0(0), q[1], nd, o.arr.data(), o.arr.data() + nd, o.iv[1], (int32_t)o.iv[2], st);

@@ -15,6 +15,7 @@ import threading
 import numpy as np
 
 from . import _lib
+from .options import get_options
 from .pairwise import GettSpec, prod
 
 _DT_CODE = {
@@ -111,10 +112,14 @@ class HipDevice:
         self.profile = None
         #: launches below this many multiplications are not bracketed by events when ``profile`` is a list
         self.profile_min_mults = 0
-        self.force_tile_cfg = int(os.environ.get("QAMD_TILE_CFG", "-1"))
-        self.force_split_k = int(os.environ.get("QAMD_SPLIT_K", "0"))
+        opts = get_options()      # developer pins, captured once per device object (quimb_amd/options.py)
+        self.force_tile_cfg = int(opts.tile_cfg)
+        self.force_split_k = int(opts.split_k)
         #: 0 = auto (streaming kernel where eligible), -1 = always the tiled GETT kernel
-        self.force_kernel = int(os.environ.get("QAMD_KERNEL", "0"))
+        self.force_kernel = int(opts.pair_kernel)
+        #: fused-pair kernel pin: "auto" | "lds" | "reg" | "quad" (QAMD_CHAIN2_FORCE_* flag bits of the plan)
+        self.force_chain2 = opts.chain2_kernel
+        self.micro_arena = opts.micro_arena
 
     # ---- memory ---------------------------------------------------------
     def empty(self, n, dtype):
@@ -323,9 +328,9 @@ class HipDevice:
         """C = (A . W1) . W2 in one pass (chain2r.hip / chain2.hip).  ``c2``: pairwise.Chain2Spec;
         ``w1`` / ``w2``: the small tensors in their own layouts (``c2.w1_pack`` / ``w2_pack`` say how
         to address them); ``ep`` = (slots_a, slots_w1, slots_w2, slots_out) or None."""
-        # the kernel choice (and with it the W addressing mode) follows these switches at call time
-        key = ("chain2", c2, dtype_code(dtype), os.environ.get("QAMD_CHAIN2R"), os.environ.get("QAMD_C2R_SC"),
-               os.environ.get("QAMD_CHAIN2Q"), os.environ.get("QAMD_CHAIN2H"))
+        # the kernel choice (and with it the W addressing mode) follows the device's pin
+        force = {"auto": 0, "lds": 16, "reg": 32, "quad": 64}[self.force_chain2]
+        key = ("chain2", c2, dtype_code(dtype), force)
         ent = self._pairs.get(key)
         if ent is None:
             pl = _lib.Chain2PlanStruct()
@@ -335,6 +340,7 @@ class HipDevice:
             pl.sa_v = c2.sa_v
             if all(o % 4 == 0 for o in c2.off_co) and all(sc % 4 == 0 for (_, _, sc) in c2.m[:-1]):
                 pl.flags = 1  # QAMD_CHAIN2_C_ALIGNED16
+            pl.flags |= force
             if c2.k1_single:
                 pl.flags |= 2  # QAMD_CHAIN2_K1_SINGLE
             if c2.no_n2out:
@@ -342,7 +348,7 @@ class HipDevice:
             buf = C.create_string_buffer(128)
             _lib.check(self.lib.qamd_chain2_describe(C.byref(pl), buf, 128), "qamd_chain2_describe")
             name = buf.value.decode()
-            if name.startswith(("chain2r", "chain2q", "chain2h")):
+            if name.startswith(("chain2r", "chain2q")):
                 # the register kernel reads the small tensors in place: no packed copies, no permute launches
                 pl.flags |= 8  # QAMD_CHAIN2_W_STRIDED
                 s1, s2 = list(c2.w1_pack.strides), list(c2.w2_pack.strides)
@@ -393,49 +399,6 @@ class HipDevice:
             self.release_temp(w2p)
 
     # ---- fused triple of streaming steps --------------------------------------------
-    def contract_chain3(self, c3, dtype, a, w1, w2, w3, c, ep=None):
-        """C = ((A . W1) . W2) . W3 in one pass (chain3.hip).  ``c3``: pairwise.Chain3Spec; the small tensors
-        are addressed in place; ``ep`` = (slots_a, slots_w1, slots_w2, slots_w3, slots_out) or None."""
-        key = ("chain3", c3, dtype_code(dtype), os.environ.get("QAMD_C3_NW"))
-        ent = self._pairs.get(key)
-        if ent is None:
-            pl = _lib.Chain3PlanStruct()
-            pl.dtype, pl.D, pl.nm = dtype_code(dtype), c3.D, len(c3.m)
-            for i, (d, sa, sc) in enumerate(c3.m):
-                pl.dim_m[i], pl.sa_m[i], pl.sc_m[i] = d, sa, sc
-            pl.sa_b, pl.sa_c = c3.sa_b, c3.sa_c
-            for i in range(4):
-                pl.w1_strides[i], pl.w2_strides[i], pl.w3_strides[i] = c3.w1s[i], c3.w2s[i], c3.w3s[i]
-            buf = C.create_string_buffer(128)
-            _lib.check(self.lib.qamd_chain3_describe(C.byref(pl), buf, 128), "qamd_chain3_describe")
-            k1 = self.torch.tensor(c3.off_k1, dtype=self.torch.int64, device=self.tdev)
-            co = self.torch.tensor(c3.off_co, dtype=self.torch.int64, device=self.tdev)
-            ent = (pl, k1, co, buf.value.decode())
-            self._pairs[key] = ent
-        pl, k1, co, name = ent
-        ptr = lambda t: (t.data_ptr() if t is not None else None)
-        sa = s1 = s2 = s3 = so = None
-        if ep is not None:
-            sa, s1, s2, s3, so = (ptr(t) for t in ep)
-        prof = self.profile
-        if self.record is not None:
-            prof = None
-            self.record.maybe_mark(c3, np.dtype(dtype), lambda: (name, 1))
-        if prof is not None:
-            e0 = self.torch.cuda.Event(enable_timing=True)
-            e1 = self.torch.cuda.Event(enable_timing=True)
-            e0.record()
-        _lib.check(
-            self.lib.qamd_contract_chain3(
-                C.byref(pl), a.data_ptr(), w1.data_ptr(), w2.data_ptr(), w3.data_ptr(), c.data_ptr(), k1.data_ptr(),
-                co.data_ptr(), sa, s1, s2, s3, so, self.stream(),
-            ),
-            "qamd_contract_chain3",
-        )
-        if prof is not None:
-            e1.record()
-            prof.append((c3, np.dtype(dtype), name, 1, e0, e1))
-
     # ---- layout / elementwise -----------------------------------------------
     def permute(self, dst, src, shape, strides, offset, dtype):
         nd = len(shape)
@@ -620,7 +583,7 @@ class HipDevice:
         steps_dev, etab_dev, ktab_dev = plan
         ninst = int(table.shape[0])
         ptrs = torch.from_numpy(np.ascontiguousarray(table, dtype=np.int64)).to(self.tdev, non_blocking=False)
-        mode = os.environ.get("QAMD_MICRO_ARENA", "auto")      # auto | lds | global
+        mode = getattr(self, "micro_arena", "auto")      # auto | lds | global
         use_lds = mt.lds_ok and (mode == "lds" or (mode == "auto" and ninst <= 2 * 256))
         arena = None if use_lds else self.empty(max(mt.arena_elems * ninst, 1), mt.dtype)
         _lib.check(

@@ -19,7 +19,7 @@ def rank_slices(nslices, rank, world):
     return range(rank, nslices, world)
 
 
-def contract_sliced(executor, arrays, strip_exponent=False, group=None, rank=None, world=None):
+def contract_sliced(executor, arrays, strip_exponent=False, group=None, rank=None, world=None, slice_graph=None):
     """Evaluate this rank's slices and all-reduce the result.
 
     Returns a numpy array on every rank (``(mantissa, exponent)`` if
@@ -34,7 +34,7 @@ def contract_sliced(executor, arrays, strip_exponent=False, group=None, rank=Non
         rank, world = 0, 1
     nsl = executor.tree.nslices
     mine = list(rank_slices(nsl, rank, world))
-    out = executor(arrays, strip_exponent=strip_exponent, slices=mine)
+    out = executor(arrays, strip_exponent=strip_exponent, slices=mine, slice_graph=slice_graph)
     if strip_exponent:
         out, e = out
     if world == 1:

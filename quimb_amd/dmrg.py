@@ -231,9 +231,48 @@ class DMRG2:
                                        miniter=ncv)
             loc_en, gs = float(evals[0]), vecs.reshape((n,))
         m = gs.reshape((dims[0] * dims[1], dims[2] * dims[3]))
+        if self.split == "rand" and max_bond and self.split_opts.get("oversample", 10) == 0 and max_bond >= min(m.shape):
+            # nothing to truncate and no singular values wanted (static bond): the isometry is the identity on the short
+            # side, or one Cholesky-QR of the tall one -- no eigen-decomposition near the ends of the chain either
+            right = direction == "right"
+            mm_, nn_ = m.shape
+            if right and mm_ <= nn_:
+                lf, rf = Array.from_numpy(np.eye(mm_, dtype=self.dtype), dev=m._dev), m
+            elif not right and nn_ <= mm_:
+                lf, rf = m, Array.from_numpy(np.eye(nn_, dtype=self.dtype), dev=m._dev)
+            elif right:
+                lf, rf = linalg.qr_via_cholesky(m, shift=True, refine=True) if self.dtype.itemsize >= 8 and self.dtype.kind == "f" \
+                    or self.dtype == np.dtype("complex128") else linalg.qr(m)
+            else:
+                if self.dtype == np.dtype("float64") or self.dtype == np.dtype("complex128"):
+                    lf, rf = linalg.lq_via_cholesky(m, shift=True, refine=True)
+                else:
+                    q_, r_ = linalg.qr(ops.transpose(m, (1, 0)))
+                    lf, rf = ops.transpose(r_, (1, 0)), ops.transpose(q_, (1, 0))
+            k = lf.shape[1]
+            A[i] = lf.reshape((dims[0], dims[1], k))
+            A[i + 1] = rf.reshape((k, dims[2], dims[3]))
+            th = ops.tensordot(A[i], A[i + 1], axes=([2], [0])).reshape((n,))
+            hv = heff.matvec(th)
+            nrm2 = float(np.real(ops.tensordot(th.conj(), th, axes=([0], [0])).item()))
+            return loc_en, float(np.real(ops.tensordot(th.conj(), hv, axes=([0], [0])).item())) / nrm2
         if self.split == "rand" and max_bond and 0 < max_bond + self.split_opts.get("oversample", 10) < min(m.shape):
             so = dict(oversample=10, num_iterations=0, method_lorthog="qr:cholesky", method_reduced="svd:eig")
             so.update(self.split_opts)
+            if so["oversample"] == 0:
+                # the reference's ``svd:rand`` with a sketch no wider than the bond (decomp.py:1808-1815, :1836-1843): the
+                # reduced factor is NOT decomposed -- an isometry on the side the sweep leaves behind, everything else moves
+                # on; static truncation to max_bond (the cutoff plays no part, as there), no singular values
+                right = direction == "right"
+                lf, _, rf = linalg.svd_rand(m, max_bond, right=right, factors_only=True, **so)
+                k = lf.shape[1]
+                A[i] = lf.reshape((dims[0], dims[1], k))
+                A[i + 1] = rf.reshape((k, dims[2], dims[3]))
+                th = ops.tensordot(A[i], A[i + 1], axes=([2], [0])).reshape((n,))
+                hv = heff.matvec(th)
+                nrm2 = float(np.real(ops.tensordot(th.conj(), th, axes=([0], [0])).item()))
+                tot = float(np.real(ops.tensordot(th.conj(), hv, axes=([0], [0])).item())) / nrm2
+                return loc_en, tot
             u, s, vh = linalg.svd_rand(m, max_bond, **so)
         else:
             u, s, vh = (linalg.svd if self.split == "svd" else linalg.svd_via_eig)(m)

@@ -22,7 +22,8 @@ import numpy as np
 
 from .array import Array, asarray, _coerce_dtype
 from .ops import _einsum_single, run_pair_step
-from .pairwise import plan_chain2, plan_chain3, plan_pair, prod
+from .options import get_options
+from .pairwise import plan_chain2, plan_pair, prod
 from .tree import ContractionTree
 
 
@@ -44,12 +45,15 @@ class TreeExecutor:
     """Plan once, run many times (the analogue of a cached cotengra expression,
     pinned by tests/test_tensor/test_contract.py:155-172 in the reference)."""
 
-    def __init__(self, tree: ContractionTree, dtype="float32", join_order=True):
+    def __init__(self, tree: ContractionTree, dtype="float32", join_order=True, options=None):
         #: issue the chains of the FIRST join first and that join right behind them (``_order_for_joins``): right for the
         #: launch-by-launch path, where the host enqueues slower than the device executes; a launch program enqueues a
         #: whole share in 0.35 ms and is recorded in plain plan order (all chains side by side, then the joins)
+        #: the options this executor was BUILT with (quimb_amd/options.py): resolved once, here; nothing below or at run
+        #: time consults the environment
+        self.options = options if options is not None else get_options()
         self.join_order = bool(join_order)
-        if os.environ.get("QAMD_REGROUP", "1") != "0":
+        if self.options.regroup:
             tree = tree.regrouped()          # (A.W1).W2 -> A.(W1.W2) where cheaper (sliced bonds); same result
         self.tree = tree
         self.dtype = _coerce_dtype(dtype)
@@ -133,18 +137,13 @@ class TreeExecutor:
     def _fuse_pairs(self, size):
         """Replace consecutive big-x-small steps that have the two-site structure by one
         fused launch (qamd_contract_chain2): the intermediate never reaches HBM."""
-        import os
-
         # on by default: 0.94 ms per fused 6^9 pair against 2 x 0.55 ms for two streaming
-        # launches (DESIGN.md 4.5); QAMD_CHAIN2=0 keeps every step a separate launch
-        if self.dtype.kind == "c" or os.environ.get("QAMD_CHAIN2", "1") == "0":
+        # launches (DESIGN.md 4.5); options.fuse_pairs = False keeps every step a separate launch
+        if self.dtype.kind == "c" or not self.options.fuse_pairs:
             return
         plan, info = self.plan, self.info
         new_plan, new_info = [], []
         isz = self.dtype.itemsize
-        # triples (chain3.hip) are opt-in: measured 1.25 ms per three sites against 0.57 ms per pair (chain2q.hip)
-        use3 = os.environ.get("QAMD_CHAIN3", "0") == "1"
-
         def big_small(entry):
             """(big operand id, small operand id, result id, step) of a plain big-x-small GETT step, else None"""
             if entry[0] != "pair":
@@ -159,21 +158,9 @@ class TreeExecutor:
             fused = None
             s1 = big_small(plan[i])
             s2 = big_small(plan[i + 1]) if i + 1 < len(plan) else None
-            s3 = big_small(plan[i + 2]) if i + 2 < len(plan) else None
-            if use3 and s1 and s2 and s3 and s2[0] == s1[2] and s3[0] == s2[2] \
-                    and self.dep[s1[2]] == self.dep[s2[2]] == self.dep[s3[2]]:
-                # three interior sites in one pass: the chunk state is exchanged through LDS (chain3.hip)
-                c3 = plan_chain3(self.layout[s1[0]], self.layout[s1[1]], s1[3].out_inds, self.layout[s2[1]],
-                                 s2[3].out_inds, self.layout[s3[1]], s3[3].out_inds, size, self.dtype.name)
-                if c3 is not None:
-                    new_plan.append(("chain3", s1[0], s1[1], s2[1], s3[1], s3[2], c3))
-                    new_info.append(StepInfo("chain3", c3.mults, isz * (c3.a_size + c3.c_size + 3 * c3.D**4),
-                                             (1, c3.M * c3.D**2, c3.D**2, c3.D**2), self.dep[s3[2]]))
-                    i += 3
-                    continue
             if s1 and s2 and s2[0] == s1[2] and self.dep[s1[2]] == self.dep[s2[2]]:
                 c2 = plan_chain2(self.layout[s1[0]], self.layout[s1[1]], s1[3].out_inds, self.layout[s2[1]],
-                                 s2[3].out_inds, size, self.dtype.name)
+                                 s2[3].out_inds, size, self.dtype.name, variants=self.options.chain2_kernel != "lds")
                 if c2 is not None:
                     fused = ("chain2", s1[0], s1[1], s2[1], s2[2], c2)
             if fused is not None:
@@ -193,9 +180,9 @@ class TreeExecutor:
         SAME layout in one inner product over all indices (the quadrant tree: B = BL.BR, then sum(T * B)) -- become one
         plan entry: the device multiplies every result tile with the matching tile of ``t`` and sums, so the join's result
         is never written or read back (``qamd_contract_pair_dot``; fp32 joins on the k-outer MFMA kernel, anything else is
-        executed as the two steps it was).  ``QAMD_JOIN_DOT=0`` keeps the steps apart."""
+        executed as the two steps it was).  ``options.join_dot = False`` keeps the steps apart."""
         if self.dtype != np.dtype("float32") or self.tree.nslices != 1 or len(self.plan) < 2 \
-                or os.environ.get("QAMD_JOIN_DOT", "1") == "0":
+                or not self.options.join_dot:
             return
         last, prev = self.plan[-1], self.plan[-2]
         if last[0] != "pair" or prev[0] != "pair":
@@ -222,8 +209,6 @@ class TreeExecutor:
             return (entry[1],), entry[2]
         if k == "chain2":
             return (entry[1], entry[2], entry[3]), entry[4]
-        if k == "chain3":
-            return (entry[1], entry[2], entry[3], entry[4]), entry[5]
         if k == "pairdot":
             return (entry[1], entry[2], entry[3]), entry[4]
         return (entry[1], entry[2]), entry[3]
@@ -286,7 +271,7 @@ class TreeExecutor:
         changes WHEN things are enqueued (``lane_priority``: HIP stream priority per lane, all normal by default)."""
         n = len(self.plan)
         self.lane_priority = [0] * self.nlanes
-        if self.nlanes <= 1 or os.environ.get("QAMD_JOIN_ORDER", "1") == "0":
+        if self.nlanes <= 1 or not self.options.join_order:
             return
         if not self.join_order:
             self._interleave_chains()
@@ -334,7 +319,7 @@ class TreeExecutor:
         # (HIP stream priorities for the first join's lanes were tried in round 4 and dropped: they did not keep a join
         # from slowing down beside a corner sweep, and streams of a second priority class cost hardware queues.
         # QAMD_LANE_PRIORITY=1 brings them back for experiments.)
-        if os.environ.get("QAMD_LANE_PRIORITY", "0") == "1":
+        if self.options.lane_priority:
             first = anchors[0]
             for i in range(n):
                 if need[i] == first:
@@ -344,9 +329,9 @@ class TreeExecutor:
         # CU's LDS and matrix pipe) and ends shortly after it, so this pays only when the join is long: the 7 ms joins of the
         # whole 10x10 D=6 network (4.96 rounds of tiles) gain 0.2 ms per step (two corner sweeps in 1.03 ms instead of four
         # in 1.85 ms, the join 0.25 ms slower), the 3.5 / 1.8 / 0.95 ms joins of a rank of 2 / 4 / 8 LOSE 0.2-0.35 ms
-        # (measured, round 4).  QAMD_HOLD_LATE=0 / 1 forces it off / on.
+        # (measured, round 4).  options.hold_late = "0" / "1" forces it off / on.
         self.hold_late = None
-        hold = os.environ.get("QAMD_HOLD_LATE", "auto")
+        hold = self.options.hold_late
         if len(anchors) > 1 and hold != "0" and (hold == "1" or self.info[anchors[0]].mults >= HOLD_LATE_MIN_MULTS):
             first = anchors[0]
             early = sorted({self.lanes[i] for i in range(n) if need[i] == first and i != first})
@@ -454,7 +439,7 @@ class TreeExecutor:
         # appended to it instead of acting on torch streams, and buffers come from (and go back to) its pool.
         rec = getattr(dev, "record", None)
         streams = None
-        use_lanes = lanes and self.nlanes > 1 and os.environ.get("QAMD_LANES", "1") != "0"
+        use_lanes = lanes and self.nlanes > 1 and self.options.lanes
         if rec is not None:
             if use_lanes:
                 for l_ in range(1, self.nlanes):
@@ -468,7 +453,7 @@ class TreeExecutor:
         foreign = set()   # ssa ids of such buffers: a program's pool never reuses them
         # QAMD_LANE_TRACE=1 (debugging aid): HIP events at the first and last launch of every lane -> self.lane_trace
         trace = trace_at = None
-        if streams is not None and os.environ.get("QAMD_LANE_TRACE"):
+        if streams is not None and self.options.lane_trace:
             trace = self.lane_trace = []
             first, last = {}, {}
             for i_, l_ in enumerate(self.lanes):
@@ -481,8 +466,6 @@ class TreeExecutor:
                 return (entry[1],)
             if entry[0] == "chain2":
                 return (entry[1], entry[2], entry[3])
-            if entry[0] == "chain3":
-                return (entry[1], entry[2], entry[3], entry[4])
             if entry[0] == "pairdot":
                 return (entry[1], entry[2], entry[3])
             return (entry[1], entry[2])
@@ -580,26 +563,6 @@ class TreeExecutor:
                     if independent and cache is not None:
                         cache[res] = x
                 ids = (a, w1, w2)
-            elif entry[0] == "chain3":
-                _, a, w1, w2, w3, res, c3 = entry
-                independent = not self.dep[res]
-                if independent and cache is not None and res in cache:
-                    live[res] = cache[res]
-                elif only_independent and not independent:
-                    continue
-                else:
-                    x = Array.empty(c3.out_shape, self.dtype, dev)
-                    ep = None
-                    if exponent is not None:
-                        ep = tuple(dev.slots_row(slots, s_) if s_ in has_scale else None for s_ in (a, w1, w2, w3))
-                        ep = ep + (dev.slots_row(slots, res),)
-                        has_scale.add(res)
-                    dev.contract_chain3(c3, self.dtype, live[a]._buf, live[w1]._buf, live[w2]._buf, live[w3]._buf,
-                                        x._buf, ep)
-                    live[res] = x
-                    if independent and cache is not None:
-                        cache[res] = x
-                ids = (a, w1, w2, w3)
             elif entry[0] == "pairdot":
                 _, a, b, t, res, jstep, dstep, jres, join_first = entry
                 x = Array.empty(dstep.out_shape, self.dtype, dev)
@@ -671,10 +634,10 @@ class TreeExecutor:
         # host side is no bottleneck: record the plain order -- every chain side by side, then the joins
         ex = self
         if self.join_order and self.nlanes > 1 and getattr(self, "hold_late", None) is None \
-                and os.environ.get("QAMD_PROGRAM_JOIN_ORDER", "0") != "1":
+                and not self.options.program_join_order:
             ex = getattr(self, "_plain_order_twin", None)
             if ex is None:
-                ex = self._plain_order_twin = TreeExecutor(self.tree, self.dtype, join_order=False)
+                ex = self._plain_order_twin = TreeExecutor(self.tree, self.dtype, join_order=False, options=self.options)
         return ContractionProgram(ex, arrays, strip_exponent, mark_min_mults)
 
     def check_inputs(self, arrays):
@@ -746,14 +709,16 @@ class TreeExecutor:
             ent["g"].replay()
         return acc.copy(), dev.read_exponent(acc_exp)
 
-    def __call__(self, arrays, strip_exponent=False, slices=None, hoist=True, defer_exponent=False):
+    def __call__(self, arrays, strip_exponent=False, slices=None, hoist=True, defer_exponent=False, lanes=None,
+                 slice_graph=None):
         """Contract.  ``slices``: iterable of slice numbers to evaluate (default
         all); the partial sum over exactly those slices is returned, which is what
         a rank of the multi-GPU driver needs before the RCCL reduce.
 
         Returns an ``Array`` (or ``(Array, exponent)`` if ``strip_exponent``).  ``defer_exponent`` (unsliced trees):
         the exponent comes back as the device-resident accumulator instead of a float, so the call does not
-        synchronise with the device -- ``dev.read_exponent(e)`` reads it later."""
+        synchronise with the device -- ``dev.read_exponent(e)`` reads it later.  ``lanes`` / ``slice_graph``: per-call
+        overrides of the executor's options (False: every launch on the caller's stream / slices launch by launch)."""
         tree = self.tree
         xs = self.check_inputs(arrays)
         dev = xs[0]._dev
@@ -774,7 +739,7 @@ class TreeExecutor:
             return (out, 0.0) if strip_exponent else out
         if nsl == 1:
             exponent = dev.new_exponent() if strip_exponent else None
-            out = self._run_core(xs, exponent, None, lanes=True)
+            out = self._run_core(xs, exponent, None, lanes=True if lanes is None else bool(lanes))
             if strip_exponent:
                 return (out, exponent) if defer_exponent else (out, dev.read_exponent(exponent))
             return out
@@ -783,7 +748,8 @@ class TreeExecutor:
         cache = {} if (hoist and not strip_exponent) else None
         acc, acc_e = None, None
         acc_exp = None   # device-resident exponent of the running sum: the slice loop never syncs with the host
-        if strip_exponent and len(todo) >= 4 and hasattr(dev, "torch") and os.environ.get("QAMD_SLICE_GRAPH", "1") != "0":
+        if strip_exponent and len(todo) >= 4 and hasattr(dev, "torch") \
+                and (self.options.slice_graph if slice_graph is None else bool(slice_graph)):
             # every slice runs the SAME launch sequence on differently sliced inputs: record it once as a
             # hipGraph over static input buffers and replay it per slice (a few tiny slicing copies + one
             # graph launch instead of ~80 Python-driven launches)

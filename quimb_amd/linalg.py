@@ -268,7 +268,7 @@ def _orth(y, method):
 
 
 def svd_rand(x, k, oversample=10, num_iterations=2, method_lorthog="qr", method_reduced="svd", right=None,
-             stabilize=False, seed=None):
+             stabilize=False, seed=None, factors_only=False):
     """Rank-``k`` randomised SVD ``(U, s, VH)`` by sketching -- the reference's ``svd_rand_truncated`` (decomp.py:1689-
     1868) with ``absorb=None``: ``y = x w`` for a Gaussian ``w`` with ``k + oversample`` columns, ``num_iterations``
     rounds of ``y <- x (x^H y)`` (plain, as the reference; ``stabilize`` re-orthogonalises y after every product -- what
@@ -277,7 +277,12 @@ def svd_rand(x, k, oversample=10, num_iterations=2, method_lorthog="qr", method_
     decomposed by ``method_reduced`` and truncated to k, ``U = Q U_B``.  ``right`` False sketches the row space instead
     (default: the shorter side is reduced: ``right = m > n``).  Every product is a GETT launch of this library; with
     ``method_lorthog="qr:cholesky"`` and ``method_reduced="svd:eig"`` the only LAPACK work left is a potrf and a syevd
-    of size k + oversample."""
+    of size k + oversample.
+
+    ``factors_only``: the reference's shortcut for ``absorb`` "right" / "left" when the sketch is no wider than the
+    target rank (``k >= k_sketch``, decomp.py:1808-1815 / :1836-1843): no decomposition of the reduced factor at all --
+    ``(Q, None, Q^H x)`` (``right``) or ``(x Q, None, Q^H)`` -- an isometry times the rest, which is all a sweep needs
+    to move its orthogonality centre.  Raises if the sketch is wider than k."""
     from . import ops
 
     x = x if isinstance(x, Array) else Array.from_numpy(np.asarray(x))
@@ -299,6 +304,10 @@ def svd_rand(x, k, oversample=10, num_iterations=2, method_lorthog="qr", method_
             y = mm(x, y)
         Q = _orth(y, method_lorthog)                                             # (m, ks)
         B = ops.tensordot(Q.conj(), x, axes=([0], [0]))                         # Q^H x, (ks, n)
+        if factors_only:
+            if k < ks:
+                raise ValueError("factors_only needs k >= k + oversample (oversample=0)")
+            return Q, None, B
     else:
         w = _randn(x._dev, (ks, m), x.dtype, seed)
         y = mm(w, x)                                                             # (ks, n)
@@ -311,6 +320,10 @@ def svd_rand(x, k, oversample=10, num_iterations=2, method_lorthog="qr", method_
             y = mm(y, x)
         Q = _orth(ops.transpose(y.conj(), (1, 0)), method_lorthog)              # (n, ks): basis of the row space
         B = mm(x, Q)                                                             # (m, ks)
+        if factors_only:
+            if k < ks:
+                raise ValueError("factors_only needs k >= k + oversample (oversample=0)")
+            return B, None, ops.transpose(Q.conj(), (1, 0))
     if method_reduced in ("svd:eig", "eig"):
         ub, s, vbh = svd_via_eig(B)
     elif method_reduced == "svd":

@@ -46,15 +46,9 @@ class MicroTree:
     def __init__(self, tree, dtype, max_elems=1 << 16):
         from .executor import TreeExecutor
 
-        old = os.environ.get("QAMD_CHAIN2")
-        os.environ["QAMD_CHAIN2"] = "0"        # one plan entry per pairwise step
-        try:
-            ex = TreeExecutor(tree, dtype)
-        finally:
-            if old is None:
-                del os.environ["QAMD_CHAIN2"]
-            else:
-                os.environ["QAMD_CHAIN2"] = old
+        from .options import get_options
+
+        ex = TreeExecutor(tree, dtype, options=get_options().replace(fuse_pairs=False))     # one plan entry per pairwise step
         if tree.nslices != 1:
             raise ValueError("MicroTree: sliced trees are not supported")
         self.tree, self.dtype = tree, np.dtype(dtype)

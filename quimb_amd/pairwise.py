@@ -376,10 +376,6 @@ def parse_einsum(eq, nops):
 def chain2_chunk(dtype_name, D):
     """m-chunk of the fused pair kernel; mirrors ``qamd_chain2_chunk`` (0 = unsupported)."""
     if dtype_name == "float32":
-        import os
-
-        if os.environ.get("QAMD_CHAIN2_V2", "")[:1] == "1":
-            return 32 if 2 <= D <= 6 else (16 if D == 7 else 0)
         return 16 if 2 <= D <= 7 else 0
     if dtype_name == "float64":
         return 16 if 2 <= D <= 6 else 0
@@ -387,12 +383,8 @@ def chain2_chunk(dtype_name, D):
 
 
 def chain2_variants_ok(dtype_name, D):
-    """Row-start / row-end pair shapes: mirrors ``qamd_chain2r_supported`` (fp32, D <= 6, 16-m chunk;
-    ``QAMD_CHAIN2R=0`` switches the register kernel off in the library, and with it these shapes)."""
-    import os
-
-    if os.environ.get("QAMD_CHAIN2R", "")[:1] == "0":
-        return False
+    """Row-start / row-end pair shapes: mirrors ``qamd_chain2r_supported`` (fp32, D <= 6, 16-m chunk; a caller that
+    pins the LDS-tile kernel -- ``Options.chain2_kernel = "lds"`` -- plans without them: ``plan_chain2(variants=False)``)."""
     return dtype_name == "float32" and 2 <= D <= 6 and chain2_chunk(dtype_name, D) == 16
 
 
@@ -428,7 +420,7 @@ class Chain2Spec:
         return prod(g[0] for g in self.m)
 
 
-def plan_chain2(la, l1, lx, l2, lc, size, dtype_name):
+def plan_chain2(la, l1, lx, l2, lc, size, dtype_name, variants=True):
     """Try to fuse  X[lx] = A[la].W1[l1]  and  C[lc] = X.W2[l2]  (all layouts are index
     tuples of C-contiguous arrays; ``lc`` is the layout already chosen for C).  Returns a
     ``Chain2Spec`` or None if the pair does not have the fusable structure."""
@@ -459,7 +451,7 @@ def plan_chain2(la, l1, lx, l2, lc, size, dtype_name):
         return None
     # row-start (k1 = one index) and row-end (n2 = one index) shapes exist in the register kernel only
     variant = len(k1) == 1 or len(n2) == 1
-    if variant and (len(k1) == 1 and len(n2) == 1 or not chain2_variants_ok(dtype_name, D)):
+    if variant and (len(k1) == 1 and len(n2) == 1 or not variants or not chain2_variants_ok(dtype_name, D)):
         return None
     chunk = chain2_chunk(dtype_name, D)
     if not chunk:
@@ -516,129 +508,4 @@ def plan_chain2(la, l1, lx, l2, lc, size, dtype_name):
         c_size=prod(size[i] for i in lc),
         K1=K1,
         NO=NO,
-    )
-
-
-# ---------------------------------------------------------------------------
-# fused triple of streaming steps (qamd_contract_chain3)
-# ---------------------------------------------------------------------------
-def chain3_chunk(dtype_name, D):
-    """m-chunk of the fused triple kernel; mirrors ``qamd_chain3_chunk`` (0 = unsupported)."""
-    return 16 if (dtype_name == "float32" and D in (2, 4, 6)) else 0
-
-
-@dataclass(frozen=True)
-class Chain3Spec:
-    """Three consecutive big-x-small steps fused (see chain3.hip):
-    X1 = A.W1 (contracts h, a) ; X2 = X1.W2 (contracts h1, b) ; C = X2.W3 (contracts h2, c)."""
-
-    D: int
-    m: tuple          # groups (dim, stride_in_A, stride_in_C), outermost first
-    sa_b: int         # A stride of b (carried through step 1, contracted in step 2)
-    sa_c: int         # A stride of c (carried through steps 1 and 2, contracted in step 3)
-    off_k1: tuple     # A element offset of every (h, a) row (D*D entries)
-    off_co: tuple     # C element offset of every h3 value (D entries)
-    w1s: tuple        # W1 element strides of (h, a, h1, x)
-    w2s: tuple        # W2 element strides of (h1, b, h2, y)
-    w3s: tuple        # W3 element strides of (h2, c, h3, z)
-    out_inds: tuple
-    out_shape: tuple
-    mults: int        # scalar multiplications of the three steps
-    a_size: int
-    c_size: int
-
-    @property
-    def M(self):
-        return prod(g[0] for g in self.m)
-
-
-def plan_chain3(la, l1, lx1, l2, lx2, l3, lc, size, dtype_name):
-    """Try to fuse  X1[lx1] = A[la].W1[l1],  X2[lx2] = X1.W2[l2]  and  C[lc] = X2.W3[l3]  (layouts are index
-    tuples of C-contiguous arrays; ``lc`` is the layout already chosen for C).  Returns a ``Chain3Spec`` or
-    None if the steps do not have the three-site structure the kernel implements."""
-    for t in (la, l1, l2, l3, lc):
-        if len(set(t)) != len(t):
-            return None
-    s1, s2, s3 = set(l1), set(l2), set(l3)
-    sx1, sx2, sc_ = set(lx1), set(lx2), set(lc)
-    sa_set = set(la)
-    # step 1: contracts k1 = (h, a); nothing summed away, no batch index
-    k1 = [ix for ix in la if ix in s1]
-    if len(k1) != 2 or any(ix in sx1 for ix in k1):
-        return None
-    n1 = [ix for ix in l1 if ix not in k1]
-    if len(n1) != 2 or sx1 != (sa_set - set(k1)) | set(n1):
-        return None
-    # step 2: contracts (h1 from W1, b from A)
-    k2 = [ix for ix in lx1 if ix in s2]
-    if len(k2) != 2 or any(ix in sx2 for ix in k2):
-        return None
-    h1 = [ix for ix in k2 if ix in n1]
-    b = [ix for ix in k2 if ix in sa_set]
-    if len(h1) != 1 or len(b) != 1:
-        return None
-    h1, b = h1[0], b[0]
-    x = [ix for ix in n1 if ix != h1][0]
-    n2 = [ix for ix in l2 if ix not in k2]
-    if len(n2) != 2 or sx2 != (sx1 - set(k2)) | set(n2):
-        return None
-    # step 3: contracts (h2 from W2, c from A)
-    k3 = [ix for ix in lx2 if ix in s3]
-    if len(k3) != 2 or any(ix in sc_ for ix in k3):
-        return None
-    h2 = [ix for ix in k3 if ix in n2]
-    c = [ix for ix in k3 if ix in sa_set]
-    if len(h2) != 1 or len(c) != 1:
-        return None
-    h2, c = h2[0], c[0]
-    y = [ix for ix in n2 if ix != h2][0]
-    n3 = [ix for ix in l3 if ix not in k3]
-    if len(n3) != 2 or sc_ != (sx2 - set(k3)) | set(n3):
-        return None
-    # C must end with [.., m_inner, x, y, z]
-    if len(lc) < 5 or lc[-3] != x or lc[-2] != y or lc[-1] not in n3:
-        return None
-    z = lc[-1]
-    h3 = [ix for ix in n3 if ix != z][0]
-    D = size[x]
-    if not chain3_chunk(dtype_name, D):
-        return None
-    if any(size[ix] != D for ix in k1 + [h1, b, x, h2, c, y, h3, z]):
-        return None
-    mm = [ix for ix in la if ix not in k1 and ix != b and ix != c]
-    if not mm or set(lc) != set(mm) | {x, y, z, h3}:
-        return None
-    sa = dict(zip(la, contig_strides(tuple(size[i] for i in la))))
-    sc = dict(zip(lc, contig_strides(tuple(size[i] for i in lc))))
-    gm = _fuse(mm, size, [sa, sc])
-    if not gm or len(gm) > MAX_GROUPS:
-        return None
-    d_in, (sa_in, sc_in) = gm[-1]
-    if sa_in != 1 or sc_in != D**3 or d_in % 16:
-        return None
-    off_k1 = tuple(i * sa[k1[0]] + j * sa[k1[1]] for i in range(D) for j in range(D))
-    if (max(off_k1) + 64) * 4 >= 2**32:
-        return None
-    off_co = tuple(i * sc[h3] for i in range(D))
-    if any(o % 4 for o in off_co) or any(st[1] % 4 for _, st in gm[:-1]):
-        return None                                    # 16-byte stores
-    s1d = dict(zip(l1, contig_strides(tuple(size[i] for i in l1))))
-    s2d = dict(zip(l2, contig_strides(tuple(size[i] for i in l2))))
-    s3d = dict(zip(l3, contig_strides(tuple(size[i] for i in l3))))
-    M = prod(size[i] for i in mm)
-    return Chain3Spec(
-        D=D,
-        m=tuple((d, st[0], st[1]) for d, st in gm),
-        sa_b=sa[b],
-        sa_c=sa[c],
-        off_k1=off_k1,
-        off_co=off_co,
-        w1s=(s1d[k1[0]], s1d[k1[1]], s1d[h1], s1d[x]),
-        w2s=(s2d[h1], s2d[b], s2d[h2], s2d[y]),
-        w3s=(s3d[h2], s3d[c], s3d[h3], s3d[z]),
-        out_inds=tuple(lc),
-        out_shape=tuple(size[i] for i in lc),
-        mults=3 * M * D**6,
-        a_size=prod(size[i] for i in la),
-        c_size=prod(size[i] for i in lc),
     )

@@ -196,7 +196,7 @@ def fused_pair_count(tree, dtype="float32"):
     """Launches of the executor's plan that are fused pairs / triples of streaming steps."""
     from .executor import TreeExecutor
 
-    return sum(1 for e in TreeExecutor(tree, dtype).plan if e[0] in ("chain2", "chain3"))
+    return sum(1 for e in TreeExecutor(tree, dtype).plan if e[0] == "chain2")
 
 
 def sweep_ssa_2d(Lx, Ly):

@@ -220,9 +220,9 @@ class ContractionProgram:
             # same ndarray object may have been written to by the next call -- it is uploaded again every time
             device_in = all(isinstance(a, Array) and a is x for a, x in zip(arrays, xs))
             self._keep_src, self._keep_ptrs = (list(arrays), ptrs) if device_in else (None, None)
-        # lane 0 = the caller's stream (as in launch-by-launch execution); QAMD_PROGRAM_OWN_LANE0=1: a pool stream of its
+        # lane 0 = the caller's stream (as in launch-by-launch execution); options.program_own_lane0: a pool stream of its
         # own, forked from / joined to the caller's (what lane priorities need)
-        own0 = os.environ.get("QAMD_PROGRAM_OWN_LANE0", "0") == "1"
+        own0 = bool(getattr(self.executor, "options", None) and self.executor.options.program_own_lane0)
         streams = dev.lane_streams(self.nlanes, self._priorities, own_lane0=own0)
         caller = dev.torch.cuda.current_stream(dev.tdev)
         # consecutive replays share the pool and the output buffer: stream order protects them on ONE caller stream; a

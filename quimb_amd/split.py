@@ -146,6 +146,16 @@ def array_split(x, method="svd", absorb="both", max_bond=None, cutoff=1e-10, cut
             warnings.warn("Using 'svd:rand' without `max_bond` is inefficient, consider simply using 'svd' or 'svd:eig' instead.")
         if opts.get("right") is None and mode in ("right", "lorthog", "rfactor", "left", "rorthog", "lfactor"):
             opts = dict(opts, right=mode in ("right", "lorthog", "rfactor"))
+        kk = min(x.shape) if max_bond is None or max_bond < 0 else min(int(max_bond), *x.shape)
+        if kk >= min(min(x.shape), kk + int(opts.get("oversample", 10))) and mode in ("right", "lorthog", "rfactor") \
+                and opts.get("right") is not False:
+            # no truncation below the sketch: the reduced factor is not decomposed (decomp.py:1808-1815)
+            q, _, b = linalg.svd_rand(x, max_bond, **dict(opts, right=True, factors_only=True))
+            return (q if mode != "rfactor" else None), None, (b if mode != "lorthog" else None)
+        if kk >= min(min(x.shape), kk + int(opts.get("oversample", 10))) and mode in ("left", "rorthog", "lfactor") \
+                and opts.get("right") is not True:
+            b, _, qh = linalg.svd_rand(x, max_bond, **dict(opts, right=False, factors_only=True))
+            return (b if mode != "rorthog" else None), None, (qh if mode != "lfactor" else None)
         u, s, vh = linalg.svd_rand(x, max_bond, **opts)
         cutoff = 0.0
     elif method == "rsvd":

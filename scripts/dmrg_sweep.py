@@ -17,6 +17,7 @@ nsweeps = int(sys.argv[3]) if len(sys.argv) > 3 else 2
 split = sys.argv[4] if len(sys.argv) > 4 else "eig"
 seq = sys.argv[5] if len(sys.argv) > 5 else "R"            # the reference's default sweeps rightwards every time
 canon = sys.argv[6] if len(sys.argv) > 6 else "qr"
+oversample = int(sys.argv[7]) if len(sys.argv) > 7 else 10   # split=rand: 0 = no decomposition of the reduced factor (static bond)
 import quimb_amd.dmrg as qdm
 
 # where a sweep's wall time goes (device sync around every phase: slightly pessimistic)
@@ -49,8 +50,9 @@ if os.environ.get("QAMD_DMRG_PHASES", "1") != "0":
     qdm.DMRG2._grow_right = timed("environment update", qdm.DMRG2._grow_right)
     qdm.TNLinearOperator = timed("operator setup", qdm.TNLinearOperator)
 
-dm = DMRG2(mpo_ham_heis(L), bond_dims=[chi], cutoffs=1e-10, split=split, canonize=canon)
-print(f"DMRG2 Heisenberg L={L} fp64, max bond {chi}, split={split}, canonize={canon}; start bond {dm.max_bond()}")
+dm = DMRG2(mpo_ham_heis(L), bond_dims=[chi], cutoffs=1e-10, split=split, canonize=canon, split_opts={"oversample": oversample})
+print(f"DMRG2 Heisenberg L={L} fp64, max bond {chi}, split={split}" + (f" (oversample {oversample})" if split == "rand" else "")
+      + f", canonize={canon}; start bond {dm.max_bond()}")
 prev = "0"
 for k in range(nsweeps):
     torch.cuda.synchronize()

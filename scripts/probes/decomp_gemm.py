@@ -9,8 +9,8 @@ import quimb_amd as qa
 from quimb_amd import linalg
 
 
-def timed(fn, reps=5):
-    fn(); torch.cuda.synchronize()
+def timed(fn, reps=8):
+    fn(); fn(); fn(); torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(reps):
         out = fn()
@@ -29,7 +29,7 @@ for refine in (False, True):
 g = torch.randn(522, 522, dtype=torch.float64, device="cuda"); g = g @ g.T + 522 * torch.eye(522, dtype=torch.float64, device="cuda")
 for n in (512, 522, 1024):
     gg = g[:n, :n].contiguous() if n <= 522 else (lambda x: x @ x.T + n * torch.eye(n, dtype=torch.float64, device="cuda"))(torch.randn(n, n, dtype=torch.float64, device="cuda"))
-    t1, _ = timed(lambda: torch.linalg.cholesky(gg))
+    t1, _ = timed(lambda: torch.linalg.cholesky_ex(gg))
     t2, _ = timed(lambda: torch.linalg.eigh(gg))
     L = torch.linalg.cholesky(gg)
     b = torch.randn(1024, n, dtype=torch.float64, device="cuda")
@@ -53,4 +53,8 @@ for q_ in (0, 1):
         s = S.to_numpy()
         rec = (U.to_numpy() * s) @ VH.to_numpy()
         best = (u[:, :len(s)] * spec[:len(s)]) @ v[:, :len(s)].T
-        print(f"split svd_rand k=512 q={q_} stabilize={stab!s:5} {t:8.3f} ms  kept {len(s)}  s rel err (first 400) {np.abs(s[:400] / exact[:400] - 1).max():.1e}  |rec - best rank-k| {np.abs(rec - best).max():.1e}")
+        print(f"split svd_rand k=512 q={q_} stabilize={stab!s:5} {t:8.3f} ms  kept {len(s)}  s rel err (first 400) {np.abs(s[:300] / exact[:300] - 1).max():.1e}  |rec - best rank-k| {np.abs(rec - best).max():.1e}")
+
+t, (Q, none, B) = timed(lambda: linalg.svd_rand(x, 512, oversample=0, num_iterations=0, method_lorthog="qr:cholesky", factors_only=True, right=True))
+rec = Q.to_numpy() @ B.to_numpy()
+print(f"split svd_rand k=512 oversample=0 factors only  {t:8.3f} ms  |Q B - x| {np.abs(rec - x.to_numpy()).max():.1e} (sigma_513 = {spec[512]:.1e})  orth {np.abs(Q.to_numpy().T @ Q.to_numpy() - np.eye(512)).max():.1e}")

@@ -115,36 +115,6 @@ class EmuDevice:
         assert len(np.unique(idx)) == idx.size
         c[idx] = Cv
 
-    def contract_chain3(self, c3, dtype, a, w1, w2, w3, c, ep=None):
-        """Semantics of qamd_contract_chain3 (see include/quimb_amd.h)."""
-        self.calls["chain3"] = self.calls.get("chain3", 0) + 1
-        D = c3.D
-        ar = np.arange(D, dtype=np.int64)
-        gather = lambda w, st: w[(ar * st[0])[:, None, None, None] + (ar * st[1])[None, :, None, None]
-                                 + (ar * st[2])[None, None, :, None] + (ar * st[3])[None, None, None, :]]
-        W1, W2, W3 = gather(w1, c3.w1s), gather(w2, c3.w2s), gather(w3, c3.w3s)   # [bond in, carried, bond out, new]
-        om_a = _offsets([(d, sa) for d, sa, _ in c3.m], 1)
-        om_c = _offsets([(d, sc) for d, _, sc in c3.m], 1)
-        ok1 = np.asarray(c3.off_k1, dtype=np.int64).reshape(D, D)
-        A = a[ok1[:, :, None, None, None] + (ar * c3.sa_b)[None, None, :, None, None]
-              + (ar * c3.sa_c)[None, None, None, :, None] + om_a[None, None, None, None, :]]    # [h, a, b, c, m]
-        X1 = np.einsum("habcm,hapx->pxbcm", A, W1)
-        X2 = np.einsum("pxbcm,pbqy->qyxcm", X1, W2)
-        Cv = np.einsum("qyxcm,qcrz->rmxyz", X2, W3)                                              # [h3, m, x, y, z]
-        if ep is not None:
-            sc = 1.0
-            for t in ep[:4]:
-                if t is not None and t.max() > 0:
-                    sc *= float(t.max())
-            Cv = Cv * np.asarray(1.0 / sc, dtype=Cv.real.dtype)
-            if ep[4] is not None and Cv.size:
-                ep[4][0] = max(ep[4][0], np.max(np.abs(Cv)))
-        oco = np.asarray(c3.off_co, dtype=np.int64)
-        idx = (oco[:, None, None, None, None] + om_c[None, :, None, None, None] + (ar * D * D)[None, None, :, None, None]
-               + (ar * D)[None, None, None, :, None] + ar[None, None, None, None, :])
-        assert len(np.unique(idx)) == idx.size
-        c[idx] = Cv
-
     def permute(self, dst, src, shape, strides, offset, dtype):
         self.calls["permute"] += 1
         n = int(np.prod(shape)) if len(shape) else 1

@@ -28,9 +28,8 @@ class RecordOnlyDevice(HipDevice):
         self.record = None
         self.profile = None
         self.profile_min_mults = 0
-        self.force_tile_cfg = int(os.environ.get("QAMD_TILE_CFG", "-1"))
-        self.force_split_k = int(os.environ.get("QAMD_SPLIT_K", "0"))
-        self.force_kernel = int(os.environ.get("QAMD_KERNEL", "0"))
+        self.force_tile_cfg, self.force_split_k, self.force_kernel = -1, 0, 0
+        self.force_chain2, self.micro_arena = "auto", "auto"
 
     def stream(self):
         return None

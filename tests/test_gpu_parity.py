@@ -103,46 +103,6 @@ def test_gemmd(hip):
     assert any("split_k=" in n and not n.endswith("split_k=1") for n in names), names
 
 
-@pytest.mark.parametrize("Lx,Ly,D", [(6, 6, 4), (8, 8, 2), (5, 8, 4), (3, 8, 6), (3, 9, 6)])
-def test_fused_triples(hip, Lx, Ly, D):
-    """Three adjacent interior site absorptions in ONE launch (chain3 kernel, chunk state exchanged through
-    LDS): same value as the fp64 oracle, with and without exponent stripping, for every workgroup width, and
-    the same as the executor with triples switched off."""
-    import os
-
-    from oracle import np_oracle as orc
-    import quimb_amd as qa
-
-    arrays, inputs = orc.tn2d_rand(Lx, Ly, D, seed=21, dtype="float32")
-    size = {ix: D for t in inputs for ix in t}
-    tree = qa.ContractionTree(inputs, (), size, path=qa.sweep_path_2d(Lx, Ly))
-    wm, we = orc.oracle_array_contract([a.astype(np.float64) for a in arrays], inputs, (), path=tree.get_path(),
-                                       strip_exponent=True)
-    want = wm.item() * 10.0**we
-    os.environ["QAMD_CHAIN3"] = "1"      # opt-in (the fused pairs of chain2q.hip are faster per site)
-    try:
-        ex = qa.TreeExecutor(tree, "float32")
-    finally:
-        del os.environ["QAMD_CHAIN3"]
-    assert any(e[0] == "chain3" for e in ex.plan)
-    for nw in ("8", "4", "12"):
-        os.environ["QAMD_C3_NW"] = nw
-        try:
-            hip.profile = []
-            m, e = ex(arrays, strip_exponent=True)
-            names = {n for (_, _, n, _, _, _) in hip.profile}
-            hip.profile = None
-            assert f"chain3_kernel<{D}, {nw}>" in names, names
-            assert m.to_numpy().item() * 10.0**e == pytest.approx(want, rel=1e-6)
-            assert ex(arrays).to_numpy().item() == pytest.approx(want, rel=1e-6)
-        finally:
-            del os.environ["QAMD_C3_NW"]
-            hip.profile = None
-    ex2 = qa.TreeExecutor(tree, "float32")   # default: no triples
-    assert not any(e[0] == "chain3" for e in ex2.plan) and ex2.flops() == ex.flops()
-    assert ex2(arrays).to_numpy().item() == pytest.approx(want, rel=1e-6)
-
-
 @pytest.mark.parametrize("Lx,Ly,D,dtype", [(4, 8, 2, "float64"), (4, 8, 2, "float32"), (3, 6, 4, "float32"),
                                            (4, 10, 4, "float32"), (5, 12, 2, "float32"),
                                            (3, 5, 4, "float64"), (3, 8, 6, "float32"), (3, 7, 6, "float64")])
@@ -160,59 +120,45 @@ def test_fused_pairs(hip, Lx, Ly, D, dtype):
     wm, we = orc.oracle_array_contract([a.astype(np.float64) for a in arrays], inputs, (), path=tree.get_path(),
                                        strip_exponent=True)
     want = wm.item() * 10.0**we
-    os.environ["QAMD_CHAIN2"] = "1"
-    os.environ["QAMD_REGROUP"] = "0"     # the tree exactly as given: every row has a start and an end pair
-    try:
-        ex = qa.TreeExecutor(tree, dtype)
-    finally:
-        del os.environ["QAMD_CHAIN2"]
-        del os.environ["QAMD_REGROUP"]
+    opts = qa.get_options()
+    # the tree exactly as given (no regrouping): every row has a start and an end pair
+    ex = qa.TreeExecutor(tree, dtype, options=opts.replace(fuse_pairs=True, regroup=False))
     assert any(e[0] == "chain2" for e in ex.plan)
     exr = qa.TreeExecutor(tree, dtype)   # default: small operands regrouped where that is a clear win
     assert exr.flops() <= ex.flops()
     assert exr(arrays).to_numpy().item() == pytest.approx(want, rel=1e-6 if dtype == "float32" else 1e-11)
-    if dtype == "float32":   # the opt-in super-chunk variant (whole-line loads + lane swaps) must agree as well
-        os.environ["QAMD_C2R_SC"] = "1"
-        try:
-            msc, esc = ex(arrays, strip_exponent=True)
-        finally:
-            del os.environ["QAMD_C2R_SC"]
-        assert msc.to_numpy().item() * 10.0**esc == pytest.approx(want, rel=1e-6)
     if dtype == "float32":   # row-start and row-end pairs are fused too (register kernel only)
         assert any(e[0] == "chain2" and e[5].k1_single for e in ex.plan)
         assert any(e[0] == "chain2" and e[5].no_n2out for e in ex.plan)
     # (the multi-block variant chain2q takes the interior pairs of the larger lattices since its size bar was lowered:
-    # pin the register kernel chain2r for this pass, chain2q has its own test)
-    os.environ["QAMD_CHAIN2Q"] = "0"
+    # pin the register kernel chain2r for this pass -- the plan's QAMD_CHAIN2_FORCE_REG flag -- chain2q has its own test)
+    hip.force_chain2 = "reg"
     try:
         hip.profile = []
         m, e = ex(arrays, strip_exponent=True)
         names = {n.split("<")[0] for (_, _, n, _, _, _) in hip.profile}
     finally:
-        del os.environ["QAMD_CHAIN2Q"]
+        hip.force_chain2 = "auto"
         hip.profile = None
     assert names & {"chain2_kernel", "chain2r_kernel"}
     if dtype == "float32":
-        # fp32 runs the register-resident variant; the LDS-tile kernel must agree too
+        # fp32 runs the register-resident variant; the LDS-tile kernel (pinned: QAMD_CHAIN2_FORCE_LDS; it has no row-start /
+        # row-end shapes, so the plan is built without them) must agree too
         assert "chain2r_kernel" in names
-        os.environ["QAMD_CHAIN2R"] = "0"
+        hip.force_chain2 = "lds"
         try:
             hip.profile = []
-            v1 = qa.TreeExecutor(tree, dtype)(arrays).to_numpy().item()
+            v1 = qa.TreeExecutor(tree, dtype, options=opts.replace(chain2_kernel="lds"))(arrays).to_numpy().item()
             names1 = {n.split("<")[0] for (_, _, n, _, _, _) in hip.profile}
         finally:
-            del os.environ["QAMD_CHAIN2R"]
+            hip.force_chain2 = "auto"
             hip.profile = None
         assert "chain2_kernel" in names1
         assert v1 == pytest.approx(want, rel=1e-6)
     rel = 1e-6 if dtype == "float32" else 1e-11
     assert m.to_numpy().item() * 10.0**e == pytest.approx(want, rel=rel)
     assert ex(arrays).to_numpy().item() == pytest.approx(want, rel=rel)
-    os.environ["QAMD_CHAIN2"] = "0"
-    try:
-        ex0 = qa.TreeExecutor(tree, dtype)
-    finally:
-        del os.environ["QAMD_CHAIN2"]
+    ex0 = qa.TreeExecutor(tree, dtype, options=opts.replace(fuse_pairs=False))
     assert ex0(arrays).to_numpy().item() == pytest.approx(want, rel=rel)
 
 
@@ -232,45 +178,27 @@ def test_fused_pairs_quad(hip, Lx, Ly, D):
     wm, we = orc.oracle_array_contract([a.astype(np.float64) for a in arrays], inputs, (), path=tree.get_path(),
                                        strip_exponent=True)
     want = wm.item() * 10.0**we
-    os.environ["QAMD_CHAIN2Q"] = "2"     # no size threshold: the small test networks take the kernel too
-    os.environ["QAMD_REGROUP"] = "0"
+    hip.force_chain2 = "quad"            # QAMD_CHAIN2_FORCE_QUAD: no size threshold, the small test networks take the kernel too
     try:
-        ex = qa.TreeExecutor(tree, "float32")
+        ex = qa.TreeExecutor(tree, "float32", options=qa.get_options().replace(regroup=False))
         hip.profile = []
         m, e = ex(arrays, strip_exponent=True)
         names = {n for (_, _, n, _, _, _) in hip.profile}
         hip.profile = None
         plain = ex(arrays).to_numpy().item()
     finally:
-        del os.environ["QAMD_CHAIN2Q"]
-        del os.environ["QAMD_REGROUP"]
+        hip.force_chain2 = "auto"
         hip.profile = None
     for variant in (f"chain2q_kernel<{D}, 2, 1>", f"chain2q_kernel<{D}, 1, 1>", f"chain2q_kernel<{D}, 2, 0>"):
         assert variant in names, names
     assert m.to_numpy().item() * 10.0**e == pytest.approx(want, rel=1e-6)
     assert plain == pytest.approx(want, rel=1e-6)
-    os.environ["QAMD_CHAIN2Q"] = "0"
+    hip.force_chain2 = "reg"
     try:
         mr, er = qa.TreeExecutor(tree, "float32")(arrays, strip_exponent=True)
     finally:
-        del os.environ["QAMD_CHAIN2Q"]
+        hip.force_chain2 = "auto"
     assert mr.to_numpy().item() * 10.0**er == pytest.approx(want, rel=1e-6)
-    if D == 6:   # the opt-in two-waves-per-SIMD variant (chain2h.hip: 32-m chunks, v / x pairs in the lane halves)
-        os.environ["QAMD_CHAIN2H"] = "1"
-        os.environ["QAMD_CHAIN2Q"] = "2"
-        os.environ["QAMD_REGROUP"] = "0"
-        try:
-            exh = qa.TreeExecutor(tree, "float32")
-            hip.profile = []
-            mh, eh = exh(arrays, strip_exponent=True)
-            names_h = {n for (_, _, n, _, _, _) in hip.profile}
-        finally:
-            hip.profile = None
-            for k in ("QAMD_CHAIN2H", "QAMD_CHAIN2Q", "QAMD_REGROUP"):
-                del os.environ[k]
-        for variant in ("chain2h_kernel<6, 2, 1>", "chain2h_kernel<6, 1, 1>", "chain2h_kernel<6, 2, 0>"):
-            assert variant in names_h, names_h
-        assert mh.to_numpy().item() * 10.0**eh == pytest.approx(want, rel=1e-6)
 
 
 @pytest.mark.parametrize("dtype", ["complex64", "complex128"])
@@ -513,11 +441,7 @@ def test_full_size_10x10_D6_properties(hip):
     # reproducibility: same executor, same inputs -> bit-identical (no atomics in the data path)
     assert log_value(ex(arrays, strip_exponent=True)) == (s0, l0)
     # fused pairs (chain2r) against one launch per step (sweep kernels)
-    os.environ["QAMD_CHAIN2"] = "0"
-    try:
-        ex_unfused = qa.TreeExecutor(tree, "float32")
-    finally:
-        del os.environ["QAMD_CHAIN2"]
+    ex_unfused = qa.TreeExecutor(tree, "float32", options=qa.get_options().replace(fuse_pairs=False))
     assert not any(e[0] == "chain2" for e in ex_unfused.plan) and any(e[0] == "chain2" for e in ex.plan)
     s1, l1 = log_value(ex_unfused(arrays, strip_exponent=True))
     assert s1 == s0 and abs(l1 - l0) < 1e-5          # 1e-5 in log10 = 2.3e-5 relative

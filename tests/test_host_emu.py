@@ -165,11 +165,7 @@ def test_fused_pairs_in_sweeps(emu, Lx, Ly, D, dtype):
     size = {ix: D for t in inputs for ix in t}
     tree = qa.ContractionTree(inputs, (), size, path=qa.sweep_path_2d(Lx, Ly))
     want = orc.oracle_array_contract([a.astype(np.float64) for a in arrays], inputs, (), path=tree.get_path())
-    os.environ["QAMD_CHAIN2"] = "1"
-    try:
-        ex = qa.TreeExecutor(tree, dtype)
-    finally:
-        del os.environ["QAMD_CHAIN2"]
+    ex = qa.TreeExecutor(tree, dtype, options=qa.get_options().replace(fuse_pairs=True))
     nfused = sum(1 for e in ex.plan if e[0] == "chain2")
     assert nfused >= 1, ex.plan
     assert ex.flops() == ex.tree.total_flops(dtype)  # fusion does not change the FLOP count
@@ -178,54 +174,9 @@ def test_fused_pairs_in_sweeps(emu, Lx, Ly, D, dtype):
     assert emu.calls.get("chain2", 0) == nfused
     m, e = ex(arrays, strip_exponent=True)
     checks.assert_close(m.to_numpy() * 10.0**e, want, dtype)
-    os.environ["QAMD_CHAIN2"] = "0"
-    try:
-        ex0 = qa.TreeExecutor(tree, dtype)
-    finally:
-        del os.environ["QAMD_CHAIN2"]
+    ex0 = qa.TreeExecutor(tree, dtype, options=qa.get_options().replace(fuse_pairs=False))
     assert not any(e[0] == "chain2" for e in ex0.plan)
     checks.assert_close(ex0(arrays).to_numpy(), want, dtype)
-
-
-@pytest.mark.parametrize("Lx,Ly,D", [(6, 6, 4), (8, 8, 2), (4, 7, 4)])
-def test_fused_triples_in_sweeps(emu, Lx, Ly, D):
-    """Three adjacent interior site absorptions are planned as ONE chain3 launch (neither intermediate
-    materialised); value, FLOP count and exponent stripping agree with the oracle / the unfused plan."""
-    import os
-
-    from oracle import np_oracle as orc
-    import quimb_amd as qa
-
-    arrays, inputs = orc.tn2d_rand(Lx, Ly, D, seed=9, dtype="float32")
-    size = {ix: D for t in inputs for ix in t}
-    tree = qa.ContractionTree(inputs, (), size, path=qa.sweep_path_2d(Lx, Ly))
-    want = orc.oracle_array_contract([a.astype(np.float64) for a in arrays], inputs, (), path=tree.get_path())
-    os.environ["QAMD_CHAIN3"] = "1"      # opt-in
-    try:
-        ex = qa.TreeExecutor(tree, "float32")
-    finally:
-        del os.environ["QAMD_CHAIN3"]
-    n3 = sum(1 for e in ex.plan if e[0] == "chain3")
-    assert n3 >= 1, [e[0] for e in ex.plan]
-    assert ex.flops() == ex.tree.total_flops("float32")
-    checks.assert_close(ex(arrays).to_numpy(), want, "float32")
-    assert emu.calls.get("chain3", 0) == n3
-    m, e = ex(arrays, strip_exponent=True)
-    checks.assert_close(m.to_numpy() * 10.0**e, want, "float32")
-    ex0 = qa.TreeExecutor(tree, "float32")   # default: pairs only
-    assert not any(e[0] == "chain3" for e in ex0.plan)
-    assert ex0.algorithmic_bytes() >= ex.algorithmic_bytes()     # the triple never moves more bytes for the same FLOPs
-    checks.assert_close(ex0(arrays).to_numpy(), want, "float32")
-
-
-def test_chain3_chunk_table_matches_library():
-    from quimb_amd import _lib
-    from quimb_amd.pairwise import chain3_chunk
-
-    lib = _lib.load()
-    for D in range(1, 9):
-        assert lib.qamd_chain3_chunk(0, D) == chain3_chunk("float32", D)
-        assert lib.qamd_chain3_chunk(1, D) == chain3_chunk("float64", D)
 
 
 def test_chain2_chunk_table_matches_library():

@@ -9,7 +9,9 @@ import numpy as np
 import pytest
 
 
-def _describe(a_inds, a_shape, b_inds, b_shape, out, dtype="float32", env=None, aligns=(16, 16, 16)):
+def _describe(a_inds, a_shape, b_inds, b_shape, out, dtype="float32", pin=None, aligns=(16, 16, 16)):
+    """``pin``: (kernel, tile_cfg) set on the plan BEFORE finalize -- the library's only steering input (it reads no
+    environment variable): kernel -2 = no MFMA GEMM kernels, -5 / -6 = gemmk / gemmd with tile 16 ta + tb."""
     from quimb_amd import _lib
     from quimb_amd.device import dtype_code, fill_plan_struct
     from quimb_amd.pairwise import plan_pair
@@ -18,16 +20,9 @@ def _describe(a_inds, a_shape, b_inds, b_shape, out, dtype="float32", env=None, 
     st = plan_pair(tuple(a_inds), tuple(a_shape), tuple(b_inds), tuple(b_shape), tuple(out), True)
     p = fill_plan_struct(st.spec, dtype_code(np.dtype(dtype)))
     p.tile_cfg, p.split_k, p.kernel = -1, 0, 0
-    old = {k: os.environ.get(k) for k in (env or {})}
-    os.environ.update(env or {})
-    try:
-        assert lib.qamd_pair_plan_finalize(C.byref(p), *aligns) == 0
-    finally:
-        for k, v in old.items():
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = v
+    if pin is not None:
+        p.kernel, p.tile_cfg = pin
+    assert lib.qamd_pair_plan_finalize(C.byref(p), *aligns) == 0
     buf = C.create_string_buffer(200)
     lib.qamd_pair_describe(C.byref(p), buf, 200)
     return buf.value.decode(), p
@@ -61,9 +56,9 @@ def test_what_gemmk_does_not_cover_keeps_the_older_kernels():
     assert not k5("km", (512, 2048), "kn", (512, 64), "mn")                              # N < 128: streaming / tiled kernels
     assert not k5("km", (512, 512), "kn", (512, 512), "mn")                              # 16 tiles: split-K kernels fill the chip
     assert not k5("km", (512, 2046), "kn", (512, 2048), "mn")                            # M % 4
-    assert not k5("km", (512, 2048), "kn", (512, 2048), "mn", env={"QAMD_GEMMK": "0"})   # switched off
+    assert not k5("km", (512, 2048), "kn", (512, 2048), "mn", pin=(-2, -1))               # pinned away from it
     assert not k5("km", (512, 2048), "kn", (512, 2048), "mn", aligns=(8, 16, 16))        # operand not 16-byte aligned
-    name, p = _describe("km", (512, 512), "kn", (512, 512), "mn", env={"QAMD_GEMMK_TILE": "22"})
+    name, p = _describe("km", (512, 512), "kn", (512, 512), "mn", pin=(-5, 16 * 2 + 2))
     assert p.kernel == 5 and name == "gemmk_kernel<2, 2, 3, 2>"                          # pinning overrides the tile floor
     # C contiguous along m: the operands swap roles inside the launch, the plan is the same kind
     assert k5("km", (512, 2048), "kn", (512, 4096), "nm")
@@ -99,13 +94,13 @@ def test_what_gemmd_does_not_cover():
     assert not k6("mk", (2048, 520), "kn", (520, 2048), "mn")                              # K % 16
     assert not k6("mk", (2048, 48), "kn", (48, 2048), "mn")                                # K < 64
     assert not k6("mk", (2047, 512), "kn", (512, 2048), "mn")                              # odd M: granules of two elements
-    assert not k6("mk", (2048, 512), "kn", (512, 2048), "mn", env={"QAMD_GEMMD": "0"})    # switched off
+    assert not k6("mk", (2048, 512), "kn", (512, 2048), "mn", pin=(-2, -1))                # pinned away from it
     assert not k6("mk", (2048, 512), "kn", (512, 2048), "mn", aligns=(8, 16, 16))         # operand not 16-byte aligned
     assert not k6("mk", (128, 512), "kn", (512, 128), "mn")                                # tiny grid: the generic kernels
     # K in two groups that cannot fuse (their order differs between the operands): the innermost one holds the k-tiles
     assert not k6("muk", (2048, 32, 24), "kun", (24, 32, 2048), "mn")                      # ... 24: not a multiple of 16
     assert k6("muk", (2048, 24, 32), "kun", (32, 24, 2048), "mn")                          # ... 32: fine, the outer group is free
-    name, p = _describe("mk", (128, 512), "kn", (512, 128), "mn", dtype="float64", env={"QAMD_GEMMD_TILE": "21"})
+    name, p = _describe("mk", (128, 512), "kn", (512, 128), "mn", dtype="float64", pin=(-6, 16 * 2 + 1))
     assert p.kernel == 6 and name.startswith("gemmd_kernel<2, 1, true, false, false>")     # pinning overrides the floors
 
 

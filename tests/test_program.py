@@ -99,13 +99,12 @@ def test_later_chains_are_held_behind_the_first_joins_chains(recdev, monkeypatch
     for w in (2, 4, 8):
         sh = QuadrantSharding(inputs, size, 10, 10, w)
         assert QuadrantRank(sh, 0, "float32").executor.hold_late is None
-    monkeypatch.setenv("QAMD_HOLD_LATE", "0")
-    assert qa.TreeExecutor(ex.tree, "float32").hold_late is None
+    assert qa.TreeExecutor(ex.tree, "float32", options=qa.get_options().replace(hold_late="0")).hold_late is None
     # a small network with the rule forced on: the program records one wait per (late lane, early lane) on top of the
     # fork and the cross-lane hand-overs, and stays in join order (no plain-order twin)
-    monkeypatch.setenv("QAMD_HOLD_LATE", "1")
     arrays, inputs, size = _network(6, 3, "float32")
-    ex = qa.TreeExecutor(qa.ContractionTree(inputs, (), size, path=qa.quadrant_path_2d(6, 6)), "float32")
+    ex = qa.TreeExecutor(qa.ContractionTree(inputs, (), size, path=qa.quadrant_path_2d(6, 6)), "float32",
+                         options=qa.get_options().replace(hold_late="1"))
     assert ex.hold_late is not None
     prog = ex.program([qa.asarray(a) for a in arrays], strip_exponent=True)
     assert prog.executor is ex
@@ -113,7 +112,6 @@ def test_later_chains_are_held_behind_the_first_joins_chains(recdev, monkeypatch
                 if o in ex._producer and ex.lanes[ex._producer[o]] != ex.lanes[i])
     assert prog.num_ops - prog.num_launches == (ex.nlanes - 1) + cross + len(ex.hold_late[1]) * len(ex.hold_late[2])
     monkeypatch.setattr(qe, "HOLD_LATE_MIN_MULTS", 1.0)
-    monkeypatch.delenv("QAMD_HOLD_LATE")
     assert qa.TreeExecutor(ex.tree, "float32").hold_late is not None
 
 
@@ -141,11 +139,10 @@ def test_expressions_record_their_own_program(recdev, monkeypatch):
     del expr, prog
     gc.collect()
     assert qc._PROGRAM_POOL[0] == base
-    for env, val in (("QAMD_AUTO_PROGRAM", "0"), ("QAMD_AUTO_PROGRAM_MAX_BYTES", "1000"), ("QAMD_AUTO_PROGRAM_TOTAL_BYTES", "1000")):
-        monkeypatch.setenv(env, val)
-        expr = mk()
+    for kw in (dict(auto_program=False), dict(auto_program_max_bytes=1000), dict(auto_program_total_bytes=1000)):
+        with qa.exec_options(**kw):
+            expr = mk()             # an expression keeps the options it was BUILT with
         assert [expr._auto_program(xs) for _ in range(4)] == [None] * 4 and expr._program is False
-        monkeypatch.delenv(env)
     # host arrays never start one; a tree of fewer than four launches is not worth one
     expr = mk()
     assert [expr._auto_program(arrays) for _ in range(4)] == [None] * 4
