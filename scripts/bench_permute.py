@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Permute kernel alone: correctness against torch on the same device data + achieved HBM GB/s
-(2 x itemsize bytes per element).  QAMD_PERMUTE_STREAM=0 runs the tile-per-workgroup kernel for comparison."""
+(2 x itemsize bytes per element)."""
 import os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

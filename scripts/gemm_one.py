@@ -10,9 +10,9 @@ from quimb_amd.ops import run_pair_step
 m, n, k = (int(x) for x in sys.argv[1:4])
 tile = sys.argv[4] if len(sys.argv) > 4 else "0"
 iters = int(sys.argv[5]) if len(sys.argv) > 5 else 5
-if tile != "0":
-    os.environ["QAMD_GEMMK_TILE"] = tile
 dev = qa.default_device()
+if tile != "0":      # pin the workgroup tile: plan inputs kernel = -5, tile_cfg = 16 ta + tb (the library reads no environment)
+    dev.force_kernel, dev.force_tile_cfg = -5, 16 * (int(tile) // 10) + int(tile) % 10
 fill = os.environ.get("QAMD_GEMM_FILL", "rand")
 ta = (torch.rand(k, m, device=dev.tdev, dtype=torch.float32) - 0.5) if fill == "rand" else torch.zeros(k, m, device=dev.tdev)
 tb = (torch.rand(k, n, device=dev.tdev, dtype=torch.float32) - 0.5) if fill == "rand" else torch.zeros(k, n, device=dev.tdev)

@@ -40,17 +40,14 @@ for (m, n, k) in shapes:
     out = qa.Array.empty((m, n), "float32", dev)
     step = plan_pair(("k", "m"), (k, m), ("k", "n"), (k, n), ("m", "n"), True)
     res = []
-    os.environ["QAMD_GEMMK"] = "0"
+    dev.force_kernel, dev.force_tile_cfg = -2, -1          # plan input: automatic choice WITHOUT the MFMA GEMM kernels
     dev._pairs.clear()
     t = timeit(lambda: run_pair_step(step, a, b, out))
     res.append(f"old {2*m*n*k/t/1e12:6.1f}")
-    os.environ.pop("QAMD_GEMMK")
+    dev.force_kernel = 0
     errs = []
     for tl in tiles:
-        if tl is None:
-            os.environ.pop("QAMD_GEMMK_TILE", None)
-        else:
-            os.environ["QAMD_GEMMK_TILE"] = str(tl)
+        dev.force_kernel, dev.force_tile_cfg = (0, -1) if tl is None else (-5, 16 * (int(tl) // 10) + int(tl) % 10)
         dev._pairs.clear()
         out._buf.zero_()
         try:
@@ -61,5 +58,5 @@ for (m, n, k) in shapes:
             res.append(f"{'auto:' + name.split('<')[1][:4] if tl is None else tl} {2*m*n*k/t/1e12:6.1f}")
         except Exception as e:
             res.append(f"{tl} fail({e})")
-    os.environ.pop("QAMD_GEMMK_TILE", None)
+    dev.force_kernel, dev.force_tile_cfg = 0, -1
     print(f"f32 {m}x{n}x{k}: library {2*m*n*k/t_lib/1e12:6.1f} TF | " + " | ".join(res) + f" | maxerr {max(errs):.2e} (K*2e-8={k*2e-8:.1e})", flush=True)

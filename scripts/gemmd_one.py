@@ -6,7 +6,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 kw = dict(a.split("=") for a in sys.argv[2:])
-os.environ["QAMD_GEMMD"] = kw.pop("gemmd", "1")
+use_gemmd = kw.pop("gemmd", "1") != "0"
 iters = int(kw.pop("iters", 5))
 import numpy as np
 import torch
@@ -18,6 +18,8 @@ dims = {k: int(v) for k, v in kw.items()}
 lhs, out = eq.split("->")
 ai, bi = lhs.split(",")
 rng = np.random.default_rng(0)
+if not use_gemmd:
+    qa.default_device().force_kernel = -2      # plan input: automatic choice without the MFMA GEMM kernels
 a = qa.asarray(rng.uniform(-0.5, 1.0, [dims[c] for c in ai]))
 b = qa.asarray(rng.uniform(-0.5, 1.0, [dims[c] for c in bi]))
 for _ in range(iters):

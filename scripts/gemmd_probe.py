@@ -31,7 +31,7 @@ for eq, dims in CASES:
     row = []
     ref = None
     for gd in ("0", "1"):
-        os.environ["QAMD_GEMMD"] = gd
+        dev.force_kernel = 0 if gd == "1" else -2       # plan input -2: automatic choice without the MFMA GEMM kernels
         dev._pairs.clear()
         dev.profile = []
         c = qa.einsum(eq, a, b)
@@ -52,4 +52,4 @@ for eq, dims in CASES:
         err = float(np.max(np.abs(x - ref)) / np.max(np.abs(ref)))
         row.append(f"{name}: {dt * 1e6:8.1f} us {flop / dt / 1e12:6.1f} TF (diff {err:.1e})")
     print(f"{eq:18s} {str(tuple(dims.values())):40s} | " + " | ".join(row))
-os.environ.pop("QAMD_GEMMD", None)
+dev.force_kernel = 0

@@ -51,14 +51,13 @@ for name, exx, xx, nst in (("circuit 16q", ex, xs, 266), ("MPS L=20", ex2, xs2, 
     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 20
     print(f"{name}, launch program: {dt*1e3:.3f} ms/contract = {dt/nst*1e6:.2f} us/step, {pr.num_launches} launches, pool {pr.pool_bytes/1e6:.1f} MB")
     del pr
-os.environ["QAMD_MICROTREE"] = "0"
-expr = qa.array_contract_expression(inputs_c, (), shapes=[a.shape for a in arrays_c], optimize="greedy", dtype="complex64", cache=False)
+with qa.exec_options(microtree=False):
+    expr = qa.array_contract_expression(inputs_c, (), shapes=[a.shape for a in arrays_c], optimize="greedy", dtype="complex64", cache=False)
 for _ in range(4): r = expr(*xs)
 torch.cuda.synchronize(); t0 = time.perf_counter()
 for _ in range(20): r = expr(*xs)
 torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 20
 print(f"circuit 16q through array_contract_expression (launch program from the third call on: {type(expr._program).__name__}): {dt*1e3:.3f} ms/contract, |err| {abs(r.item()-amp):.2e}")
-del os.environ["QAMD_MICROTREE"]
 # BASELINE config #2: 53-qubit depth-10 brickwork circuit, one amplitude, complex64 -- 895 tiny steps, width 9:
 # dispatch-bound, so the numbers are eager (one Python launch per step) vs one hipGraph replay
 arrays, inputs, _ = checks.random_circuit_network(53, 10, np.random.default_rng(0), "complex64", dense=False)

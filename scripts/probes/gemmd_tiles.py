@@ -12,7 +12,7 @@ for eq, dims in CASES:
     flop = 2.0 * np.prod([dims[c] for c in set(ai) | set(bi)])
     for tile in ("21", "31", "41", "51", "22", "32", "42", "52"):
         for sk in ("0", "1", "2", "4", "8"):
-            os.environ["QAMD_GEMMD_TILE"] = tile
+            dev.force_kernel, dev.force_tile_cfg = -6, 16 * int(tile[0]) + int(tile[1])
             dev.force_split_k = int(sk)
             dev._pairs.clear()
             dev.profile = []

@@ -9,7 +9,7 @@ for (m, n, k) in [(256, 256, 48), (256, 256, 64), (256, 256, 128), (256, 256, 72
     b = rng.uniform(-0.5, 0.5, (k, n)).astype(np.float32)
     want = a.astype(np.float64).T @ b.astype(np.float64)
     for tile in (44, 33, 22, 42, 24):
-        os.environ["QAMD_GEMMK_TILE"] = str(tile)
+        dev.force_kernel, dev.force_tile_cfg = -5, 16 * (tile // 10) + tile % 10
         dev._pairs.clear()
         got = qa.einsum("km,kn->mn", qa.asarray(a), qa.asarray(b)).to_numpy().astype(np.float64)
         err = np.abs(got - want)
