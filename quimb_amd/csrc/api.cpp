@@ -328,12 +328,18 @@ extern "C" int qamd_pair_plan_finalize(qamd_pair_plan* p, int64_t align_a, int64
     const int ev = 16 / es;  // elements per 16-byte vector
     int kern = 0, vc = 1;
     const int64_t d_in = n_inner_block(p);
+    // the innermost M group is a whole number of chunks -- or (round 5) it is not, but the whole bundle is and 16-byte
+    // stores never cross a piece of it (the last site of rows 2-4 of a boundary sweep: runs of 36 / 216 open-leg values,
+    // until now the generic tiled kernel at 0.13 of the HBM roof): the kernel then looks every row's C offset up
+    const int64_t l_in = p->nm >= 1 ? p->dim_m[p->nm - 1] : 0;
+    const bool z_chunks = l_in % (16 * ev) == 0 ||
+                          (d.M % (16 * ev) == 0 && l_in % 2 == 0 && (l_in * d_in) % ev == 0 && (16 * ev * d_in) % ev == 0);
     if (base_ok && p->nn >= 1 && d_in > 1 && p->sc_m[p->nm - 1] == d_in && p->vec_a >= ev &&
-        align_c % 16 == 0 && p->dim_m[p->nm - 1] % (16 * ev) == 0) {
+        align_c % 16 == 0 && z_chunks) {
       bool ok = true;
       for (int i = 0; i + 1 < p->nm; ++i) ok = ok && (p->sc_m[i] % ev == 0);
       for (int i = 0; i < p->nn; ++i) ok = ok && (p->sc_n[i] < d_in || p->sc_n[i] % ev == 0);
-      ok = ok && (stream_lds_bytes(d.K, d.N, es) + 4 * (d.N + d_in) * 16 * ev * es <= 80 * 1024);
+      ok = ok && (stream_lds_bytes(d.K, d.N, es) + 4 * (d.N + d_in) * 16 * ev * es + 4 * 16 * ev * 8 <= 80 * 1024);
       if (ok) { kern = 2; vc = ev; }
     }
     if (!kern && base_ok && p->sc_m[p->nm - 1] == 1 && stream_lds_bytes(d.K, d.N, es) <= 64 * 1024) {

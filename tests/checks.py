@@ -466,15 +466,41 @@ def check_stream_kernels(dtype, seed=8):
         ("ham,hx->axm", dict(h=4, a=5, m=8192, x=4)),     # X, two M groups
         ("km,kn->mn", dict(k=2, m=1 << 16, n=2)),         # gate-like, C row-major -> Z with d_in = 2
         ("lkr,kn->lnr", dict(l=64, k=4, r=1024, n=4)),    # 2-qubit gate on a state
+        # Z with chunks that straddle pieces of the innermost M group (round 5): the last site of rows 3 / 4 of a corner
+        # sweep -- the open-leg run is 36 / 216 long, the chunk 64 (fp32) or 32 (fp64) rows
+        ("hvab,hxvy->axby", dict(h=6, v=6, a=32, b=216, x=6, y=6)),
+        ("hvab,hxvy->axby", dict(h=6, v=6, a=128, b=36, x=6, y=6)),
+        ("vab,vxy->axby", dict(v=6, a=64, b=108, x=6, y=6)),            # K = 6, run of 108
+        ("hvcab,hxvy->caxby", dict(h=4, v=4, c=3, a=32, b=72, x=4, y=4)),   # three M groups, D = 4
     ]
+    dev = qa.default_device()
     for eq, dims in cases:
         lhs, out = eq.split("->")
         ai, bi = lhs.split(",")
         a = rand(rng, [dims[c] for c in ai], dtype)
         b = rand(rng, [dims[c] for c in bi], dtype)
         want = np.einsum(eq, a.astype(hi), b.astype(hi))
-        got = qa.einsum(eq, qa.asarray(a), qa.asarray(b))
+        prof = hasattr(dev, "describe_pair")
+        if prof:
+            dev.profile, dev.profile_min_mults = [], 0
+        try:
+            got = qa.einsum(eq, qa.asarray(a), qa.asarray(b))
+        finally:
+            names = [rec[2] for rec in (dev.profile or [])] if prof else []
+            if prof:
+                dev.profile = None
         assert_close(got.to_numpy(), want, dtype)
+        if prof and "axby" in out:          # on the HIP device: these land on the streaming kernel's Z path, not on the tiled one
+            assert any(n.startswith("stream_kernel<") and n.rstrip(">").endswith("true") for n in names), (eq, names)
+    # ... and through a tree with the fused exponent epilogue (scales in, absmax out of the Z stores)
+    a = rand(rng, (6, 6, 32, 216), dtype) * 1e20
+    s1 = rand(rng, (6, 6, 6, 6), dtype) * 1e-12
+    s2 = rand(rng, (6, 32, 6, 216, 6), dtype)
+    inputs = [("h", "v", "a", "b"), ("h", "x", "v", "y"), ("x", "a", "q", "b", "y")]
+    tree = qa.ContractionTree(inputs, ("q",), dict(h=6, v=6, a=32, b=216, x=6, y=6, q=6), path=[(0, 1), (0, 1)])
+    m, e = qa.TreeExecutor(tree, dtype)([a, s1, s2], strip_exponent=True)
+    want = np.einsum("hvab,hxvy,xaqby->q", a.astype(hi), s1.astype(hi), s2.astype(hi))
+    assert_close(m.to_numpy() * 10.0**e, want, dtype)
 
 
 FAST_TILE_CASES = [
