@@ -257,6 +257,24 @@ static bool gemmd_config(const qamd_pair_plan* p, const PairDims& d, int64_t ali
   return tiles >= 64 || te;       // tiny grids keep the generic kernels
 }
 
+// Z-mode streaming with a "break": the innermost M group (length l_in, C stride d_in) is not a whole number of chunks of
+// ``ch`` = 16 ev rows, but (i) l_in >= ch, so a chunk crosses its end at most once, (ii) A is contiguous across a suffix of
+// the M groups whose product R is a multiple of ch (chunks then never straddle a run of A), (iii) the break falls on a
+// 16-byte vector boundary of C.  Returns R (elements) or 0.
+static int64_t z_break_run(const qamd_pair_plan* p, int ev, int64_t d_in) {
+  const int64_t ch = 16 * ev;
+  if (p->nm < 2 || p->sa_m[p->nm - 1] != 1) return 0;
+  const int64_t l_in = p->dim_m[p->nm - 1];
+  if (l_in % ch == 0 || l_in < ch || (l_in * d_in) % ev || (ch * d_in) % ev) return 0;
+  int64_t run = l_in;
+  for (int g = p->nm - 2; g >= 0; --g) {
+    if (p->sa_m[g] != run) break;          // A no longer contiguous across this group
+    run *= p->dim_m[g];
+    if (run % ch == 0) return run;
+  }
+  return 0;
+}
+
 extern "C" int qamd_pair_plan_finalize(qamd_pair_plan* p, int64_t align_a, int64_t align_b, int64_t align_c) {
   PairDims d;
   int rc = pair_dims(p, d);
@@ -328,18 +346,17 @@ extern "C" int qamd_pair_plan_finalize(qamd_pair_plan* p, int64_t align_a, int64
     const int ev = 16 / es;  // elements per 16-byte vector
     int kern = 0, vc = 1;
     const int64_t d_in = n_inner_block(p);
-    // the innermost M group is a whole number of chunks -- or (round 5) it is not, but the whole bundle is and 16-byte
-    // stores never cross a piece of it (the last site of rows 2-4 of a boundary sweep: runs of 36 / 216 open-leg values,
-    // until now the generic tiled kernel at 0.13 of the HBM roof): the kernel then looks every row's C offset up
+    // the innermost M group is a whole number of chunks -- or (round 5) it is not, but it is at least a chunk long, A runs
+    // on contiguously across it and 16-byte stores never cross its end (the last site of row 4 of a boundary sweep: runs of
+    // 216 open-leg values, until now the generic tiled kernel at 0.13 of the HBM roof): a chunk then breaks at most once in C
     const int64_t l_in = p->nm >= 1 ? p->dim_m[p->nm - 1] : 0;
-    const bool z_chunks = l_in % (16 * ev) == 0 ||
-                          (d.M % (16 * ev) == 0 && l_in % 2 == 0 && (l_in * d_in) % ev == 0 && (16 * ev * d_in) % ev == 0);
+    const bool z_chunks = l_in % (16 * ev) == 0 || z_break_run(p, ev, d_in) > 0;
     if (base_ok && p->nn >= 1 && d_in > 1 && p->sc_m[p->nm - 1] == d_in && p->vec_a >= ev &&
         align_c % 16 == 0 && z_chunks) {
       bool ok = true;
       for (int i = 0; i + 1 < p->nm; ++i) ok = ok && (p->sc_m[i] % ev == 0);
       for (int i = 0; i < p->nn; ++i) ok = ok && (p->sc_n[i] < d_in || p->sc_n[i] % ev == 0);
-      ok = ok && (stream_lds_bytes(d.K, d.N, es) + 4 * (d.N + d_in) * 16 * ev * es + 4 * 16 * ev * 8 <= 80 * 1024);
+      ok = ok && (stream_lds_bytes(d.K, d.N, es) + 4 * (d.N + d_in) * 16 * ev * es <= 80 * 1024);
       if (ok) { kern = 2; vc = ev; }
     }
     if (!kern && base_ok && p->sc_m[p->nm - 1] == 1 && stream_lds_bytes(d.K, d.N, es) <= 64 * 1024) {
@@ -489,7 +506,7 @@ static bool sweep_config(const qamd_pair_plan* p, const StreamArgs& s, int V, in
   const int ev = 16 / es;
   int64_t kmax = 0;
   for (int i = 0; i < p->nk; ++i) kmax += (p->dim_k[i] - 1) * p->sa_k[i];
-  if (!(s.aligned && V == ev && s.KS <= 9 && (kmax + 16 * ev) * es < (1ll << 32)))
+  if (!(s.aligned && !s.c_break && V == ev && s.KS <= 9 && (kmax + 16 * ev) * es < (1ll << 32)))
     return false;
   static const int kPS[6] = {1, 2, 3, 4, 6, 9};
   PS = 9;
@@ -526,6 +543,16 @@ static void fill_stream_args(const qamd_pair_plan* p, const PairDims& d, StreamA
   s.sc_m_in = p->sc_m[p->nm - 1];
   s.aligned = (p->dim_m[p->nm - 1] % (16 * V) == 0) ? 1 : 0;
   s.inner_chunks = s.aligned ? (uint32_t)(p->dim_m[p->nm - 1] / (16 * V)) : 1;
+  s.l_in = (uint32_t)p->dim_m[p->nm - 1];
+  if (s.zmode && !s.aligned) {
+    // (finalize admitted this plan to the Z path through z_break_run: V = 16 / itemsize here)
+    const int64_t run = z_break_run(p, V, (int64_t)s.d_in);
+    if (run > 0) {
+      s.c_break = 1;
+      s.aligned = 1;                                        // loads: chunks are whole pieces of A's contiguous run
+      s.inner_chunks = (uint32_t)(run / (16 * V));
+    }
+  }
   s.chunks = (uint32_t)((d.M + 16 * V - 1) / (16 * V));
   const uint32_t target_waves = 256 * 4 * 3;
   s.chunks_per_wave = (s.chunks + target_waves - 1) / target_waves;

@@ -46,6 +46,8 @@ struct StreamArgs {
   uint32_t zmode;         // 1: C[.., m, n_in] with n_in stride-1 -> LDS-transposed stores
   uint32_t d_in;          // zmode: size of the innermost N group
   int64_t sc_m_in;        // C stride of the innermost M group
+  uint32_t c_break;       // zmode: the innermost M group of C (l_in >= a chunk, not a multiple of it) may end inside a chunk;
+  uint32_t l_in;          //        ``aligned`` / ``inner_chunks`` then describe the (longer) contiguous run of A
 };
 
 // fused pair of streaming contractions (chain2.hip)

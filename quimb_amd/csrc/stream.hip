@@ -124,9 +124,6 @@ __global__ __launch_bounds__(256) void stream_kernel(const StreamArgs p, const T
   int64_t* koffA = offBn + NPAD;                             // [Kpad]
   T* Wl = reinterpret_cast<T*>(koffA + p.Kpad);              // [Kpad][LDW]
   T* Zl = Wl + (size_t)p.Kpad * LDW;                         // ZMODE: 4 x [N*CH] wave-private tiles
-  // ZMODE with chunks that are NOT whole pieces of the innermost M group (its length is not a multiple of CH: the last
-  // site of rows 2-4 of a boundary sweep leaves runs of 36 / 216 open-leg values): 4 x [CH] C offsets of a chunk's rows
-  int64_t* cmT = reinterpret_cast<int64_t*>(Zl + (size_t)4 * p.N * CH);
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -271,7 +268,7 @@ __global__ __launch_bounds__(256) void stream_kernel(const StreamArgs p, const T
               }
             const uint32_t run_v = (CH * p.d_in) / EV;          // 16-byte vectors per n_out run
             const uint32_t tot_v = (p.N * CH) / EV;
-            if (aligned) {
+            if (!p.c_break) {
               __builtin_amdgcn_wave_barrier();
               for (uint32_t q = lane; q < tot_v; q += 64) {
                 uint32_t no = q / run_v, wv = q - no * run_v;
@@ -285,20 +282,23 @@ __global__ __launch_bounds__(256) void stream_kernel(const StreamArgs p, const T
                 vstore<T, EV>(C + cbase + offCn[no * p.d_in] + (int64_t)wv * EV, o);
               }
             } else {
-              // the chunk's CH rows straddle pieces of the innermost M group: every row's C offset from the mixed-radix
-              // decomposition (lane l: rows l, l + 64, ...), then the same 16-byte stores -- a vector never crosses a
-              // piece boundary (the host checks group length x d_in and CH x d_in against the vector width)
-              int64_t* cm = cmT + wave * CH;
-              for (int r = lane; r < CH; r += 64) {
-                int64_t oa, oc = -1;
-                const uint32_t m = cp_chunk * CH + r;
-                if (m < p.M) sdecomp2(m, p.nm, p.dim_m, p.sa_m, p.sc_m, oa, oc);
-                cm[r] = oc;
+              // c_break: the innermost M group of C (length l_in >= CH, not a multiple of it) ends INSIDE this chunk at
+              // most once -- the last site of row 4 of a corner sweep leaves runs of 216 open-leg values.  Two pieces,
+              // each contiguous in C; their bases are wave-uniform (one mixed-radix decomposition per chunk, not per
+              // lane), a 16-byte vector never crosses the break (host-checked divisibility)
+              const uint32_t m0 = cp_chunk * CH;
+              const uint32_t q0 = m0 / p.l_in, r0 = m0 - q0 * p.l_in;
+              int64_t oa_, c1, c2 = 0;
+              sdecomp2(m0, p.nm, p.dim_m, p.sa_m, p.sc_m, oa_, c1);
+              uint32_t brk_e = CH * p.d_in;
+              if (r0 + CH > p.l_in) {
+                brk_e = (p.l_in - r0) * p.d_in;
+                sdecomp2(m0 + (p.l_in - r0), p.nm, p.dim_m, p.sa_m, p.sc_m, oa_, c2);
               }
               __builtin_amdgcn_wave_barrier();
               for (uint32_t q = lane; q < tot_v; q += 64) {
                 uint32_t no = q / run_v, wv = q - no * run_v;
-                const uint32_t e0 = wv * EV, ml = e0 / p.d_in, ni = e0 - ml * p.d_in;
+                const uint32_t e0 = wv * EV;
                 T o[EV];
                 vload<T, EV>(o, tile + (size_t)q * EV);
 #pragma unroll
@@ -306,8 +306,8 @@ __global__ __launch_bounds__(256) void stream_kernel(const StreamArgs p, const T
                   T a = o[e] < T(0) ? -o[e] : o[e];
                   vmax = a > vmax ? a : vmax;
                 }
-                const int64_t oc = cm[ml];
-                if (oc >= 0) vstore<T, EV>(C + oc + offCn[no * p.d_in] + ni, o);
+                const int64_t oc = e0 < brk_e ? c1 + (int64_t)e0 : c2 + (int64_t)(e0 - brk_e);
+                vstore<T, EV>(C + oc + offCn[no * p.d_in], o);
               }
             }
             __builtin_amdgcn_wave_barrier();
@@ -344,7 +344,7 @@ __global__ __launch_bounds__(256) void stream_kernel(const StreamArgs p, const T
             for (int nt = 0; nt < NT; ++nt) acc[t][nt] = acc_t{0, 0, 0, 0};
           cp_chunk += CSTRIDE;
           cp_in += CSTRIDE;
-          if (aligned && cp_chunk < c_end) {
+          if (aligned && !p.c_break && cp_chunk < c_end) {
             if (cp_in < inner_chunks) {
               cbase += (int64_t)(CSTRIDE * CH) * p.sc_m_in;
             } else {
@@ -380,7 +380,7 @@ static int launch_stream_vnz(const StreamArgs& a, const void* A, const void* B, 
   constexpr int NPAD = NT * 16;
   constexpr int LDW = NPAD + ((48 - NPAD % 32) % 32);
   size_t lds = (size_t)(2 * NPAD + a.Kpad) * 8 + (size_t)a.Kpad * LDW * sizeof(T);
-  if (ZMODE) lds += (size_t)4 * a.N * 16 * V * sizeof(T) + (size_t)4 * 16 * V * sizeof(int64_t);
+  if (ZMODE) lds += (size_t)4 * a.N * 16 * V * sizeof(T);
   if (lds > 64 * 1024)
     (void)hipFuncSetAttribute((const void*)stream_kernel<T, V, NT, RING, ZMODE>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
