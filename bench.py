@@ -670,29 +670,6 @@ def main():
                     del qr_, loc_
                 except Exception as err:
                     projection[str(w_)] = {"error": f"{type(err).__name__}: {err}"}
-        # throughput with TWO contractions in flight (consecutive steps on alternating HIP streams: the corner sweeps of
-        # step i + 1 run under the joins of step i) -- reported beside the headline, never as it: ``value`` stays one
-        # contraction at a time, where latency and throughput are the same number
-        throughput2 = None
-        if mode == "single" and not pipelined and not args.no_secondary and hasattr(torch.cuda, "Stream"):
-            try:
-                rings_ = [torch.cuda.Stream(device=dev.tdev) for _ in range(2)]
-                for s_ in rings_:
-                    s_.wait_stream(torch.cuda.current_stream(dev.tdev))
-                k_ = [0]
-
-                def step2():
-                    k_[0] += 1
-                    with torch.cuda.stream(rings_[k_[0] % 2]):
-                        return step()
-
-                for _ in range(2):
-                    step2()
-                t2_, _ = _time_steps(step2, max(args.steps, 4), sync)
-                throughput2 = {"contractions_in_flight": 2, "ms_per_contraction": t2_ * 1e3, "tflops": flops_step / t2_ / 1e12,
-                               "note": "independent contractions on alternating streams; latency per contraction is ms_per_step"}
-            except Exception as err:
-                throughput2 = {"error": f"{type(err).__name__}: {err}"}
         cpu = None if (args.no_cpu or world > 1 or emulate) else cpu_baseline(args.D, args.Ly, args.seed)   # N=1 only
         nsl = plan.nslices if mode == "two_sided" else tree.nslices
         if mode == "single":
@@ -746,8 +723,6 @@ def main():
             "roofline": roof,
             "cpu_baseline": cpu,
         }
-        if throughput2 is not None:
-            out["throughput_two_in_flight"] = throughput2
         if dry_run:
             out["dry_run"] = True
         if secondary is not None:
