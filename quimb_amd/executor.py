@@ -318,7 +318,7 @@ class TreeExecutor:
             return
         # (HIP stream priorities for the first join's lanes were tried in round 4 and dropped: they did not keep a join
         # from slowing down beside a corner sweep, and streams of a second priority class cost hardware queues.
-        # QAMD_LANE_PRIORITY=1 brings them back for experiments.)
+        # options.lane_priority = True brings them back for experiments.)
         if self.options.lane_priority:
             first = anchors[0]
             for i in range(n):
@@ -451,7 +451,7 @@ class TreeExecutor:
         laned = streams is not None or (rec is not None and use_lanes)
         keep_alive = []   # buffers handed from one lane to another stay allocated until every launch is queued
         foreign = set()   # ssa ids of such buffers: a program's pool never reuses them
-        # QAMD_LANE_TRACE=1 (debugging aid): HIP events at the first and last launch of every lane -> self.lane_trace
+        # options.lane_trace (debugging aid): HIP events at the first and last launch of every lane -> self.lane_trace
         trace = trace_at = None
         if streams is not None and self.options.lane_trace:
             trace = self.lane_trace = []
