@@ -68,3 +68,16 @@ def test_struct_layout_matches_header():
     # int32 x8 + 13 int64[8] arrays + int32 x8
     assert C.sizeof(_lib.PairPlanStruct) == 8 * 4 + 13 * 8 * 8 + 8 * 4
     assert C.sizeof(_lib.Epilogue) == 24
+
+
+def test_library_reads_no_environment():
+    """"no hidden global state".  The shared library has no reference to getenv / secure_getenv at all --
+    kernel choices are steered by plan inputs only (qamd_pair_plan.kernel / tile_cfg / split_k, QAMD_CHAIN2_FORCE_* flags)."""
+    import subprocess
+
+    from quimb_amd import _lib
+
+    out = subprocess.run(["nm", "-D", "--undefined-only", _lib.library_path()], capture_output=True, text=True)
+    if out.returncode != 0:
+        pytest.skip("nm not available")
+    assert "getenv" not in out.stdout, [ln for ln in out.stdout.splitlines() if "getenv" in ln]
