@@ -1501,6 +1501,20 @@ def check_decomp_drivers(dtype="float64"):
         assert np.max(np.abs(lf @ rf - r8)) <= (1e-9 if not lo else 1e-3) * np.max(np.abs(r8))
         iso = lf.T @ lf if absorb == "right" else rf @ rf.T
         assert np.max(np.abs(iso - np.eye(8))) <= (1e-10 if not lo else 1e-3)
+    # ... through ``tensor_split`` (the Tensor-level entry quimb's callers use, tensor_core.py:390-640): options reach the driver,
+    # the new bond sits last on the left factor and first on the right one
+    T4 = qa.Tensor(qa.asarray(r8.reshape(12, 8, 5, 8)), ("a", "b", "c", "d"))
+    for method, kw in (("svd:rand", dict(max_bond=8, absorb="right", oversample=0, num_iterations=0, method_lorthog="qr:cholesky")),
+                       ("qr:cholesky", dict(absorb="right", cutoff=0.0, refine=True)),
+                       ("rsvd", dict(max_bond=8, absorb="both", cutoff=0.0))):
+        tl, tr = qa.tensor_split(T4, ("a", "b"), method=method, bond_ind="k", **kw)
+        assert tl.inds == ("a", "b", "k") and tr.inds == ("k", "c", "d")
+        rec = np.tensordot(np.asarray(tl.data.to_numpy()), np.asarray(tr.data.to_numpy()), axes=([2], [0]))
+        assert np.max(np.abs(rec.reshape(96, 40) - r8)) <= (1e-8 if not lo else 2e-3) * np.max(np.abs(r8)), method
+    cx = (rng.normal(size=(40, 12)) + 1j * rng.normal(size=(40, 12))).astype(np.complex64 if lo else np.complex128)
+    lc, qc = qa.linalg.lq_via_cholesky(qa.asarray(cx.T.copy()), refine=True)
+    assert np.max(np.abs(lc.to_numpy() @ qc.to_numpy() - cx.T)) <= 200 * eps * np.max(np.abs(cx))
+    assert np.max(np.abs(qc.to_numpy() @ qc.to_numpy().conj().T - np.eye(12))) <= 200 * eps
     l_, q_ = qa.linalg.lq_via_cholesky(qa.asarray(bad.T.copy()), refine=True)
     assert np.max(np.abs(l_.to_numpy() @ q_.to_numpy() - bad.T)) <= 100 * eps
     assert np.max(np.abs(q_.to_numpy() @ q_.to_numpy().T - np.eye(24))) <= 50 * eps
