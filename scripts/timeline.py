@@ -5,7 +5,7 @@ queue, name.   python scripts/timeline.py results.db [marker]"""
 import re, sqlite3, sys
 
 path = sys.argv[1]
-marker = sys.argv[2] if len(sys.argv) > 2 else "dotm_kernel"
+marker = sys.argv[2] if len(sys.argv) > 2 else "gemmk_dot_finish"
 c = sqlite3.connect(path)
 tabs = [r[0] for r in c.execute("select name from sqlite_master where type='table'")]
 t = lambda n: [x for x in tabs if x.startswith(n)][0]
