@@ -356,7 +356,8 @@ extern "C" int qamd_pair_plan_finalize(qamd_pair_plan* p, int64_t align_a, int64
       bool ok = true;
       for (int i = 0; i + 1 < p->nm; ++i) ok = ok && (p->sc_m[i] % ev == 0);
       for (int i = 0; i < p->nn; ++i) ok = ok && (p->sc_n[i] < d_in || p->sc_n[i] % ev == 0);
-      ok = ok && (stream_lds_bytes(d.K, d.N, es) + 4 * (d.N + d_in) * 16 * ev * es <= 80 * 1024);
+      // (+ the table of group starts in break mode: a few entries, 1 KiB reserved)
+      ok = ok && (stream_lds_bytes(d.K, d.N, es) + 4 * (d.N + d_in) * 16 * ev * es + (l_in % (16 * ev) ? 1024 : 0) <= 80 * 1024);
       if (ok) { kern = 2; vc = ev; }
     }
     if (!kern && base_ok && p->sc_m[p->nm - 1] == 1 && stream_lds_bytes(d.K, d.N, es) <= 64 * 1024) {
@@ -559,6 +560,8 @@ static void fill_stream_args(const qamd_pair_plan* p, const PairDims& d, StreamA
   if (s.chunks_per_wave < 1) s.chunks_per_wave = 1;
   uint32_t waves = (s.chunks + s.chunks_per_wave - 1) / s.chunks_per_wave;
   s.grid = (waves + 3) / 4;
+  if (s.c_break)      // pieces of the innermost group a workgroup's rows (4 waves x chunks_per_wave chunks) can touch, + the next
+    s.zb_groups = (uint32_t)((uint64_t)s.chunks_per_wave * 4 * 16 * V / s.l_in + 3);
 }
 
 static int launch_stream(const qamd_pair_plan* p, const PairDims& d, const void* A, const void* B, void* C,

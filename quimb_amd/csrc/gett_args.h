@@ -48,6 +48,8 @@ struct StreamArgs {
   int64_t sc_m_in;        // C stride of the innermost M group
   uint32_t c_break;       // zmode: the innermost M group of C (l_in >= a chunk, not a multiple of it) may end inside a chunk;
   uint32_t l_in;          //        ``aligned`` / ``inner_chunks`` then describe the (longer) contiguous run of A
+  uint32_t zb_groups;     // c_break: entries of a workgroup's table of group starts (0 otherwise)
+  uint32_t pad2_;
 };
 
 // fused pair of streaming contractions (chain2.hip)

@@ -124,6 +124,8 @@ __global__ __launch_bounds__(256) void stream_kernel(const StreamArgs p, const T
   int64_t* koffA = offBn + NPAD;                             // [Kpad]
   T* Wl = reinterpret_cast<T*>(koffA + p.Kpad);              // [Kpad][LDW]
   T* Zl = Wl + (size_t)p.Kpad * LDW;                         // ZMODE: 4 x [N*CH] wave-private tiles
+  int64_t* gb = reinterpret_cast<int64_t*>(Zl + (size_t)4 * p.N * CH);   // c_break: C offsets of the group starts this
+                                                                          // workgroup's rows touch ([p.zb_groups])
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -164,6 +166,21 @@ __global__ __launch_bounds__(256) void stream_kernel(const StreamArgs p, const T
   }
 
   const T alpha = T(1) / (read_scale(scale_a) * read_scale(scale_b));
+  // c_break (ZMODE): the C offset of the first row of every innermost-M-group piece this workgroup can meet, tabulated once
+  // -- the store path then needs no division or mixed-radix decomposition per chunk
+  uint32_t zq_first = 0;
+  if constexpr (ZMODE) {
+    if (p.c_break) {
+      zq_first = (blockIdx.x * (p.chunks_per_wave * 4) * CH) / p.l_in;
+      for (uint32_t t = tid; t < p.zb_groups; t += 256) {
+        const uint32_t m = (zq_first + t) * p.l_in;
+        int64_t oa_, oc = 0;
+        if (m < p.M) sdecomp2(m, p.nm, p.dim_m, p.sa_m, p.sc_m, oa_, oc);
+        gb[t] = oc;
+      }
+      __syncthreads();
+    }
+  }
 
   // ---- this wave's chunk range ------------------------------------------------
   const uint32_t wglob = blockIdx.x * 4 + wave;
@@ -237,6 +254,15 @@ __global__ __launch_bounds__(256) void stream_kernel(const StreamArgs p, const T
   int* zoffT = reinterpret_cast<int*>(offBn);
   T* tile = nullptr;
   if constexpr (ZMODE) tile = Zl + (size_t)wave * (p.N * CH);
+  // c_break: (piece index relative to the table, row inside the piece) of the chunk being stored; advanced incrementally
+  uint32_t zt_ = 0, zr_ = 0;
+  if constexpr (ZMODE) {
+    if (p.c_break) {
+      const uint32_t m0 = c_begin * CH;
+      zt_ = m0 / p.l_in - zq_first;
+      zr_ = m0 - (m0 / p.l_in) * p.l_in;
+    }
+  }
 
   for (uint32_t g0 = 0; g0 < g_total; g0 += RING) {
 #pragma unroll
@@ -284,17 +310,10 @@ __global__ __launch_bounds__(256) void stream_kernel(const StreamArgs p, const T
             } else {
               // c_break: the innermost M group of C (length l_in >= CH, not a multiple of it) ends INSIDE this chunk at
               // most once -- the last site of row 4 of a corner sweep leaves runs of 216 open-leg values.  Two pieces,
-              // each contiguous in C; their bases are wave-uniform (one mixed-radix decomposition per chunk, not per
-              // lane), a 16-byte vector never crosses the break (host-checked divisibility)
-              const uint32_t m0 = cp_chunk * CH;
-              const uint32_t q0 = m0 / p.l_in, r0 = m0 - q0 * p.l_in;
-              int64_t oa_, c1, c2 = 0;
-              sdecomp2(m0, p.nm, p.dim_m, p.sa_m, p.sc_m, oa_, c1);
-              uint32_t brk_e = CH * p.d_in;
-              if (r0 + CH > p.l_in) {
-                brk_e = (p.l_in - r0) * p.d_in;
-                sdecomp2(m0 + (p.l_in - r0), p.nm, p.dim_m, p.sa_m, p.sc_m, oa_, c2);
-              }
+              // each contiguous in C; their bases come from the workgroup's table of group starts (no division, no
+              // decomposition here), a 16-byte vector never crosses the break (host-checked divisibility)
+              const int64_t c1 = gb[zt_] + (int64_t)zr_ * p.sc_m_in, c2 = gb[zt_ + 1];
+              const uint32_t brk_e = (zr_ + CH > p.l_in) ? (p.l_in - zr_) * p.d_in : CH * p.d_in;
               __builtin_amdgcn_wave_barrier();
               for (uint32_t q = lane; q < tot_v; q += 64) {
                 uint32_t no = q / run_v, wv = q - no * run_v;
@@ -309,6 +328,8 @@ __global__ __launch_bounds__(256) void stream_kernel(const StreamArgs p, const T
                 const int64_t oc = e0 < brk_e ? c1 + (int64_t)e0 : c2 + (int64_t)(e0 - brk_e);
                 vstore<T, EV>(C + oc + offCn[no * p.d_in], o);
               }
+              zr_ += CSTRIDE * CH;                       // this wave's next chunk
+              while (zr_ >= p.l_in) { zr_ -= p.l_in; ++zt_; }
             }
             __builtin_amdgcn_wave_barrier();
           } else {
@@ -380,7 +401,7 @@ static int launch_stream_vnz(const StreamArgs& a, const void* A, const void* B, 
   constexpr int NPAD = NT * 16;
   constexpr int LDW = NPAD + ((48 - NPAD % 32) % 32);
   size_t lds = (size_t)(2 * NPAD + a.Kpad) * 8 + (size_t)a.Kpad * LDW * sizeof(T);
-  if (ZMODE) lds += (size_t)4 * a.N * 16 * V * sizeof(T);
+  if (ZMODE) lds += (size_t)4 * a.N * 16 * V * sizeof(T) + (size_t)a.zb_groups * sizeof(int64_t);
   if (lds > 64 * 1024)
     (void)hipFuncSetAttribute((const void*)stream_kernel<T, V, NT, RING, ZMODE>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
