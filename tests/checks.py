@@ -1532,6 +1532,39 @@ def check_decomp_drivers(dtype="float64"):
     assert np.max(np.abs((U.to_numpy() * S) @ VH.to_numpy() - m)) <= (1e-7 if not lo else 1e-2) * exact[0]
 
 
+def check_decomp_full_chi(chi=512, d=2, dtype="float64"):
+    """The GEMM-shaped drivers at BASELINE config #5's real sizes (the golden fixtures are small): canonisation of a
+    (chi d) x chi site matrix by Cholesky-QR, the split of a (chi d) x (d chi) two-site tensor with a DMRG-like decaying
+    spectrum by the sketch -- with the reduced factor decomposed (oversample 10) and without (oversample 0: isometry x rest)."""
+    rng = np.random.default_rng(12)
+    n = chi * d
+    site = rng.standard_normal((n, chi)).astype(dtype)
+    q, r = qa.linalg.qr_via_cholesky(qa.asarray(site), refine=True)
+    q, r = q.to_numpy(), r.to_numpy()
+    assert np.max(np.abs(q.T @ q - np.eye(chi))) <= 1e-11 and np.max(np.abs(q @ r - site)) <= 1e-12 * np.max(np.abs(site)) * chi
+    assert np.all(np.diag(r) > 0) and np.max(np.abs(np.tril(r, -1))) == 0.0
+    u, _ = np.linalg.qr(rng.standard_normal((n, n)))
+    v, _ = np.linalg.qr(rng.standard_normal((n, n)))
+    spec = np.exp(-np.arange(n) / 30.0)                       # sigma_513 = 3.9e-8 sigma_1: numerically rank < chi + 10
+    theta = ((u * spec) @ v.T).astype(dtype)
+    x = qa.asarray(theta)
+    Q, none, B = qa.linalg.svd_rand(x, chi, oversample=0, num_iterations=0, method_lorthog="qr:cholesky", right=True,
+                                    factors_only=True)
+    Q, B = Q.to_numpy(), B.to_numpy()
+    assert none is None and Q.shape == (n, chi) and B.shape == (chi, n)
+    assert np.max(np.abs(Q.T @ Q - np.eye(chi))) <= 1e-10
+    # a sketch with no oversampling is exact up to a modest multiple of the discarded tail
+    tail = float(np.sqrt(np.sum(spec[chi:] ** 2)))
+    assert np.linalg.norm(Q @ B - theta) <= 50 * tail, (np.linalg.norm(Q @ B - theta), tail)
+    U, S, VH = qa.linalg.svd_rand(x, chi, oversample=10, num_iterations=0, method_lorthog="qr:cholesky", method_reduced="svd:eig")
+    S = S.to_numpy()
+    # the Gram route inside loses relative accuracy as eps (s_max / s)^2: 1e-6 down to s = 1e-4 s_max, 5e-4 at 1e-6 s_max
+    nk = int(np.count_nonzero(spec[:chi] > 1e-4))
+    assert len(S) >= nk and np.max(np.abs(S[:nk] / spec[:nk] - 1.0)) <= 1e-6, np.max(np.abs(S[:nk] / spec[:nk] - 1.0))
+    rec = (U.to_numpy()[:, :len(S)] * S) @ VH.to_numpy()[:len(S)]
+    assert np.linalg.norm(rec - theta) <= 50 * tail + 1e-6 * np.sqrt(float(np.sum(spec[len(S):chi] ** 2)) + 1e-300) + 1e-7
+
+
 def check_split(dtype="float64"):
     import json
 

@@ -106,6 +106,16 @@ def test_decomp_drivers_hip_match_real_quimb(hip, dtype):
     checks.check_decomp_drivers(dtype)
 
 
+def test_decomp_drivers_at_chi512_host_logic(emu):
+    checks.check_decomp_full_chi()
+
+
+@pytest.mark.gpu
+def test_decomp_drivers_at_chi512(hip):
+    """Cholesky-QR of a 1024 x 512 site matrix and the sketch split of a 1024 x 1024 two-site tensor on the device."""
+    checks.check_decomp_full_chi()
+
+
 def test_circuits_host_logic_match_real_quimb(emu):
     """``Circuit`` (dense state, amplitudes, batched amplitudes) and ``CircuitMPS`` (exact, truncated to chi = 4,
     non-local gates through swaps) reproduce the real quimb's states on the same gate lists."""
