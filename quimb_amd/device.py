@@ -324,12 +324,13 @@ class HipDevice:
         return True
 
     # ---- fused pair of streaming steps ---------------------------------------------
-    def contract_chain2(self, c2, dtype, a, w1, w2, c, ep=None):
+    def contract_chain2(self, c2, dtype, a, w1, w2, c, ep=None, pin=None):
         """C = (A . W1) . W2 in one pass (chain2r.hip / chain2.hip).  ``c2``: pairwise.Chain2Spec;
         ``w1`` / ``w2``: the small tensors in their own layouts (``c2.w1_pack`` / ``w2_pack`` say how
         to address them); ``ep`` = (slots_a, slots_w1, slots_w2, slots_out) or None."""
-        # the kernel choice (and with it the W addressing mode) follows the device's pin
-        force = {"auto": 0, "lds": 16, "reg": 32, "quad": 64}[self.force_chain2]
+        # the kernel choice (and with it the W addressing mode) follows the caller's pin (an executor's
+        # ``options.chain2_kernel``), else the device's
+        force = {"auto": 0, "lds": 16, "reg": 32, "quad": 64}[pin if pin not in (None, "auto") else self.force_chain2]
         key = ("chain2", c2, dtype_code(dtype), force)
         ent = self._pairs.get(key)
         if ent is None:

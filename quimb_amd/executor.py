@@ -558,7 +558,11 @@ class TreeExecutor:
                         ep = tuple(dev.slots_row(slots, s_) if s_ in has_scale else None for s_ in (a, w1, w2))
                         ep = ep + (dev.slots_row(slots, res),)
                         has_scale.add(res)
-                    dev.contract_chain2(c2, self.dtype, live[a]._buf, live[w1]._buf, live[w2]._buf, x._buf, ep)
+                    if self.options.chain2_kernel != "auto":
+                        dev.contract_chain2(c2, self.dtype, live[a]._buf, live[w1]._buf, live[w2]._buf, x._buf, ep,
+                                            pin=self.options.chain2_kernel)
+                    else:
+                        dev.contract_chain2(c2, self.dtype, live[a]._buf, live[w1]._buf, live[w2]._buf, x._buf, ep)
                     live[res] = x
                     if independent and cache is not None:
                         cache[res] = x

@@ -85,7 +85,7 @@ class EmuDevice:
         out[0] = z
         return True
 
-    def contract_chain2(self, c2, dtype, a, w1, w2, c, ep=None):
+    def contract_chain2(self, c2, dtype, a, w1, w2, c, ep=None, pin=None):
         """Semantics of qamd_contract_chain2 (see include/quimb_amd.h); the small tensors arrive in
         their own layouts and are gathered as ``c2.w1_pack`` / ``w2_pack`` describe."""
         self.calls["chain2"] = self.calls.get("chain2", 0) + 1
