@@ -242,14 +242,19 @@ def lq_via_cholesky(x, shift=True, refine=False):
 
 def _randn(dev, shape, dtype, seed):
     """Gaussian test matrix.  ``seed`` given: numpy's ``default_rng(seed).normal`` on the host (the stream the
-    reference draws from, decomp.py:1795-1799 -- results reproducible against it); None: drawn on the device."""
+    reference draws from, decomp.py:1795-1799 -- results reproducible against it); None: drawn on the device from a
+    per-device generator seeded once (the same sequence in every process)."""
     dtype = np.dtype(dtype)
     if seed is not None or not hasattr(dev, "torch"):
         rng = seed if isinstance(seed, np.random.Generator) else np.random.default_rng(seed)
         return Array.from_numpy(rng.normal(size=shape).astype(dtype), dev=dev)      # (real draws for complex x too, as there)
     torch = dev.torch
     rdt = np.zeros(0, dtype).real.dtype
-    t = torch.randn(shape, dtype=dev._tdt[np.dtype(rdt)], device=dev.tdev).to(dev._tdt[dtype])
+    gen = getattr(dev, "_sketch_generator", None)
+    if gen is None:          # one generator per device object, seeded once: sketches are reproducible run to run
+        gen = dev._sketch_generator = torch.Generator(device=dev.tdev)
+        gen.manual_seed(0x5EED)
+    t = torch.randn(shape, dtype=dev._tdt[np.dtype(rdt)], device=dev.tdev, generator=gen).to(dev._tdt[dtype])
     return Array(dev, t.reshape(-1), tuple(shape), dtype)
 
 
