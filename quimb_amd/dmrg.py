@@ -167,7 +167,7 @@ class DMRG2:
         def qr_tall(m):
             if chol and m.shape[0] >= m.shape[1]:
                 try:
-                    return linalg.qr_via_cholesky(m, shift=True, refine=True)
+                    return linalg.qr_via_cholesky(m, shift=True, refine="auto")
                 except np.linalg.LinAlgError:
                     pass
             return linalg.qr(m)
@@ -175,7 +175,7 @@ class DMRG2:
         def lq_wide(m):                      # (lower factor, isometry with orthonormal rows)
             if chol and m.shape[0] <= m.shape[1]:
                 try:
-                    return linalg.lq_via_cholesky(m, shift=True, refine=True)
+                    return linalg.lq_via_cholesky(m, shift=True, refine="auto")
                 except np.linalg.LinAlgError:
                     pass
             q, rr = linalg.qr(ops.transpose(m, (1, 0)))           # LQ through the QR of the transpose: A = (R^T)(Q^T)
@@ -241,11 +241,11 @@ class DMRG2:
             elif not right and nn_ <= mm_:
                 lf, rf = m, Array.from_numpy(np.eye(nn_, dtype=self.dtype), dev=m._dev)
             elif right:
-                lf, rf = linalg.qr_via_cholesky(m, shift=True, refine=True) if self.dtype.itemsize >= 8 and self.dtype.kind == "f" \
+                lf, rf = linalg.qr_via_cholesky(m, shift=True, refine="auto") if self.dtype.itemsize >= 8 and self.dtype.kind == "f" \
                     or self.dtype == np.dtype("complex128") else linalg.qr(m)
             else:
                 if self.dtype == np.dtype("float64") or self.dtype == np.dtype("complex128"):
-                    lf, rf = linalg.lq_via_cholesky(m, shift=True, refine=True)
+                    lf, rf = linalg.lq_via_cholesky(m, shift=True, refine="auto")
                 else:
                     q_, r_ = linalg.qr(ops.transpose(m, (1, 0)))
                     lf, rf = ops.transpose(r_, (1, 0)), ops.transpose(q_, (1, 0))

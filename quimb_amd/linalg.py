@@ -206,12 +206,26 @@ def cholesky_regularized(g, shift=True):
     return _wrap(g, L)
 
 
+def _gram_defect(g):
+    """max |g - I| of a (small) Gram matrix, read back as one float."""
+    g, hook = _hook(g, "eigh")
+    if hook is not None:                      # the plan interpreter: numpy
+        a = g.to_numpy()
+        return float(np.max(np.abs(a - np.eye(a.shape[0], dtype=a.dtype))))
+    import torch
+
+    g, t = _as_torch(g)
+    return float((t - torch.eye(t.shape[0], dtype=t.dtype, device=t.device)).abs().max().item())
+
+
 def qr_via_cholesky(x, shift=True, refine=False):
     """``(Q, R)`` of a tall 2-d array (m >= n) from the Cholesky factor of its Gram matrix -- the reference's
     ``qr_via_cholesky`` (decomp.py:2359-2420): ``G = x^H x`` (one GETT launch), ``G = R^H R`` (potrf on n x n),
     ``Q = x R^-1`` (a triangular solve).  Orthogonality of Q degrades as cond(x)^2 eps (and by the regularising shift);
     ``refine`` repeats the step on Q (CholeskyQR2: orthogonal to eps for cond(x) < eps^-1/2) and folds the second
-    triangle into R.  R has a positive real diagonal by construction (no phase fix needed)."""
+    triangle into R; ``refine="auto"`` forms ``Q^H Q`` (the Gram matrix the second pass would factor anyway), reads its
+    distance from the identity back and runs the second pass only if that exceeds 100 eps -- a well-conditioned input
+    pays one extra GETT launch instead of a second potrf + trsm.  R has a positive real diagonal by construction."""
     from . import ops
 
     x = x if isinstance(x, Array) else Array.from_numpy(np.asarray(x))
@@ -219,7 +233,14 @@ def qr_via_cholesky(x, shift=True, refine=False):
     L = cholesky_regularized(g, shift=shift)                    # g = L L^H  ->  R = L^H
     R = ops.transpose(L.conj(), (1, 0))
     Q = solve_triangular(R, x, lower=False, left=False)         # Q R = x
-    if refine:
+    if refine == "auto":
+        g2 = ops.tensordot(Q.conj(), Q, axes=([0], [0]))
+        if _gram_defect(g2) > 100.0 * float(np.finfo(np.dtype(x.dtype)).eps):
+            L2 = cholesky_regularized(g2, shift=shift)
+            R2 = ops.transpose(L2.conj(), (1, 0))
+            Q = solve_triangular(R2, Q, lower=False, left=False)
+            R = ops.tensordot(R2, R, axes=([1], [0]))
+    elif refine:
         Q, R2 = qr_via_cholesky(Q, shift=shift, refine=False)
         R = ops.tensordot(R2, R, axes=([1], [0]))
     return Q, R
@@ -227,14 +248,20 @@ def qr_via_cholesky(x, shift=True, refine=False):
 
 def lq_via_cholesky(x, shift=True, refine=False):
     """``(L, Q)`` of a wide 2-d array (m <= n): ``x x^H = L L^H``, ``Q = L^-1 x`` -- the form the Cholesky route yields
-    directly (decomp.py:2383-2386, ``transposed = False``)."""
+    directly (decomp.py:2383-2386, ``transposed = False``).  ``refine`` as in ``qr_via_cholesky``."""
     from . import ops
 
     x = x if isinstance(x, Array) else Array.from_numpy(np.asarray(x))
     g = ops.tensordot(x, x.conj(), axes=([1], [1]))            # x x^H, (m, m)
     L = cholesky_regularized(g, shift=shift)
     Q = solve_triangular(L, x, lower=True, left=True)           # L Q = x
-    if refine:
+    if refine == "auto":
+        g2 = ops.tensordot(Q, Q.conj(), axes=([1], [1]))
+        if _gram_defect(g2) > 100.0 * float(np.finfo(np.dtype(x.dtype)).eps):
+            L2 = cholesky_regularized(g2, shift=shift)
+            Q = solve_triangular(L2, Q, lower=True, left=True)
+            L = ops.tensordot(L, L2, axes=([1], [0]))
+    elif refine:
         L2, Q = lq_via_cholesky(Q, shift=shift, refine=False)
         L = ops.tensordot(L, L2, axes=([1], [0]))
     return L, Q
@@ -260,7 +287,7 @@ def _randn(dev, shape, dtype, seed):
 
 def _orth(y, method):
     if method in ("qr:cholesky", "cholesky"):
-        return qr_via_cholesky(y, shift=True, refine=True)[0]
+        return qr_via_cholesky(y, shift=True, refine="auto")[0]
     if method == "qr":
         return qr(y)[0]
     if method in ("svd:eig", "eig", "svd"):

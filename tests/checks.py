@@ -1483,7 +1483,7 @@ def check_decomp_drivers(dtype="float64"):
     v, _ = np.linalg.qr(rng.normal(size=(24, 24)))
     bad = ((u * np.logspace(0, -5 if not lo else -2, 24)) @ v.T).astype(np.float32 if lo else np.float64)
     eps = np.finfo(bad.dtype).eps
-    for refine in (False, True):
+    for refine in (False, True, "auto"):
         q, r = qa.linalg.qr_via_cholesky(qa.asarray(bad), refine=refine)
         q, r = q.to_numpy(), r.to_numpy()
         assert np.max(np.abs(q @ r - bad)) <= 100 * eps
