@@ -138,7 +138,7 @@ class TreeExecutor:
         """Replace consecutive big-x-small steps that have the two-site structure by one
         fused launch (qamd_contract_chain2): the intermediate never reaches HBM."""
         # on by default: 0.94 ms per fused 6^9 pair against 2 x 0.55 ms for two streaming
-        # launches (DESIGN.md 4.5); options.fuse_pairs = False keeps every step a separate launch
+        # launches (DESIGN.md 4.4); options.fuse_pairs = False keeps every step a separate launch
         if self.dtype.kind == "c" or not self.options.fuse_pairs:
             return
         plan, info = self.plan, self.info

@@ -134,7 +134,7 @@ def random_greedy(inputs, output, size_dict, repeats=32, seed=0, temperature=0.3
 
 
 # gfx950 roofs the time model prices a step against (MI355X_MICROARCH.md: dense MFMA peaks, achievable HBM copy rate),
-# and what this library's kernels reach of them (round-3 measurements): the k-outer MFMA kernel
+# and what this library's kernels reach of them (round-3 measurements, docs/history/DESIGN_rounds1-4.md section 5): the k-outer MFMA kernel
 # 0.85 of the peak on GEMM-shaped fp32 joins, the older tiled kernels ~0.5; streaming / fused-pair kernels 4.9 of the
 # 6.29 TB/s a copy reaches; a launch that moves less than a few MB is latency: ~12 us on the device
 _PEAK_FLOPS = {"float32": 157.3e12, "float64": 78.6e12, "complex64": 157.3e12, "complex128": 78.6e12}

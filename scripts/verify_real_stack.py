@@ -30,7 +30,7 @@ for name in ("autoray", "cotengra", "quimb"):
         missing.append(f"{name} ({type(err).__name__}: {err})")
 if missing:
     print("SKIPPED: the real stack is not importable here -- " + "; ".join(missing))
-    print("         B1 / B2 remain verified against tests/golden/_shims only (see DESIGN.md section 2.1)")
+    print("         B1 / B2 remain verified against tests/golden/_shims only (see DESIGN.md section 2)")
     sys.exit(0)
 
 import numpy as np  # noqa: E402
