@@ -257,15 +257,17 @@ static bool gemmd_config(const qamd_pair_plan* p, const PairDims& d, int64_t ali
   return tiles >= 64 || te;       // tiny grids keep the generic kernels
 }
 
-// Z-mode streaming with a "break": the innermost M group (length l_in, C stride d_in) is not a whole number of chunks of
-// ``ch`` = 16 ev rows, but (i) l_in >= ch, so a chunk crosses its end at most once, (ii) A is contiguous across a suffix of
-// the M groups whose product R is a multiple of ch (chunks then never straddle a run of A), (iii) the break falls on a
-// 16-byte vector boundary of C.  Returns R (elements) or 0.
+// Z-mode streaming with "breaks": the innermost M group (length l_in, C stride d_in) is not a whole number of chunks of
+// ``ch`` = 16 ev rows, but (i) 4 l_in >= ch, so a chunk meets a handful of its pieces at most, (ii) A is contiguous across
+// a suffix of the M groups whose product R is a multiple of ch (chunks then never straddle a run of A), (iii) every piece
+// end falls on a 16-byte vector boundary of C (chunk starts are multiples of gcd(ch, l_in) rows).  Returns R (elements) or 0.
 static int64_t z_break_run(const qamd_pair_plan* p, int ev, int64_t d_in) {
   const int64_t ch = 16 * ev;
   if (p->nm < 2 || p->sa_m[p->nm - 1] != 1) return 0;
   const int64_t l_in = p->dim_m[p->nm - 1];
-  if (l_in % ch == 0 || l_in < ch || (l_in * d_in) % ev || (ch * d_in) % ev) return 0;
+  int64_t g = ch, r = l_in;
+  while (r) { const int64_t t = g % r; g = r; r = t; }          // gcd(ch, l_in)
+  if (l_in % ch == 0 || 4 * l_in < ch || (l_in * d_in) % ev || (g * d_in) % ev) return 0;
   int64_t run = l_in;
   for (int g = p->nm - 2; g >= 0; --g) {
     if (p->sa_m[g] != run) break;          // A no longer contiguous across this group
@@ -356,8 +358,8 @@ extern "C" int qamd_pair_plan_finalize(qamd_pair_plan* p, int64_t align_a, int64
       bool ok = true;
       for (int i = 0; i + 1 < p->nm; ++i) ok = ok && (p->sc_m[i] % ev == 0);
       for (int i = 0; i < p->nn; ++i) ok = ok && (p->sc_n[i] < d_in || p->sc_n[i] % ev == 0);
-      // (+ the table of group starts in break mode: a few entries, 1 KiB reserved)
-      ok = ok && (stream_lds_bytes(d.K, d.N, es) + 4 * (d.N + d_in) * 16 * ev * es + (l_in % (16 * ev) ? 1024 : 0) <= 80 * 1024);
+      // (+ the table of group starts in break mode: 2 KiB reserved)
+      ok = ok && (stream_lds_bytes(d.K, d.N, es) + 4 * (d.N + d_in) * 16 * ev * es + (l_in % (16 * ev) ? 2048 : 0) <= 80 * 1024);
       if (ok) { kern = 2; vc = ev; }
     }
     if (!kern && base_ok && p->sc_m[p->nm - 1] == 1 && stream_lds_bytes(d.K, d.N, es) <= 64 * 1024) {
@@ -560,8 +562,8 @@ static void fill_stream_args(const qamd_pair_plan* p, const PairDims& d, StreamA
   if (s.chunks_per_wave < 1) s.chunks_per_wave = 1;
   uint32_t waves = (s.chunks + s.chunks_per_wave - 1) / s.chunks_per_wave;
   s.grid = (waves + 3) / 4;
-  if (s.c_break)      // pieces of the innermost group a workgroup's rows (4 waves x chunks_per_wave chunks) can touch, + the next
-    s.zb_groups = (uint32_t)((uint64_t)s.chunks_per_wave * 4 * 16 * V / s.l_in + 3);
+  if (s.c_break)      // pieces of the innermost group a workgroup's rows (4 waves x chunks_per_wave chunks) can touch, + what the
+    s.zb_groups = (uint32_t)((uint64_t)s.chunks_per_wave * 4 * 16 * V / s.l_in + 3 + 16 * V / s.l_in + 2);   // last chunk looks up
 }
 
 static int launch_stream(const qamd_pair_plan* p, const PairDims& d, const void* A, const void* B, void* C,

@@ -308,12 +308,15 @@ __global__ __launch_bounds__(256) void stream_kernel(const StreamArgs p, const T
                 vstore<T, EV>(C + cbase + offCn[no * p.d_in] + (int64_t)wv * EV, o);
               }
             } else {
-              // c_break: the innermost M group of C (length l_in >= CH, not a multiple of it) ends INSIDE this chunk at
-              // most once -- the last site of row 4 of a corner sweep leaves runs of 216 open-leg values.  Two pieces,
-              // each contiguous in C; their bases come from the workgroup's table of group starts (no division, no
-              // decomposition here), a 16-byte vector never crosses the break (host-checked divisibility)
-              const int64_t c1 = gb[zt_] + (int64_t)zr_ * p.sc_m_in, c2 = gb[zt_ + 1];
-              const uint32_t brk_e = (zr_ + CH > p.l_in) ? (p.l_in - zr_) * p.d_in : CH * p.d_in;
+              // c_break: the innermost M group of C (length l_in, not a multiple of CH) ends INSIDE this chunk -- the last
+              // site of rows 3 / 4 of a corner sweep leaves runs of 36 / 216 open-leg values.  A few pieces, each contiguous
+              // in C; their bases come from the workgroup's table of group starts (no division, no decomposition here), a
+              // 16-byte vector never crosses a break (host-checked divisibility)
+              // pieces of this chunk: piece 0 = rows zr_ .. of group zt_, piece k >= 1 = group zt_ + k from its first row;
+              // in ELEMENTS of a run (row x d_in) piece k starts at thr[k - 1]: no division anywhere
+              const uint32_t le = p.l_in * p.d_in;                       // elements of a whole piece
+              const uint32_t thr0 = (p.l_in - zr_) * p.d_in;            // end of piece 0 (may lie beyond the chunk)
+              const int64_t c0 = gb[zt_] + (int64_t)zr_ * p.sc_m_in;
               __builtin_amdgcn_wave_barrier();
               for (uint32_t q = lane; q < tot_v; q += 64) {
                 uint32_t no = q / run_v, wv = q - no * run_v;
@@ -325,7 +328,12 @@ __global__ __launch_bounds__(256) void stream_kernel(const StreamArgs p, const T
                   T a = o[e] < T(0) ? -o[e] : o[e];
                   vmax = a > vmax ? a : vmax;
                 }
-                const int64_t oc = e0 < brk_e ? c1 + (int64_t)e0 : c2 + (int64_t)(e0 - brk_e);
+                int64_t oc = c0 + (int64_t)e0;
+                if (e0 >= thr0) {
+                  uint32_t k = 1, rest = e0 - thr0;
+                  while (rest >= le) { rest -= le; ++k; }               // (<= CH / l_in + 1 pieces: a handful)
+                  oc = gb[zt_ + k] + (int64_t)rest;
+                }
                 vstore<T, EV>(C + oc + offCn[no * p.d_in], o);
               }
               zr_ += CSTRIDE * CH;                       // this wave's next chunk

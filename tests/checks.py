@@ -471,12 +471,13 @@ def check_stream_kernels(dtype, seed=8):
         ("ham,hx->axm", dict(h=4, a=5, m=8192, x=4)),     # X, two M groups
         ("km,kn->mn", dict(k=2, m=1 << 16, n=2)),         # gate-like, C row-major -> Z with d_in = 2
         ("lkr,kn->lnr", dict(l=64, k=4, r=1024, n=4)),    # 2-qubit gate on a state
-        # Z with a chunk that straddles the end of the innermost M group (round 5): the last site of row 4 of a corner sweep
-        # -- the open-leg run is 216 long, the chunk 64 (fp32) or 32 (fp64) rows; runs shorter than a chunk keep the tiled kernel
+        # Z with chunks that straddle ends of the innermost M group (round 5): the last site of rows 3 / 4 of a corner sweep
+        # -- the open-leg run is 36 / 216 long, the chunk 64 (fp32) or 32 (fp64) rows: one to three breaks per chunk
         ("hvab,hxvy->axby", dict(h=6, v=6, a=32, b=216, x=6, y=6)),
         ("hvab,hxvy->axby", dict(h=6, v=6, a=128, b=36, x=6, y=6)),
         ("vab,vxy->axby", dict(v=6, a=64, b=108, x=6, y=6)),            # K = 6, run of 108
         ("hvcab,hxvy->caxby", dict(h=4, v=4, c=3, a=32, b=72, x=4, y=4)),   # three M groups, D = 4
+        ("hvab,hxvy->axby", dict(h=6, v=6, a=256, b=20, x=6, y=6)),     # run of 20: up to four pieces per 64-row chunk
     ]
     dev = qa.default_device()
     for eq, dims in cases:
@@ -496,7 +497,7 @@ def check_stream_kernels(dtype, seed=8):
                 dev.profile = None
         assert_close(got.to_numpy(), want, dtype)
         chunk = 64 if np.dtype(dtype).itemsize == 4 else 32
-        if prof and "axby" in out and dims["b"] >= chunk:      # on the HIP device: the streaming kernel's Z path, not the tiled one
+        if prof and "axby" in out and 4 * dims["b"] >= chunk:  # on the HIP device: the streaming kernel's Z path, not the tiled one
             assert any(n.startswith("stream_kernel<") and n.rstrip(">").endswith("true") for n in names), (eq, names)
     # ... and through a tree with the fused exponent epilogue (scales in, absmax out of the Z stores)
     a = rand(rng, (6, 6, 32, 216), dtype) * 1e20
