@@ -1077,7 +1077,8 @@ extern "C" int qamd_pair_describe(const qamd_pair_plan* p, char* buf, int32_t bu
   }
   if (p->kernel == 5) {
     const int ta = p->tile_cfg / 16, tb = p->tile_cfg % 16;
-    snprintf(buf, buflen, "gemmk_kernel<%d, %d, 3, %d>", ta, tb, ta * tb <= 6 ? 2 : 1);
+    const bool two = ta * tb == 12 || ta * tb == 9;   // (gemmk.hip, QAMD_GEMMK_CASES: two-stage ring, two workgroups per CU)
+    snprintf(buf, buflen, "gemmk_kernel<%d, %d, %d, %d>", ta, tb, two ? 2 : 3, (two || ta * tb <= 6) ? 2 : 1);
     return QAMD_OK;
   }
   if (p->kernel == 6) {

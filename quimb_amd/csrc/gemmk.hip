@@ -240,9 +240,12 @@ __global__ __launch_bounds__(256, MINW) void gemmk_kernel(const GettArgs p, cons
     const int stn_ = st + 1 >= NS ? 0 : st + 1;                                                               \
     const int st2_ = stn_ + 1 >= NS ? 0 : stn_ + 1;                                                           \
     _Pragma("unroll") for (int s = 0; s < NSTEPS_; ++s) {                                                    \
-      const bool sync_ = (s == NSTEPS_ - 3);                                                                  \
+      /* NS == 2: the request for tile t + 2 overwrites THIS tile's stage, so the barrier is the tile's last */ \
+      /* step (every wave has read all of it; the reads have returned: lgkmcnt)                             */ \
+      const bool sync_ = (s == NSTEPS_ - (NS == 2 ? 1 : 3));                                                  \
       if (sync_) {                                                                                            \
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                      \
+        if (NS == 2) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                              \
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                 \
         __builtin_amdgcn_s_barrier();                                                                         \
         asm volatile("" ::: "memory");                                                                        \
       }                                                                                                       \
@@ -422,6 +425,14 @@ static int launch_one(const GettArgs& a, const void* A, const void* B, void* C, 
 
 using namespace qamdk;
 
+// (tile, ring stages, workgroups per CU).  The 12- and 9-sub-tile wave tiles run a TWO-stage ring so that two workgroups
+// share a CU (2 x 61 KB of LDS, 237 registers): the other workgroup's MFMAs fill this one's barrier, prologue and
+// epilogue -- 7776^3: 134.7 -> 139.6 TFLOP/s, 8192^3 on 192 x 256: 125.5 -> 129.9 (profiles/r05_gemmk_two_per_cu.txt).
+// 4 x 4 (256 accumulator registers) and the 8-sub-tile shapes (no gain measured) keep three stages.
+#define QAMD_GEMMK_CASES                                                                \
+  QK_CASE(4, 4, 3, 1) QK_CASE(4, 3, 2, 2) QK_CASE(3, 4, 2, 2) QK_CASE(3, 3, 2, 2)        \
+  QK_CASE(4, 2, 3, 1) QK_CASE(2, 4, 3, 1) QK_CASE(3, 2, 3, 2) QK_CASE(2, 3, 3, 2) QK_CASE(2, 2, 3, 2)
+
 // ta, tb in {2, 3, 4}: workgroup tile (64 ta) x (64 tb).  a->tiles_m / tiles_n must be ceil(M / 64 ta), ceil(N / 64 tb);
 // a->sa_k0 / sb_k0 the strides of the single K group; a->vec_c >= tb enables vector stores along n.
 // Preconditions (host planner): fp32, M % 4 == N % 4 == 0, M, N >= 4, K % 8 == 0, 16-byte aligned operands whose free
@@ -430,10 +441,9 @@ extern "C" int qamd_gemmk_launch(int ta, int tb, const GettArgs* a, const void* 
                                  const void* scale_a, const void* scale_b, void* absmax_out, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   if (a->K < 48 || a->K % 8 || a->M < 4 || a->N < 4 || a->M % 4 || a->N % 4) return -2;
-#define QK_CASE(TA_, TB_, MINW_) \
-  if (ta == TA_ && tb == TB_) return launch_one<TA_, TB_, 3, MINW_>(*a, A, B, C, scale_a, scale_b, absmax_out, st);
-  QK_CASE(4, 4, 1) QK_CASE(4, 3, 1) QK_CASE(3, 4, 1) QK_CASE(3, 3, 1)
-  QK_CASE(4, 2, 1) QK_CASE(2, 4, 1) QK_CASE(3, 2, 2) QK_CASE(2, 3, 2) QK_CASE(2, 2, 2)
+#define QK_CASE(TA_, TB_, NS_, MINW_) \
+  if (ta == TA_ && tb == TB_) return launch_one<TA_, TB_, NS_, MINW_>(*a, A, B, C, scale_a, scale_b, absmax_out, st);
+  QAMD_GEMMK_CASES
 #undef QK_CASE
   return -2;
 }
@@ -445,11 +455,10 @@ extern "C" int qamd_gemmk_dot_launch(int ta, int tb, const GettArgs* a, const vo
                                      void* partial, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   if (a->K < 48 || a->K % 8 || a->M < 4 || a->N < 4 || a->M % 4 || a->N % 4) return -2;
-#define QK_CASE(TA_, TB_, MINW_) \
-  if (ta == TA_ && tb == TB_)    \
-    return launch_one<TA_, TB_, 3, MINW_, true>(*a, A, B, const_cast<void*>(T), nullptr, nullptr, partial, st);
-  QK_CASE(4, 4, 1) QK_CASE(4, 3, 1) QK_CASE(3, 4, 1) QK_CASE(3, 3, 1)
-  QK_CASE(4, 2, 1) QK_CASE(2, 4, 1) QK_CASE(3, 2, 2) QK_CASE(2, 3, 2) QK_CASE(2, 2, 2)
+#define QK_CASE(TA_, TB_, NS_, MINW_) \
+  if (ta == TA_ && tb == TB_)         \
+    return launch_one<TA_, TB_, NS_, MINW_, true>(*a, A, B, const_cast<void*>(T), nullptr, nullptr, partial, st);
+  QAMD_GEMMK_CASES
 #undef QK_CASE
   return -2;
 }

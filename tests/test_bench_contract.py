@@ -209,8 +209,8 @@ def test_roofline_classes_table():
         return GettSpec(b=(), m=((M, K, 0, N),), n=((N, 0, 1, 1),), k=((K, 1, N, 0),))
 
     join, stream, tiny = gett(7776, 7776, 7776), gett(6**9, 36, 36), gett(216, 36, 36)
-    prof = [(join, None, "gemmk_kernel<3, 4, 3, 1>", 1, Ev(0.0), Ev(7.0)),
-            (join, None, "gemmk_kernel<3, 4, 3, 1>", 1, Ev(7.0), Ev(14.0)),
+    prof = [(join, None, "gemmk_kernel<3, 4, 2, 2>", 1, Ev(0.0), Ev(7.0)),
+            (join, None, "gemmk_kernel<3, 4, 2, 2>", 1, Ev(7.0), Ev(14.0)),
             (stream, None, "sweep_kernel<float>", 1, Ev(0.0), Ev(0.6)),
             (tiny, None, "gett_kernel<float,4,1,4>", 1, Ev(0.0), Ev(0.01)),
             (tiny, None, "stream_kernel<float,2>", 1, Ev(0.0), Ev(0.02))]

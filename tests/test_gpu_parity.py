@@ -83,7 +83,10 @@ def test_gemmk(hip):
         hip.profile = None
     pinned = [n for n in names[len(checks.GEMMK_CASES):]]
     assert all(n.startswith("gemmk_kernel") for n in pinned), pinned
-    assert {n for n in pinned} >= {f"gemmk_kernel<{a}, {b}, 3, {2 if a * b <= 6 else 1}>" for a in (2, 3, 4) for b in (2, 3, 4)}
+    # (12- and 9-sub-tile wave tiles: two-stage ring, two workgroups per CU; gemmk.hip QAMD_GEMMK_CASES)
+    two = lambda a, b: a * b in (12, 9)
+    assert {n for n in pinned} >= {f"gemmk_kernel<{a}, {b}, {2 if two(a, b) else 3}, {2 if two(a, b) or a * b <= 6 else 1}>"
+                                   for a in (2, 3, 4) for b in (2, 3, 4)}
 
 
 def test_gemmd(hip):

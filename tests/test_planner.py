@@ -29,7 +29,7 @@ def _describe(a_inds, a_shape, b_inds, b_shape, out, dtype="float32", pin=None, 
 
 
 @pytest.mark.parametrize("m,n,k,want", [
-    (7776, 7776, 7776, "gemmk_kernel<3, 4, 3, 1>"),      # the joins of the 10x10 D=6 quadrant tree: 1271 tiles = 4.96 rounds
+    (7776, 7776, 7776, "gemmk_kernel<3, 4, 2, 2>"),      # the joins of the 10x10 D=6 quadrant tree: 1271 tiles = 4.96 rounds
     (3888, 1944, 7776, "gemmk_kernel<2, 4, 3, 1>"),      # one rank of eight
     (3888, 3888, 7776, None),                            # one rank of four: any gemmk tile
     (8192, 8192, 8192, "gemmk_kernel<4, 4, 3, 1>"),
@@ -111,7 +111,7 @@ def test_join_dot_workspace_follows_the_gemmk_tiles():
 
     lib = _lib.load()
     name, p = _describe("km", (7776, 7776), "kn", (7776, 7776), "mn")
-    assert name == "gemmk_kernel<3, 4, 3, 1>"
+    assert name == "gemmk_kernel<3, 4, 2, 2>"
     assert lib.qamd_pair_dot_workspace_bytes(C.byref(p)) == 8 * 41 * 31
     name, p = _describe("km", (7776, 3888), "kn", (7776, 1944), "mn")          # one rank of eight: 128 x 256 tiles
     assert lib.qamd_pair_dot_workspace_bytes(C.byref(p)) == 8 * 31 * 8
