@@ -26,7 +26,8 @@
 //    ~2000 idle matrix-pipe cycles per k-tile).
 //  * workgroup = 8 waves (2 x 4), wave tile (16 TA) x (16 TB), TA in {2..5}, TB in {1, 2}: workgroup tiles
 //    (32 TA) x (64 TB) = 64 ... 160 by 64 / 128, ONE workgroup per CU = two waves per SIMD (one wave's fragment reads
-//    and barrier waits hide behind the other's MFMAs); the host picks the tile for the fewest rounds on 256 CUs
+//    and barrier waits hide behind the other's MFMAs) -- or, for grids of more workgroups than CUs, TWO per CU on a
+//    two-stage ring (qamd_gemmd_launch); the host picks the tile for the fewest rounds on 256 CUs
 //    (2560 x 2048 -> 160 x 128: 256 tiles, one round) and k slabs for under-filled grids (reduced by gett.hip's
 //    splitk_reduce_kernel).
 //  * edge tiles re-read the last valid granule / row (their rows and columns of the tile are never stored).
@@ -103,14 +104,14 @@ struct DLoader {
   }
 };
 
-template <int TA, int TB, bool AKC, bool BKC, bool SWAP>
-__global__ __launch_bounds__(512, 1) void gemmd_kernel(const GettArgs p, const double* __restrict__ A,
+template <int TA, int TB, bool AKC, bool BKC, bool SWAP, int NS = 4, int MINB = 1>
+__global__ __launch_bounds__(512, MINB) void gemmd_kernel(const GettArgs p, const double* __restrict__ A,
                                                        const double* __restrict__ B, double* __restrict__ C,
                                                        const int64_t* __restrict__ ktab,
                                                        const double* __restrict__ scale_a,
                                                        const double* __restrict__ scale_b,
                                                        double* __restrict__ absmax_out) {
-  constexpr int BM = 32 * TA, BN = 64 * TB, BK = 16, NS = 4;
+  constexpr int BM = 32 * TA, BN = 64 * TB, BK = 16;
   constexpr int STAGE = BK * (BM + BN);   // doubles per stage: A image, then B image
   extern __shared__ __attribute__((aligned(16))) char dsmem[];
   double* stages = reinterpret_cast<double*>(dsmem);
@@ -227,6 +228,7 @@ __global__ __launch_bounds__(512, 1) void gemmd_kernel(const GettArgs p, const d
   };
   constexpr int P = LA::NPW + LB::NPW;      // requests per wave and tile
   static_assert((P + 3) / 4 <= TA * TB, "every piece of a request needs an MFMA of its k-step to hide behind");
+  static_assert(NS != 2 || P <= TA * TB, "two-stage ring: the whole request goes out behind the last k-step's MFMAs");
 
   acc4 acc[TA][TB];
 #pragma unroll
@@ -297,7 +299,10 @@ __global__ __launch_bounds__(512, 1) void gemmd_kernel(const GettArgs p, const d
       if (last && more) {
         // this wave's pieces of tile t + 1 (requested during tile t - 1); the pieces of tile t + 2 issued in steps 0..2
         // of this tile may still be in flight
-        if (req) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(Q012) : "memory");
+        // (two-stage ring: the request for tile t + 2 goes out BEHIND this barrier, into this tile's stage -- every wave's
+        // reads of it must have returned)
+        if (NS == 2) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        else if (req) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(Q012) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
@@ -321,7 +326,9 @@ __global__ __launch_bounds__(512, 1) void gemmd_kernel(const GettArgs p, const d
           if (SWAP) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(bf[s & 1][j], af[s & 1][i], acc[i][j], 0, 0, 0);
           else acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[s & 1][i], bf[s & 1][j], acc[i][j], 0, 0, 0);
           // this k-step's share of the request for tile t + 2: pieces s, s + 4, ... behind the first MFMAs
-          if (req && s + 4 * (i * TB + j) < P) issue_piece(st2, s + 4 * (i * TB + j));
+          if (NS == 2) {
+            if (req && last && i * TB + j < P) issue_piece(st, i * TB + j);
+          } else if (req && s + 4 * (i * TB + j) < P) issue_piece(st2, s + 4 * (i * TB + j));
         }
     }
     st = stn;
@@ -366,37 +373,37 @@ __global__ __launch_bounds__(512, 1) void gemmd_kernel(const GettArgs p, const d
   }
 }
 
-template <int TA, int TB, bool AKC, bool BKC>
+template <int TA, int TB, bool AKC, bool BKC, int NS = 4, int MINB = 1>
 static int launch_swap(const GettArgs& a, int swap, const void* A, const void* B, void* C, const void* ktab,
                        const void* sa, const void* sb, void* amax, hipStream_t st) {
   constexpr int BM = 32 * TA, BN = 64 * TB;
-  const size_t lds = (size_t)4 * 16 * (BM + BN) * sizeof(double) + (size_t)(BM + BN) * sizeof(int64_t) + 1024;
+  const size_t lds = (size_t)NS * 16 * (BM + BN) * sizeof(double) + (size_t)(BM + BN) * sizeof(int64_t) + 1024;
   const unsigned grid = a.tiles_m * a.tiles_n * a.B * a.split_k;
   if (swap) {
     if (lds > 64 * 1024)
-      (void)hipFuncSetAttribute((const void*)gemmd_kernel<TA, TB, AKC, BKC, true>,
+      (void)hipFuncSetAttribute((const void*)gemmd_kernel<TA, TB, AKC, BKC, true, NS, MINB>,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    QAMD_LAUNCH((gemmd_kernel<TA, TB, AKC, BKC, true>), dim3(grid), dim3(512), lds, st, a, (const double*)A,
+    QAMD_LAUNCH((gemmd_kernel<TA, TB, AKC, BKC, true, NS, MINB>), dim3(grid), dim3(512), lds, st, a, (const double*)A,
                 (const double*)B, (double*)C, (const int64_t*)ktab, (const double*)sa, (const double*)sb, (double*)amax);
   } else {
     if (lds > 64 * 1024)
-      (void)hipFuncSetAttribute((const void*)gemmd_kernel<TA, TB, AKC, BKC, false>,
+      (void)hipFuncSetAttribute((const void*)gemmd_kernel<TA, TB, AKC, BKC, false, NS, MINB>,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    QAMD_LAUNCH((gemmd_kernel<TA, TB, AKC, BKC, false>), dim3(grid), dim3(512), lds, st, a, (const double*)A,
+    QAMD_LAUNCH((gemmd_kernel<TA, TB, AKC, BKC, false, NS, MINB>), dim3(grid), dim3(512), lds, st, a, (const double*)A,
                 (const double*)B, (double*)C, (const int64_t*)ktab, (const double*)sa, (const double*)sb, (double*)amax);
   }
   return hipGetLastError() == hipSuccess ? 0 : -4;
 }
 
-template <int TA, int TB>
+template <int TA, int TB, int NS = 4, int MINB = 1>
 static int launch_layout(const GettArgs& a, int swap, const void* A, const void* B, void* C, const void* ktab,
                          const void* sa, const void* sb, void* amax, hipStream_t st) {
   if (a.a_kcontig) {
-    if (a.b_kcontig) return launch_swap<TA, TB, true, true>(a, swap, A, B, C, ktab, sa, sb, amax, st);
-    return launch_swap<TA, TB, true, false>(a, swap, A, B, C, ktab, sa, sb, amax, st);
+    if (a.b_kcontig) return launch_swap<TA, TB, true, true, NS, MINB>(a, swap, A, B, C, ktab, sa, sb, amax, st);
+    return launch_swap<TA, TB, true, false, NS, MINB>(a, swap, A, B, C, ktab, sa, sb, amax, st);
   }
-  if (a.b_kcontig) return launch_swap<TA, TB, false, true>(a, swap, A, B, C, ktab, sa, sb, amax, st);
-  return launch_swap<TA, TB, false, false>(a, swap, A, B, C, ktab, sa, sb, amax, st);
+  if (a.b_kcontig) return launch_swap<TA, TB, false, true, NS, MINB>(a, swap, A, B, C, ktab, sa, sb, amax, st);
+  return launch_swap<TA, TB, false, false, NS, MINB>(a, swap, A, B, C, ktab, sa, sb, amax, st);
 }
 
 }  // namespace qamdd
@@ -414,6 +421,16 @@ extern "C" int qamd_gemmd_launch(int ta, int tb, const GettArgs* a, int swap, co
                                  void* stream) {
   hipStream_t st = (hipStream_t)stream;
   if (a->K < 16 || a->K % 16 || a->Kc % 16 || a->M < 2 || a->N < 2) return -2;
+  // More workgroups than CUs: the two-stage ring (half the LDS) with 4 waves per SIMD allowed, so that TWO workgroups share
+  // a CU and one's barrier waits, prologue and epilogue sit under the other's MFMAs -- 4096^3 on 128 x 128 tiles 63.9 -> 67.5
+  // TFLOP/s, 96 x 128: 55.1 -> 61.6, 160 x 64: 51.9 -> 59.3 (profiles/r05_gemmd_two_per_cu.txt).  Grids of at most one
+  // workgroup per CU (the chi = 512 matvec's products) keep the four-stage ring: nothing to overlap with, deeper prefetch.
+  if ((uint64_t)a->tiles_m * a->tiles_n * a->B * a->split_k > 256) {
+#define QD2_CASE(TA_, TB_) \
+  if (ta == TA_ && tb == TB_) return launch_layout<TA_, TB_, 2, 4>(*a, swap, A, B, C, ktab, scale_a, scale_b, absmax_out, st);
+    QD2_CASE(4, 2) QD2_CASE(3, 2) QD2_CASE(4, 1) QD2_CASE(5, 1)
+#undef QD2_CASE
+  }
 #define QD_CASE(TA_, TB_) \
   if (ta == TA_ && tb == TB_) return launch_layout<TA_, TB_>(*a, swap, A, B, C, ktab, scale_a, scale_b, absmax_out, st);
   QD_CASE(4, 2) QD_CASE(5, 2) QD_CASE(3, 2) QD_CASE(2, 2) QD_CASE(4, 1) QD_CASE(5, 1) QD_CASE(3, 1) QD_CASE(2, 1)

@@ -595,6 +595,9 @@ GEMMD_CASES = [
     ("mk,kn->mn", dict(m=64, k=1024, n=64)),            # one tile, long K: k slabs + the slab reduction
     ("xmk,kn->xmn", dict(x=2, m=70, k=48, n=64)),       # K = 48: three k-tiles exactly (the ring's prologue alone)
     ("mk,kn->mn", dict(m=66, k=16, n=64)),              # K = 16: ONE k-tile (below the planner's bar: pinned tiles only)
+    # more workgroups than CUs: the two-stage ring, two workgroups per CU (tiles 42 / 32 / 41 / 51), both loaders
+    ("mk,kn->mn", dict(m=2120, k=80, n=2090)),
+    ("km,nk->mn", dict(m=2120, k=48, n=1100)),
 ]
 
 
