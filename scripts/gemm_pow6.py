@@ -25,7 +25,7 @@ def timeit(fn, n=5):
     return e0.elapsed_time(e1) / n * 1e-3
 
 
-shapes = [(7776, 7776, 7776), (3888, 1944, 7776), (1944, 3888, 7776), (972, 7776, 7776), (3888, 7776, 7776),
+shapes = [(7776, 7776, 7776), (3888, 1944, 7776), (1944, 3888, 7776), (972, 7776, 7776), (3888, 7776, 7776), (3888, 3888, 7776),
           (1296, 1296, 7776), (7776, 7776, 1296), (4096, 4096, 4096), (8192, 8192, 8192), (2048, 2560, 512)]
 if quick:
     shapes = shapes[:3] + shapes[7:8]
