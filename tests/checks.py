@@ -576,6 +576,16 @@ def check_gemmk(seed=21, tiles=(None,)):
                 bound = 2 * np.sqrt(kk) * 2.0**-24 * np.max(np.einsum(eq, np.abs(a).astype(np.float64), np.abs(b).astype(np.float64)))
                 err = np.max(np.abs(got.to_numpy().astype(np.float64) - want))
                 assert err <= bound, (eq, tile, err, bound)
+            if tile in (34, 43, 33):
+                # the two-stage ring of these tiles (the request for tile t + 2 overwrites tile t's stage behind the
+                # tile's LAST k-step): every short k-loop, with and without the leading half tile, several tiles per CU
+                for kk in (64, 72, 80, 88, 96, 104, 120, 136, 200, 328):
+                    a = rand(rng, (kk, 200), "float32")
+                    b = rand(rng, (kk, 264), "float32")
+                    want = a.astype(np.float64).T @ b.astype(np.float64)
+                    got = qa.einsum("km,kn->mn", qa.asarray(a), qa.asarray(b)).to_numpy().astype(np.float64)
+                    bound = 2 * np.sqrt(kk) * 2.0**-24 * np.max(np.abs(a).astype(np.float64).T @ np.abs(b).astype(np.float64))
+                    assert np.max(np.abs(got - want)) <= bound, (tile, kk, np.max(np.abs(got - want)), bound)
         finally:
             dev.force_kernel, dev.force_tile_cfg = old_pin
             if hasattr(dev, "_pairs"):
