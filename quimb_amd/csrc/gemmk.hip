@@ -11,12 +11,16 @@
 //  * workgroup = 2 x 2 waves, wave tile (32 TA) x (32 TB) on v_mfma_f32_32x32x2_f32 (64 cycles per
 //    instruction and SIMD: one wave per SIMD issues the matrix pipe back to back and has ~12 issue
 //    slots to spare per MFMA), TA, TB in {2, 3, 4}: workgroup tiles 128 ... 256 on a side, picked by
-//    the host for the least quantisation loss on 256 CUs.
+//    the host for the least quantisation loss on 256 CUs.  The 12- and 9-sub-tile wave tiles run a
+//    TWO-stage ring so that two workgroups share a CU (QAMD_GEMMK_CASES below): whatever one wave
+//    loses at its barrier, prologue or epilogue, the SIMD's other wave fills.
 //  * operands go HBM/L2 -> LDS with LDS-DMA (global_load_lds_dwordx4), never through registers:
 //    the stage image [16 k][BM] / [16 k][BN] is lane-linear because the free bundle is contiguous, and
 //    a 32x32x2 fragment read (32 consecutive m of one k row per half wave) is conflict-free on it
-//    with no padding.  NS-stage ring, loads two k-tiles ahead, ONE barrier per k-tile
-//    (counted vmcnt: the tile being waited for was requested ~16 K cycles earlier).
+//    with no padding.  NS-stage ring, ONE barrier per k-tile.  NS = 3: loads two k-tiles ahead, the barrier
+//    three k-steps before the tile ends (the tile being waited for was requested ~16 K cycles earlier);
+//    NS = 2: one k-tile ahead, the barrier at the tile's last k-step (the request that follows it
+//    overwrites the stage this tile was read from).
 //  * edge tiles: lanes past M / N re-read the last valid vector (their rows / columns of the tile are
 //    never stored, and a product row only ever pollutes itself); K % 16 == 8 runs a half tile last.
 //  * TA / TB == 2 or 4: "permuted" fragments -- lane i of sub-tile t holds row TA*i + t, so ONE
