@@ -20,8 +20,6 @@ struct GettArgs {
   int64_t slab_stride;  // elements between split-K slabs
   int64_t sa_k0, sb_k0; // gemmk.hip: strides of the single K group
   int32_t vec_c;        // gemmk.hip: elements of C that are contiguous and aligned along n (1, 2, 4)
-  int32_t tail_first;   // gemmk.hip: first tile of the k-split tail (>= tiles: no tail)
-  int32_t tail_split;   // gemmk.hip: k parts per tail tile
   int32_t pad_;
   // gemmd.hip: the K groups themselves (k offsets are computed in registers, not read from the k-offset table: a
   // table read in the request path would tie the request counter to ordinary loads)
