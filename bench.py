@@ -169,6 +169,9 @@ def _launch_work(spec):
     if hasattr(spec, "off_k1") and hasattr(spec, "K1"):  # fused pair of steps (Chain2Spec)
         shape = {"fused_steps": 2, "M": spec.M, "D": spec.D, "K": spec.K1, "N": spec.NO * spec.D}
         return shape, 4 * (spec.a_size + spec.c_size + spec.K1 * spec.D**2 + spec.D**3 * spec.NO), 2 * spec.mults
+    if hasattr(spec, "w_strides") and hasattr(spec, "s_groups"):  # a whole row of site absorptions (RowpassSpec)
+        shape = {"fused_steps": len(spec.sv), "D": spec.D, "out_elems": spec.c_size}
+        return shape, 4 * (spec.a_size + spec.c_size + len(spec.sv) * spec.D**4), 2 * spec.mults
     shape = {"B": spec.B, "M": spec.M, "N": spec.N, "K": spec.K}
     return (shape, 4 * spec.B * (spec.M * spec.K + spec.K * spec.N + spec.M * spec.N),
             2 * spec.B * spec.M * spec.N * spec.K)

@@ -175,6 +175,31 @@ int qamd_contract_chain2(const qamd_chain2_plan* plan, const void* A, const void
                          const void* scale_2, void* absmax_out, void* stream);
 
 /*
+ * One ROW of a 2D boundary sweep in ONE launch (csrc/rowpass.hip).  quimb absorbs a row into the boundary tensor site by
+ * site -- quimb/tensor/tn2d/core.py:1393-1402, in exact mode five dependent pairwise contractions per row of a 5-wide
+ * block -- which for the small rows of a corner sweep is dispatch latency, not bandwidth.  This entry is those five steps:
+ *
+ *   C[S, d1..d5, h] = sum_{v1..v5, b1..b4} A[S, v1..v5] W[0][v1, d1, b1] W[1][v2, b1, d2, b2] ... W[4][v5, b4, d5, h]
+ *
+ * fp32, nsites = 5, every leg of the site tensors of size D = 6 (qamd_rowpass_supported says what else is served: nothing
+ * yet).  S = every other index of A, as up to 4 groups (dim_s, A strides sa_s, C strides sc_s, outermost first); sv / sd / sh:
+ * element strides of the up legs in A and of the new down legs / the row's new open leg in C; w_strides[c] = element strides
+ * of site c's (up, left bond, down, right bond) legs in W[c] (site 0 has no left bond, site 4's right bond is h).  A, C and
+ * the W[c] are read and written in place at those strides: the call consumes and produces exactly the layouts the five
+ * separate steps would have.  scale_a / scale_w[c] / absmax_out: absmax slots as for the epilogue struct above (any NULL;
+ * scale_w itself may be NULL): C is scaled by 1 / (max|A| max|W[0]| ... max|W[4]|); the intermediates never exist.
+ */
+typedef struct {
+  int32_t dtype, D, nsites, nS;
+  int64_t sv[5], sd[5], sh;
+  int64_t dim_s[4], sa_s[4], sc_s[4];
+  int64_t w_strides[5][4];
+} qamd_rowpass_plan;
+int qamd_rowpass_supported(int32_t dtype, int32_t D, int32_t nsites);
+int qamd_contract_rowpass(const qamd_rowpass_plan* plan, const void* A, const void* const* W, void* C, const void* scale_a,
+                          const void* const* scale_w, void* absmax_out, void* stream);
+
+/*
  * slots: n_tensors x QAMD_ABSMAX_SLOTS values (float for F32/C64, double
  * otherwise).  *out_dev (double, device) = sum_t log10(max over tensor t's slots),
  * tensors whose max is 0 are skipped.
@@ -327,7 +352,7 @@ int qamd_microtree_run(int32_t dtype, const qamd_micro_step* steps_dev, int32_t 
  *                                                        re-based onto input_ptrs[i] at every run)
  *   qamd_program_run(P, lane_streams, input_ptrs, timing);   (lane 0 = the caller's stream: forked from / joined to)
  *
- * Recorded are: qamd_contract_pair(_ex), qamd_contract_pair_dot, qamd_contract_chain2, qamd_permute, qamd_reduce_sum, qamd_binary,
+ * Recorded are: qamd_contract_pair(_ex), qamd_contract_pair_dot, qamd_contract_chain2, qamd_contract_rowpass, qamd_permute, qamd_reduce_sum, qamd_binary,
  * qamd_scale, qamd_axpby(_exp), qamd_conj, qamd_cast, qamd_fill, qamd_complex_expand, qamd_strip_exponent,
  * qamd_absmax_log10_sum(_add), qamd_div_by_absmax, qamd_unary, qamd_minmax, qamd_absmax.  Plan compilation
  * (qamd_pair_build_ktab) and qamd_microtree_run execute immediately.  Every buffer a recorded call names -- other

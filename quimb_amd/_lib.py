@@ -52,6 +52,17 @@ class Chain2PlanStruct(C.Structure):
     ]
 
 
+class RowpassPlanStruct(C.Structure):
+    """Mirror of ``qamd_rowpass_plan``."""
+
+    _fields_ = [
+        ("dtype", C.c_int32), ("D", C.c_int32), ("nsites", C.c_int32), ("nS", C.c_int32),
+        ("sv", C.c_int64 * 5), ("sd", C.c_int64 * 5), ("sh", C.c_int64),
+        ("dim_s", C.c_int64 * 4), ("sa_s", C.c_int64 * 4), ("sc_s", C.c_int64 * 4),
+        ("w_strides", (C.c_int64 * 4) * 5),
+    ]
+
+
 class Epilogue(C.Structure):
     """Mirror of ``qamd_epilogue``."""
 
@@ -97,6 +108,8 @@ SYMBOLS = [
     ("qamd_absmax_log10_sum_add", C.c_int, [_vp, _i64, _i32, _vp, _vp]),
     # a join consumed by one inner product (gemmk.hip, DOT variant)
     ("qamd_pair_dot_workspace_bytes", _i64, [_vp]),
+    ("qamd_rowpass_supported", C.c_int, [_i32, _i32, _i32]),
+    ("qamd_contract_rowpass", C.c_int, [C.POINTER(RowpassPlanStruct), _vp, C.POINTER(C.c_void_p), _vp, _vp, C.POINTER(C.c_void_p), _vp, _vp]),
     ("qamd_contract_pair_dot", C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp]),
     # the vector work of a Lanczos step (krylov.hip)
     ("qamd_krylov_workspace_bytes", _i64, [_i32, _i64, _i32]),

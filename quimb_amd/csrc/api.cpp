@@ -1238,6 +1238,43 @@ extern "C" int qamd_contract_chain2(const qamd_chain2_plan* p, const void* A, co
 }
 
 // ---------------------------------------------------------------------------
+// one row of a 2D boundary sweep in one launch (rowpass.hip)
+// ---------------------------------------------------------------------------
+extern "C" int qamd_rowpass_supported(int32_t dtype, int32_t D, int32_t nsites) {
+  return dtype == QAMD_F32 && D == 6 && nsites == 5;
+}
+
+extern "C" int qamd_contract_rowpass(const qamd_rowpass_plan* p, const void* A, const void* const* W, void* C,
+                                     const void* scale_a, const void* const* scale_w, void* absmax_out, void* stream) {
+  if (!p || !W) return QAMD_EINVAL;
+  if (qamdp_recording()) return qamdp_rec_rowpass(p, A, W, C, scale_a, scale_w, absmax_out);
+  if (!A || !C) return QAMD_EINVAL;
+  if (!qamd_rowpass_supported(p->dtype, p->D, p->nsites) || p->nS < 0 || p->nS > 4) return QAMD_EUNSUPPORTED;
+  RowArgs a;
+  memset(&a, 0, sizeof(a));
+  int64_t items = p->D;
+  for (int i = 0; i < 5; ++i) {
+    if (!W[i]) return QAMD_EINVAL;
+    a.sv[i] = p->sv[i];
+    a.sd[i] = p->sd[i];
+    for (int j = 0; j < 4; ++j) a.ws[i][j] = p->w_strides[i][j];
+  }
+  a.sh = p->sh;
+  a.nS = p->nS;
+  for (int g = 0; g < p->nS; ++g) {
+    if (p->dim_s[g] <= 0 || p->dim_s[g] >= (1ll << 31)) return QAMD_EINVAL;
+    a.dimS[g] = (uint32_t)p->dim_s[g];
+    a.sSa[g] = p->sa_s[g];
+    a.sSc[g] = p->sc_s[g];
+    items *= p->dim_s[g];
+    if (items >= (1ll << 31)) return QAMD_EUNSUPPORTED;
+  }
+  a.items = (uint32_t)items;
+  const int rc = qamd_rowpass_launch(&a, A, W, C, scale_a, scale_w, absmax_out, stream);
+  return rc == 0 ? QAMD_OK : (rc == -2 ? QAMD_EUNSUPPORTED : QAMD_ELAUNCH);
+}
+
+// ---------------------------------------------------------------------------
 // device-resident tree of small contractions (microtree.hip)
 // ---------------------------------------------------------------------------
 extern "C" int qamd_microtree_launch(int dtype, const qamd_micro_step* steps_dev, int nsteps, const int32_t* etab,

@@ -71,6 +71,17 @@ struct DotArgs {
   uint32_t grid;        // workgroups = slabs of partial sums
 };
 
+// one row of a 2D boundary sweep in one launch (rowpass.hip): five sites, bond dimension 6
+struct RowArgs {
+  int64_t sv[5];        // strides (elements) of the five up legs v1..v5 in the boundary tensor
+  int64_t sd[5], sh;    // strides of the new down legs d1..d5 and of the row's new open leg h in the result
+  int32_t nS, pad_;     // spectator groups (every other index of the boundary tensor), outermost first
+  uint32_t dimS[4];
+  int64_t sSa[4], sSc[4];
+  int64_t ws[5][4];     // site tensor strides of (up, left, down, right); site 0 has no left leg, site 4's right leg is h
+  uint32_t items, pad2_;   // (number of S values) x 6
+};
+
 struct KtabArgs {
   int32_t nk;
   uint32_t K, Kpad;
@@ -93,6 +104,8 @@ int qamd_dotm_launch(int dtype, const DotArgs* a, const void* R, const void* v, 
 int qamd_stream_launch(int dtype, int V, const StreamArgs* a, const void* A, const void* B, void* C,
                        const void* ktab, const void* scale_a, const void* scale_b, void* absmax_out,
                        void* stream);
+int qamd_rowpass_launch(const RowArgs* a, const void* A, const void* const* W, void* C, const void* scale_a,
+                        const void* const* scale_w, void* absmax_out, void* stream);
 int qamd_sweep_launch_f32(int PS, const StreamArgs* a, const void* A, const void* B, void* C, const void* ktab,
                           const void* scale_a, const void* scale_b, void* absmax_out, void* stream);
 int qamd_sweep_launch_f64(int PS, const StreamArgs* a, const void* A, const void* B, void* C, const void* ktab,

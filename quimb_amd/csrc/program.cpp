@@ -121,6 +121,15 @@ int qamdp_rec_chain2(const qamd_chain2_plan* p, const void* A, const void* W1, c
   put_blob(o, p);
   return QAMD_OK;
 }
+int qamdp_rec_rowpass(const qamd_rowpass_plan* p, const void* A, const void* const* W, void* C, const void* sa,
+                      const void* const* sw, void* amax) {
+  if (!p || !W) return QAMD_EINVAL;
+  // pointer slots: A, C, W[0..4], scale_a, scale_w[0..4], absmax_out
+  Op& o = push(QP_ROWPASS, {A, C, W[0], W[1], W[2], W[3], W[4], sa, sw ? sw[0] : nullptr, sw ? sw[1] : nullptr,
+                            sw ? sw[2] : nullptr, sw ? sw[3] : nullptr, sw ? sw[4] : nullptr, amax});
+  put_blob(o, p);
+  return QAMD_OK;
+}
 int qamdp_rec_permute(void* dst, const void* src, int32_t ndim, const int64_t* shape, const int64_t* strides,
                       int64_t offset, int32_t dtype) {
   if (ndim < 0 || ndim > QAMD_MAX_NDIM) return QAMD_EINVAL;
@@ -282,6 +291,11 @@ static int run_op(const Op& o, const void* const* q, void* st) {
     case QP_CHAIN2:
       return qamd_contract_chain2((const qamd_chain2_plan*)o.blob.data(), q[0], q[1], q[2], P0(3), q[4], q[5], q[6],
                                   q[7], q[8], P0(9), st);
+    case QP_ROWPASS: {
+      const void* W[5] = {q[2], q[3], q[4], q[5], q[6]};
+      const void* sw[5] = {q[8], q[9], q[10], q[11], q[12]};
+      return qamd_contract_rowpass((const qamd_rowpass_plan*)o.blob.data(), q[0], W, P0(1), q[7], sw, P0(13), st);
+    }
     case QP_PERMUTE: {
       const int nd = (int)o.iv[0];
       return qamd_permute(P0(0), q[1], nd, o.arr.data(), o.arr.data() + nd, o.iv[1], (int32_t)o.iv[2], st);

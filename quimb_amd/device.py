@@ -323,6 +323,47 @@ class HipDevice:
         self.release_temp(ws_keep)
         return True
 
+    # ---- one row of a boundary sweep in one launch --------------------------------------
+    def contract_rowpass(self, rp, dtype, a, ws, c, ep=None):
+        """C = the five site absorptions of one row applied to A (rowpass.hip).  ``rp``: pairwise.RowpassSpec; ``ws``:
+        the five site tensors in their own layouts; ``ep`` = (slots_a, slots_w0 .. slots_w4, slots_out) or None."""
+        key = ("rowpass", rp, dtype_code(dtype))
+        pl = self._pairs.get(key)
+        if pl is None:
+            pl = _lib.RowpassPlanStruct()
+            pl.dtype, pl.D, pl.nsites, pl.nS = dtype_code(dtype), rp.D, len(rp.sv), len(rp.s_groups)
+            for i in range(5):
+                pl.sv[i], pl.sd[i] = rp.sv[i], rp.sd[i]
+                for j in range(4):
+                    pl.w_strides[i][j] = rp.w_strides[i][j]
+            pl.sh = rp.sh
+            for i, (d, sa_, sc_) in enumerate(rp.s_groups):
+                pl.dim_s[i], pl.sa_s[i], pl.sc_s[i] = d, sa_, sc_
+            self._pairs[key] = pl
+        ptr = lambda t: (t.data_ptr() if t is not None else None)
+        wp = (C.c_void_p * 5)(*[w.data_ptr() for w in ws])
+        sa = so = None
+        sw = None
+        if ep is not None:
+            sa, so = ptr(ep[0]), ptr(ep[6])
+            sw = (C.c_void_p * 5)(*[ptr(t) for t in ep[1:6]])
+        name = f"rowpass_kernel<{rp.D}, {len(rp.sv)}>"
+        prof = self.profile
+        if prof is not None and rp.mults < self.profile_min_mults:
+            prof = None
+        if self.record is not None:
+            prof = None
+            self.record.maybe_mark(rp, np.dtype(dtype), lambda: (name, 1))
+        if prof is not None:
+            e0 = self.torch.cuda.Event(enable_timing=True)
+            e1 = self.torch.cuda.Event(enable_timing=True)
+            e0.record()
+        _lib.check(self.lib.qamd_contract_rowpass(C.byref(pl), a.data_ptr(), wp, c.data_ptr(), sa, sw, so, self.stream()),
+                   "qamd_contract_rowpass")
+        if prof is not None:
+            e1.record()
+            prof.append((rp, np.dtype(dtype), name, 1, e0, e1))
+
     # ---- fused pair of streaming steps ---------------------------------------------
     def contract_chain2(self, c2, dtype, a, w1, w2, c, ep=None, pin=None):
         """C = (A . W1) . W2 in one pass (chain2r.hip / chain2.hip).  ``c2``: pairwise.Chain2Spec;

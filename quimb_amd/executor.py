@@ -23,7 +23,7 @@ import numpy as np
 from .array import Array, asarray, _coerce_dtype
 from .ops import _einsum_single, run_pair_step
 from .options import get_options
-from .pairwise import plan_chain2, plan_pair, prod
+from .pairwise import ROWPASS_SITES, plan_chain2, plan_pair, plan_rowpass, prod
 from .tree import ContractionTree
 
 
@@ -123,6 +123,7 @@ class TreeExecutor:
             self.info.append(StepInfo(step.kind, step.mults, nbytes, dims, dep[res]))
         self.layout = layout
         self.dep = dep
+        self._fuse_rows(size)
         self._fuse_pairs(size)
         self._fuse_join_dot()
         self._assign_lanes()
@@ -133,6 +134,82 @@ class TreeExecutor:
         if n == 1 and not tree.steps:
             self.out_inds = tuple(tree.output)
         self._hoisted = None  # cache of slice-independent intermediates for the current inputs
+
+    def _fuse_rows(self, size):
+        """Five consecutive site absorptions of a SMALL boundary-sweep row (each step's result the next one's big operand)
+        become one launch (``qamd_contract_rowpass``, csrc/rowpass.hip): in the first rows of a corner sweep every step
+        is ~12 us of dispatch latency around a few microseconds of work, and five of them depend on each other.  The fused
+        entry reads and writes the layouts the five steps had; rows too large to be latency-bound (``ROWPASS_MAX_OUT``)
+        and everything that does not have the row structure (``plan_rowpass``) stay as they were -- fused pairs take
+        the large rows.  ``options.fuse_rows = False`` keeps every step a separate launch."""
+        if self.dtype != np.dtype("float32") or not self.options.fuse_rows:
+            return
+        plan, info = self.plan, self.info
+        uses = {}
+        for e in plan:
+            for o in self._entry_io(e)[0]:
+                uses[o] = uses.get(o, 0) + 1
+        isz = self.dtype.itemsize
+
+        def big_small(entry):
+            if entry[0] != "pair":
+                return None
+            _, a, b, r, st = entry
+            if st.kind != "gett" or any(st.pre) or st.spec.b:
+                return None
+            return ((b, a) if st.swapped else (a, b)) + (r, st)
+
+        # pass 1: which runs of five steps have the row structure (layouts as planned step by step)
+        runs = {}
+        i = 0
+        while i < len(plan):
+            run = []
+            for j in range(i, min(i + ROWPASS_SITES, len(plan))):
+                bs = big_small(plan[j])
+                if bs is None or (run and (bs[0] != run[-1][2] or uses.get(bs[0], 0) != 1
+                                           or self.dep[bs[2]] != self.dep[run[0][2]])):
+                    break
+                run.append(bs)
+            if len(run) == ROWPASS_SITES and plan_rowpass(self.layout[run[0][0]], [self.layout[r[1]] for r in run],
+                                                           run[-1][3].out_inds, size, self.dtype.name) is not None:
+                runs[i] = run
+                i += ROWPASS_SITES
+            else:
+                i += 1
+        # pass 2: a fused row whose result feeds the NEXT fused row (and nothing else) is free to write it in the order
+        # that serves both kernels -- spectators and the new open leg outermost, the five new down legs innermost: the
+        # producer then stores 5 KB runs and the consumer's work items read 31 KB contiguous each, instead of 24-byte runs
+        # and a 7776-line gather in the death-ordered layout.  (The last fused row keeps the planned layout: what follows
+        # it -- fused pairs, streaming kernels -- was planned against that.)
+        by_big = {run[0][0]: i_ for i_, run in runs.items()}
+        new_plan, new_info = [], []
+        i = 0
+        while i < len(plan):
+            run = runs.get(i)
+            rp = None
+            if run is not None:
+                res = run[-1][2]
+                lc = tuple(run[-1][3].out_inds)
+                if res in by_big and uses.get(res, 0) == 1:
+                    nxt_sites = set()
+                    for r in runs[by_big[res]]:
+                        nxt_sites |= set(self.layout[r[1]])
+                    downs = [ix for ix in lc if ix in nxt_sites]              # the next row's up legs, in their order
+                    if len(downs) == ROWPASS_SITES:
+                        lc = tuple(ix for ix in lc if ix not in nxt_sites) + tuple(downs)
+                rp = plan_rowpass(self.layout[run[0][0]], [self.layout[r[1]] for r in run], lc, size, self.dtype.name)
+            if rp is not None:
+                res = run[-1][2]
+                self.layout[res] = rp.out_inds
+                new_plan.append(("rowpass", run[0][0], tuple(r[1] for r in run), res, rp))
+                new_info.append(StepInfo("rowpass", rp.mults, isz * (rp.a_size + rp.c_size + ROWPASS_SITES * rp.D**4),
+                                         (1, rp.c_size // rp.D**2, rp.D**2, rp.D**2), self.dep[res]))
+                i += ROWPASS_SITES
+            else:
+                new_plan.append(plan[i])
+                new_info.append(info[i])
+                i += 1
+        self.plan, self.info = new_plan, new_info
 
     def _fuse_pairs(self, size):
         """Replace consecutive big-x-small steps that have the two-site structure by one
@@ -209,6 +286,8 @@ class TreeExecutor:
             return (entry[1],), entry[2]
         if k == "chain2":
             return (entry[1], entry[2], entry[3]), entry[4]
+        if k == "rowpass":
+            return (entry[1],) + tuple(entry[2]), entry[3]
         if k == "pairdot":
             return (entry[1], entry[2], entry[3]), entry[4]
         return (entry[1], entry[2]), entry[3]
@@ -466,6 +545,8 @@ class TreeExecutor:
                 return (entry[1],)
             if entry[0] == "chain2":
                 return (entry[1], entry[2], entry[3])
+            if entry[0] == "rowpass":
+                return (entry[1],) + tuple(entry[2])
             if entry[0] == "pairdot":
                 return (entry[1], entry[2], entry[3])
             return (entry[1], entry[2])
@@ -567,6 +648,25 @@ class TreeExecutor:
                     if independent and cache is not None:
                         cache[res] = x
                 ids = (a, w1, w2)
+            elif entry[0] == "rowpass":
+                _, a, wids, res, rp = entry
+                independent = not self.dep[res]
+                if independent and cache is not None and res in cache:
+                    live[res] = cache[res]
+                elif only_independent and not independent:
+                    continue
+                else:
+                    x = Array.empty(rp.out_shape, self.dtype, dev)
+                    ep = None
+                    if exponent is not None:
+                        ep = tuple(dev.slots_row(slots, s_) if s_ in has_scale else None for s_ in (a,) + tuple(wids))
+                        ep = ep + (dev.slots_row(slots, res),)
+                        has_scale.add(res)
+                    dev.contract_rowpass(rp, self.dtype, live[a]._buf, [live[w_]._buf for w_ in wids], x._buf, ep)
+                    live[res] = x
+                    if independent and cache is not None:
+                        cache[res] = x
+                ids = (a,) + tuple(wids)
             elif entry[0] == "pairdot":
                 _, a, b, t, res, jstep, dstep, jres, join_first = entry
                 x = Array.empty(dstep.out_shape, self.dtype, dev)

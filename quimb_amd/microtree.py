@@ -48,7 +48,7 @@ class MicroTree:
 
         from .options import get_options
 
-        ex = TreeExecutor(tree, dtype, options=get_options().replace(fuse_pairs=False))     # one plan entry per pairwise step
+        ex = TreeExecutor(tree, dtype, options=get_options().replace(fuse_pairs=False, fuse_rows=False))     # one plan entry per pairwise step
         if tree.nslices != 1:
             raise ValueError("MicroTree: sliced trees are not supported")
         self.tree, self.dtype = tree, np.dtype(dtype)

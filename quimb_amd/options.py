@@ -26,6 +26,7 @@ class Options:
     # ---- plan building (TreeExecutor.__init__) ------------------------------------------------------------------------
     regroup: bool = True            #: (A.W1).W2 -> A.(W1.W2) where cheaper                          [QAMD_REGROUP]
     fuse_pairs: bool = True         #: two consecutive big-x-small steps -> one fused launch           [QAMD_CHAIN2]
+    fuse_rows: bool = True          #: five site absorptions of a small boundary-sweep row -> one launch  [QAMD_ROWPASS]
     join_dot: bool = True           #: the closing inner product inside the last join's epilogue       [QAMD_JOIN_DOT]
     join_order: bool = True         #: issue the first join's chains first                             [QAMD_JOIN_ORDER]
     lane_priority: bool = False     #: stream priorities for the lanes (measured: a loss)              [QAMD_LANE_PRIORITY]
@@ -59,7 +60,7 @@ class Options:
         env = os.environ if env is None else env
         on = lambda k, d: (env.get(k, "1" if d else "0") != "0") if d else (env.get(k, "0") == "1")
         kw = dict(
-            regroup=on("QAMD_REGROUP", True), fuse_pairs=on("QAMD_CHAIN2", True), join_dot=on("QAMD_JOIN_DOT", True),
+            regroup=on("QAMD_REGROUP", True), fuse_pairs=on("QAMD_CHAIN2", True), fuse_rows=on("QAMD_ROWPASS", True), join_dot=on("QAMD_JOIN_DOT", True),
             join_order=on("QAMD_JOIN_ORDER", True), lane_priority=on("QAMD_LANE_PRIORITY", False),
             hold_late=env.get("QAMD_HOLD_LATE", "auto"), program_join_order=on("QAMD_PROGRAM_JOIN_ORDER", False),
             pair_kernel=int(env.get("QAMD_KERNEL", "0")), tile_cfg=int(env.get("QAMD_TILE_CFG", "-1")),

@@ -420,6 +420,99 @@ class Chain2Spec:
         return prod(g[0] for g in self.m)
 
 
+@dataclass(frozen=True)
+class RowpassSpec:
+    """Five consecutive site absorptions of a boundary sweep fused into one launch (see rowpass.hip)."""
+
+    D: int
+    sv: tuple         # boundary-tensor strides of the five up legs
+    sd: tuple         # result strides of the five new down legs
+    sh: int           # result stride of the row's new open leg
+    s_groups: tuple   # spectators: groups (dim, stride_in_A, stride_in_C), outermost first
+    w_strides: tuple  # per site: strides of (up, left bond, down, right bond) in the site tensor
+    out_inds: tuple
+    out_shape: tuple
+    mults: int        # scalar multiplications of the five steps
+    a_size: int
+    c_size: int
+
+ROWPASS_SITES = 5
+ROWPASS_MAX_OUT = 1 << 24      # elements of the row's result: beyond that a row is bandwidth, not latency (fused pairs)
+
+
+def rowpass_supported(dtype_name, D, nsites):
+    """(mirror of qamd_rowpass_supported)"""
+    return dtype_name == "float32" and D == 6 and nsites == ROWPASS_SITES
+
+
+def plan_rowpass(la, site_layouts, lc, size, dtype_name):
+    """Try to express FIVE consecutive site absorptions of a boundary sweep as ONE ``qamd_contract_rowpass``
+    (csrc/rowpass.hip; quimb absorbs the row site by site, quimb/tensor/tn2d/core.py:1393-1402).  ``la``: layout of the
+    boundary tensor the first site meets, ``site_layouts``: the five site tensors' layouts in absorption order, ``lc``:
+    the layout already chosen for the LAST step's result (all index tuples of C-contiguous arrays).  Returns a
+    ``RowpassSpec`` or None when the steps do not have the row structure
+
+        site 0: up v1 -> (down d1, bond b1);   site c: (up v, bond b_c) -> (down d, bond b_c+1);   site 4: -> (d5, open h)
+
+    with every leg of the site tensors of one size D, the up legs taken from the boundary tensor itself, the bonds
+    consumed by the next site and everything else of the boundary tensor untouched (the spectators S)."""
+    if len(site_layouts) != ROWPASS_SITES:
+        return None
+    la, lc = tuple(la), tuple(lc)
+    if len(set(la)) != len(la) or len(set(lc)) != len(lc):
+        return None
+    sa = dict(zip(la, contig_strides(tuple(size[i] for i in la))))
+    sc = dict(zip(lc, contig_strides(tuple(size[i] for i in lc))))
+    cur, bond, D = set(la), None, None
+    sv, sd, ws, sh = [], [], [], None
+    touched = set()
+    for c, lw in enumerate(site_layouts):
+        lw = tuple(lw)
+        if len(set(lw)) != len(lw) or (bond is not None and bond not in lw):
+            return None
+        touched |= set(lw)
+        sw = dict(zip(lw, contig_strides(tuple(size[i] for i in lw))))
+        ups = [ix for ix in lw if ix in cur and ix != bond]
+        new = [ix for ix in lw if ix not in cur]
+        if len(ups) != 1 or len(new) != 2 or len(lw) != (3 if bond is None else 4) or ups[0] not in sa:
+            return None
+        up = ups[0]
+        D = size[up] if D is None else D
+        if any(size[ix] != D for ix in lw):
+            return None
+        if c < ROWPASS_SITES - 1:
+            nb = [ix for ix in new if ix in site_layouts[c + 1]]       # the bond the NEXT site carries
+            if len(nb) != 1:
+                return None
+            nbond = nb[0]
+            down = new[0] if new[1] == nbond else new[1]
+            if nbond in sc or down not in sc:
+                return None
+        else:
+            down, nbond = new                                          # (d5, h): two open legs, either naming works
+            if down not in sc or nbond not in sc:
+                return None
+            sh = sc[nbond]
+        sv.append(sa[up])
+        sd.append(sc[down])
+        ws.append((sw[up], sw[bond] if bond is not None else 0, sw[down], sw[nbond]))
+        cur = (cur - {up, bond}) | {down, nbond}
+        bond = nbond
+    if not rowpass_supported(dtype_name, D, ROWPASS_SITES) or cur != set(lc):
+        return None
+    spect = [ix for ix in la if ix not in touched]
+    gs = _fuse(spect, size, [sa, sc])
+    n_s = prod(size[i] for i in spect)
+    c_size = prod(size[i] for i in lc)
+    if len(gs) > 4 or c_size > ROWPASS_MAX_OUT or n_s * D >= 2**31:
+        return None
+    # multiplications of the five steps as they would have run one by one: D^7 for the first site, D^8 for each other
+    mults = n_s * (D**7 + (ROWPASS_SITES - 1) * D**8)
+    return RowpassSpec(D=D, sv=tuple(sv), sd=tuple(sd), sh=sh, s_groups=tuple((d, st[0], st[1]) for d, st in gs),
+                       w_strides=tuple(ws), out_inds=lc, out_shape=tuple(size[i] for i in lc), mults=mults,
+                       a_size=prod(size[i] for i in la), c_size=c_size)
+
+
 def plan_chain2(la, l1, lx, l2, lc, size, dtype_name, variants=True):
     """Try to fuse  X[lx] = A[la].W1[l1]  and  C[lc] = X.W2[l2]  (all layouts are index
     tuples of C-contiguous arrays; ``lc`` is the layout already chosen for C).  Returns a

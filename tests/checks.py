@@ -2361,3 +2361,102 @@ def check_program_on_general_trees(dtype, seed=11):
                     want = ref.to_numpy()
                 truth = orc.oracle_array_contract([a.astype(hi) for a in host], inputs, output)
                 assert_close(want, np.asarray(truth), dtype)
+
+
+def check_rowpass(seed=41):
+    """One row of a boundary sweep in one launch (csrc/rowpass.hip, ``qamd_contract_rowpass``) against numpy: the boundary
+    tensor, the five site tensors and the result in RANDOM index orders (the entry reads and writes whatever layouts the
+    five separate steps would have had), 1 to 3 spectator indices, with and without the fused exponent epilogue."""
+    from quimb_amd.pairwise import plan_rowpass
+
+    rng = np.random.default_rng(seed)
+    dev = qa.default_device()
+    D = 6
+    for nspect in (1, 2, 3, 1):
+        spect = [f"s{i}" for i in range(nspect)]
+        ups = [f"v{i}" for i in range(5)]
+        downs = [f"d{i}" for i in range(5)]
+        bonds = [f"b{i}" for i in range(4)]
+        sdim = {ix: D for ix in ups + downs + bonds + ["h"]}
+        sdim.update({ix: int(rng.integers(2, 5)) for ix in spect})
+        la = list(rng.permutation(spect + ups))
+        sites = []
+        for c in range(5):
+            legs = [ups[c], downs[c]] + ([bonds[c - 1]] if c else []) + ([bonds[c]] if c < 4 else ["h"])
+            sites.append(tuple(rng.permutation(legs)))
+        lc = tuple(rng.permutation(spect + downs + ["h"]))
+        rp = plan_rowpass(tuple(la), sites, lc, sdim, "float32")
+        assert rp is not None and rp.out_inds == lc
+        a = rand(rng, [sdim[i] for i in la], "float32")
+        ws = [rand(rng, [sdim[i] for i in t], "float32") for t in sites]
+        num = {ix: i for i, ix in enumerate(sdim)}
+        sub = lambda t: [num[ix] for ix in t]
+        want = np.einsum(a.astype(np.float64), sub(la), *[x for w, t in zip(ws, sites) for x in (w.astype(np.float64), sub(t))],
+                         sub(lc), optimize=True)
+        xa, xw = qa.asarray(a), [qa.asarray(w) for w in ws]
+        out = qa.Array.empty(rp.out_shape, "float32", dev)
+        dev.contract_rowpass(rp, np.dtype("float32"), xa._buf, [w._buf for w in xw], out._buf, None)
+        got = out.to_numpy().astype(np.float64)
+        assert_close(got, want, "float32")
+    # row structures the entry does not serve are refused at plan time: four sites, a bond of another size, a site that
+    # takes its up leg from somewhere else
+    assert plan_rowpass(tuple(la), sites[:4], lc, sdim, "float32") is None
+    assert plan_rowpass(tuple(la), sites, lc, dict(sdim, b1=5), "float32") is None
+    assert plan_rowpass(tuple(la), sites, lc, sdim, "float64") is None
+
+
+def check_row_fusion(shapes=((4, 10), (6, 10)), seed=3, blocks=(2, 3)):
+    """Trees with fused rows (TreeExecutor._fuse_rows).  ``blocks``: the top-left R x 5 block of a 10-wide D = 6 lattice with
+    its cut legs open, absorbed site by site -- rows 2..R become one launch each, and between two fused rows the tensor takes
+    the kernels' own order -- against numpy's fp64 einsum of the same block.  ``shapes``: the quadrant trees of whole
+    Lx x 10 networks against the fp64 oracle and against the same tree with every step its own launch, plain and with
+    strip_exponent."""
+    for R in blocks:
+        arrays, inputs = orc.tn2d_rand(2 * R, 10, 6, seed=seed, dtype="float64")
+        # (tn2d_rand lists the sites row by row: keep rows < R, columns < 5)
+        keep = [r * 10 + c for r in range(R) for c in range(5)]
+        sub_in = [tuple(inputs[i]) for i in keep]
+        sub_ar = [arrays[i] for i in keep]
+        cnt = {}
+        for t in sub_in:
+            for ix in t:
+                cnt[ix] = cnt.get(ix, 0) + 1
+        out = tuple(ix for t in sub_in for ix in t if cnt[ix] == 1)
+        size = {ix: 6 for t in sub_in for ix in t}
+        n = len(sub_in)
+        ssa = [(0, 1)] + [(n + k - 1, k + 1) for k in range(1, n - 1)]
+        tree = qa.ContractionTree(sub_in, out, size, ssa_path=ssa)
+        ex = qa.TreeExecutor(tree, "float32")
+        assert sum(1 for e in ex.plan if e[0] == "rowpass") == R - 1, [e[0] for e in ex.plan]
+        num = {ix: i for i, ix in enumerate(size)}
+        want = np.einsum(*[x for a, t in zip(sub_ar, sub_in) for x in (a, [num[ix] for ix in t])], [num[ix] for ix in out],
+                         optimize=True)
+        xs = [qa.asarray(a.astype(np.float32)) for a in sub_ar]
+        assert_close(ex(xs).to_numpy(), want, "float32")
+        m, e = ex(xs, strip_exponent=True)
+        assert_close(m.to_numpy().astype(np.float64) * 10.0 ** float(e), want, "float32")
+    for (Lx, Ly) in shapes:
+        arrays, inputs = orc.tn2d_rand(Lx, Ly, 6, seed=seed, dtype="float64")
+        inputs = [tuple(t) for t in inputs]
+        size = {ix: 6 for t in inputs for ix in t}
+        path = qa.quadrant_path_2d(Lx, Ly)
+        tree = qa.ContractionTree(inputs, (), size, path=path)
+        ref = float(np.asarray(orc.oracle_array_contract(arrays, inputs, (), path=path)).item())
+        xs = [qa.asarray(a.astype(np.float32)) for a in arrays]
+        ex = qa.TreeExecutor(tree, "float32")
+        nrow = sum(1 for e in ex.plan if e[0] == "rowpass")
+        assert nrow == 4 * (Lx // 2 - 1), (Lx, nrow)
+        with qa.exec_options(fuse_rows=False):
+            ex0 = qa.TreeExecutor(tree, "float32")
+        assert not any(e[0] == "rowpass" for e in ex0.plan) and len(ex0.plan) > len(ex.plan)
+        for strip in (False, True):
+            vals = []
+            for e_ in (ex, ex0):
+                r = e_(xs, strip_exponent=strip)
+                vals.append(float(r[0].to_numpy().item()) * 10.0 ** float(r[1]) if strip else float(r.to_numpy().item()))
+            # (on the plan interpreter the steps are numpy's own fp32 einsums -- sequential sums, 2.3e-6 on the 6 x 10
+            # network fused or not -- so the bar there is 5e-6; the device's MFMA chains are held to the 1e-6 of RTOL)
+            tol = 5e-6 if getattr(qa.default_device(), "name", "") == "emu" else None
+            for v in vals:
+                assert_close(np.array([v]), np.array([ref]), "float32", tol=tol)
+

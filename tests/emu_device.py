@@ -85,6 +85,37 @@ class EmuDevice:
         out[0] = z
         return True
 
+    def contract_rowpass(self, rp, dtype, a, ws, c, ep=None):
+        """Semantics of qamd_contract_rowpass (include/quimb_amd.h): five site absorptions, strided in and out."""
+        self.calls["rowpass"] = self.calls.get("rowpass", 0) + 1
+        D = rp.D
+        os_a = _offsets([(d, sa) for d, sa, _ in rp.s_groups], 1)
+        os_c = _offsets([(d, sc) for d, _, sc in rp.s_groups], 1)
+        ov = _offsets([(D, s) for s in rp.sv], 1)
+        T = a[os_a[:, None] + ov[None, :]].reshape((len(os_a),) + (D,) * 5)            # [S, v1..v5]
+        W = []
+        for i, st in enumerate(rp.w_strides):
+            dims = [(D, st[0]), (D if i else 1, st[1]), (D, st[2]), (D, st[3])]
+            W.append(ws[i][_offsets(dims, 1)].reshape(D, D if i else 1, D, D))       # [up, left, down, right]
+        X = np.einsum("sabcde,axyz->sbcdeyz", T, W[0])[..., :, :]                      # site 0 (left extent 1 summed)
+        # X[s, v2..v5, d1, b1] -> absorb sites 1..4
+        X = np.einsum("sbcdeyz,bzpq->scdeypq", X, W[1])     # -> [s, v3, v4, v5, d1, d2, b2]
+        X = np.einsum("scdeypq,cqrt->sdeyprt", X, W[2])     # -> [s, v4, v5, d1, d2, d3, b3]
+        X = np.einsum("sdeyprt,dtuv->seypruv", X, W[3])     # -> [s, v5, d1, d2, d3, d4, b4]
+        X = np.einsum("seypruv,evwh->sypruwh", X, W[4])     # -> [s, d1..d5, h]
+        if ep is not None:
+            scl = 1.0
+            for t in ep[:6]:
+                if t is not None and t.max() > 0:
+                    scl *= float(t.max())
+            X = X * np.asarray(1.0 / scl, dtype=X.real.dtype)
+            if ep[6] is not None and X.size:
+                ep[6][0] = max(ep[6][0], np.max(np.abs(X)))
+        od = _offsets([(D, s) for s in rp.sd] + [(D, rp.sh)], 1)
+        idx = os_c[:, None] + od[None, :]
+        assert len(np.unique(idx)) == idx.size
+        c[idx] = X.reshape(len(os_c), -1)
+
     def contract_chain2(self, c2, dtype, a, w1, w2, c, ep=None, pin=None):
         """Semantics of qamd_contract_chain2 (see include/quimb_amd.h); the small tensors arrive in
         their own layouts and are gathered as ``c2.w1_pack`` / ``w2_pack`` describe."""

@@ -89,6 +89,13 @@ def test_gemmk(hip):
                                    for a in (2, 3, 4) for b in (2, 3, 4)}
 
 
+def test_rowpass(hip):
+    """One row of a boundary sweep in one launch (rowpass.hip): random index orders on every operand against numpy, then the
+    quadrant trees of 4x10 / 6x10 D = 6 networks with fused rows against the fp64 oracle and against the unfused plans."""
+    checks.check_rowpass()
+    checks.check_row_fusion()
+
+
 def test_gemmd(hip):
     """fp64 MFMA GETT on the LDS-DMA ring (gemmd.hip): k-contiguous and free-contiguous operands in every combination,
     ragged edges, swapped roles, K in two groups, batch, k slabs -- with the planner's tile and with workgroup tiles

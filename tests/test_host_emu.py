@@ -447,3 +447,28 @@ def test_constants_are_folded_once(emu):
 def test_program_interface_on_the_interpreter(emu):
     """The program checks' host logic on the plan interpreter (``EagerProgram``: every call re-executes the plan)."""
     checks.check_program_on_general_trees("float64")
+
+
+def test_rowpass_on_the_plan_interpreter(emu):
+    """Five site absorptions of a row as ONE plan entry: plan_rowpass on random layouts and whole trees with fused rows, the
+    entry's semantics interpreted in numpy (tests/emu_device.py:contract_rowpass mirrors include/quimb_amd.h)."""
+    import quimb_amd as qa
+    from oracle import np_oracle as orc
+
+    checks.check_rowpass()
+    checks.check_row_fusion(shapes=())                 # (whole networks run on the device: their joins are minutes of numpy)
+    assert emu.calls.get("rowpass", 0) > 0
+    # two fused rows in a row (planning only): the tensor between them takes the kernels' own order -- spectators and the
+    # new open leg outermost, the next row's five up legs innermost and contiguous
+    _, inputs = orc.tn2d_rand(6, 10, 6, seed=3, dtype="float32")
+    inputs = [tuple(t) for t in inputs]
+    size = {ix: 6 for t in inputs for ix in t}
+    ex = qa.TreeExecutor(qa.ContractionTree(inputs, (), size, path=qa.quadrant_path_2d(6, 10)), "float32")
+    rows = [e for e in ex.plan if e[0] == "rowpass"]
+    assert len(rows) == 8
+    fed = {e[3]: e for e in rows}
+    pairs = [(fed[e[1]], e) for e in rows if e[1] in fed]
+    assert len(pairs) == 4
+    for first, second in pairs:
+        assert second[4].sv == (1296, 216, 36, 6, 1) and first[4].sd[:4] == (1296, 216, 36, 6)
+
