@@ -132,7 +132,8 @@ def test_fused_pairs(hip, Lx, Ly, D, dtype):
     want = wm.item() * 10.0**we
     opts = qa.get_options()
     # the tree exactly as given (no regrouping): every row has a start and an end pair
-    ex = qa.TreeExecutor(tree, dtype, options=opts.replace(fuse_pairs=True, regroup=False))
+    # (and no fused ROWS: on a D = 6 fp32 lattice the first five sites of a row would go to rowpass.hip, which has its own test)
+    ex = qa.TreeExecutor(tree, dtype, options=opts.replace(fuse_pairs=True, regroup=False, fuse_rows=False))
     assert any(e[0] == "chain2" for e in ex.plan)
     exr = qa.TreeExecutor(tree, dtype)   # default: small operands regrouped where that is a clear win
     assert exr.flops() <= ex.flops()
