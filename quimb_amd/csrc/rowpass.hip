@@ -52,7 +52,8 @@ __global__ __launch_bounds__(256, 2) void rowpass_kernel(const RowArgs p, const 
   extern __shared__ __attribute__((aligned(16))) float sm[];
   float* ST0 = sm;                      // [36][RP]
   float* ST1 = ST0 + DD * RP;           // [36][RP]
-  float* Wl = ST1 + DD * RP;            // [36][LDW]  (+ slack behind it: padded reads of the last state row end here)
+  float* Wl = ST1 + DD * RP;            // two site images [36][LDW] (+ slack: the padded reads of a state row's tail end in what follows it --
+                                        // finite or not, those columns m >= 216 only ever reach result columns that are not stored)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, kq = lane >> 4;
   const uint32_t item = blockIdx.x;
   const uint32_t d1 = item % D;
