@@ -188,6 +188,8 @@ int qamd_contract_chain2(const qamd_chain2_plan* plan, const void* A, const void
  * the W[c] are read and written in place at those strides: the call consumes and produces exactly the layouts the five
  * separate steps would have.  scale_a / scale_w[c] / absmax_out: absmax slots as for the epilogue struct above (any NULL;
  * scale_w itself may be NULL): C is scaled by 1 / (max|A| max|W[0]| ... max|W[4]|); the intermediates never exist.
+ * nS = -1: the FIRST row of a sweep -- no boundary tensor (A ignored, may be NULL), the site tensors have no up legs:
+ * C[d1..d5, h] = sum_b W[0][d1, b1] W[1][b1, d2, b2] ... W[4][b4, d5, h] (w_strides[c][0] unused).
  */
 typedef struct {
   int32_t dtype, D, nsites, nS;

@@ -1248,8 +1248,8 @@ extern "C" int qamd_contract_rowpass(const qamd_rowpass_plan* p, const void* A, 
                                      const void* scale_a, const void* const* scale_w, void* absmax_out, void* stream) {
   if (!p || !W) return QAMD_EINVAL;
   if (qamdp_recording()) return qamdp_rec_rowpass(p, A, W, C, scale_a, scale_w, absmax_out);
-  if (!A || !C) return QAMD_EINVAL;
-  if (!qamd_rowpass_supported(p->dtype, p->D, p->nsites) || p->nS < 0 || p->nS > 4) return QAMD_EUNSUPPORTED;
+  if (!C || (!A && p->nS >= 0)) return QAMD_EINVAL;
+  if (!qamd_rowpass_supported(p->dtype, p->D, p->nsites) || p->nS < -1 || p->nS > 4) return QAMD_EUNSUPPORTED;
   RowArgs a;
   memset(&a, 0, sizeof(a));
   int64_t items = p->D;
@@ -1269,7 +1269,7 @@ extern "C" int qamd_contract_rowpass(const qamd_rowpass_plan* p, const void* A, 
     items *= p->dim_s[g];
     if (items >= (1ll << 31)) return QAMD_EUNSUPPORTED;
   }
-  a.items = (uint32_t)items;
+  a.items = p->nS < 0 ? 0 : (uint32_t)items;
   const int rc = qamd_rowpass_launch(&a, A, W, C, scale_a, scale_w, absmax_out, stream);
   return rc == 0 ? QAMD_OK : (rc == -2 ? QAMD_EUNSUPPORTED : QAMD_ELAUNCH);
 }

@@ -207,20 +207,78 @@ __global__ __launch_bounds__(256, 2) void rowpass_kernel(const RowArgs p, const 
   }
 }
 
+// The FIRST row of a sweep has no boundary tensor yet: its five site tensors (the lattice edge: no up legs) are simply
+// multiplied along their bonds,
+//   C[d1..d5, h] = sum_{b1..b4} W0[d1, b1] W1[b1, d2, b2] W2[b2, d3, b3] W3[b3, d4, b4] W4[b4, d5, h]
+// -- four dependent launches of a few microseconds of work for the pairwise executor, one here.  A thread owns
+// (d1, d2, d3, d4): it carries the 6-vector over the open bond through sites 1..3 and writes its 36 results (d5, h).
+__global__ __launch_bounds__(256) void rowfirst_kernel(const RowArgs p, const RowPtrs w, float* __restrict__ C,
+                                                       float* __restrict__ absmax_out) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float vmax = 0.f;
+  if (e < D * D * D * D) {
+    const int d1 = e / (D * D * D), d2 = (e / (D * D)) % D, d3 = (e / D) % D, d4 = e % D;
+    const int dd[4] = {d1, d2, d3, d4};
+    float t[D], u[D];
+#pragma unroll
+    for (int b = 0; b < D; ++b) t[b] = w.W[0][d1 * p.ws[0][2] + b * p.ws[0][3]];
+#pragma unroll
+    for (int c = 1; c < 4; ++c) {
+#pragma unroll
+      for (int bn = 0; bn < D; ++bn) {
+        float s = 0.f;
+#pragma unroll
+        for (int b = 0; b < D; ++b) s += t[b] * w.W[c][b * p.ws[c][1] + dd[c] * p.ws[c][2] + bn * p.ws[c][3]];
+        u[bn] = s;
+      }
+#pragma unroll
+      for (int b = 0; b < D; ++b) t[b] = u[b];
+    }
+    float alpha = 1.f;
+#pragma unroll
+    for (int c = 0; c < 5; ++c) alpha /= rp_read_scale(w.scale_w[c]);
+    float* cp = C + d1 * p.sd[0] + d2 * p.sd[1] + d3 * p.sd[2] + d4 * p.sd[3];
+#pragma unroll
+    for (int d5 = 0; d5 < D; ++d5)
+#pragma unroll
+      for (int h = 0; h < D; ++h) {
+        float s = 0.f;
+#pragma unroll
+        for (int b = 0; b < D; ++b) s += t[b] * w.W[4][b * p.ws[4][1] + d5 * p.ws[4][2] + h * p.ws[4][3]];
+        s *= alpha;
+        cp[d5 * p.sd[4] + h * p.sh] = s;
+        vmax = fmaxf(vmax, fabsf(s));
+      }
+  }
+  if (absmax_out) {
+#pragma unroll
+    for (int dl = 32; dl > 0; dl >>= 1) vmax = fmaxf(vmax, __shfl_down(vmax, dl, 64));
+    if (lane == 0)
+      atomicMax(reinterpret_cast<unsigned int*>(absmax_out) + ((blockIdx.x * 4 + wave) % QAMD_SLOTS), __float_as_uint(vmax));
+  }
+}
+
 }  // namespace qamdr
 
 using namespace qamdr;
 
-// One row (five sites, D = 6) in one launch.  a->items = (number of S values) * 6.  W[c] / scale_w[c]: the five site
+// One row (five sites, D = 6) in one launch.  a->items = (number of S values) * 6; a->nS = -1: the first row (no boundary tensor).  W[c] / scale_w[c]: the five site
 // tensors and their absmax slots (NULL = 1); strides in a->ws (elements).
 extern "C" int qamd_rowpass_launch(const RowArgs* a, const void* A, const void* const* W, void* C, const void* scale_a,
                                    const void* const* scale_w, void* absmax_out, void* stream) {
-  if (!a || a->items == 0 || a->nS < 0 || a->nS > 4) return -2;
+  if (!a || a->nS > 4) return -2;
   RowPtrs w;
   for (int c = 0; c < 5; ++c) {
     w.W[c] = (const float*)W[c];
     w.scale_w[c] = scale_w ? (const float*)scale_w[c] : nullptr;
   }
+  if (a->nS < 0) {   // the first row of a sweep: no boundary tensor
+    QAMD_LAUNCH(rowfirst_kernel, dim3((D * D * D * D + 255) / 256), dim3(256), 0, (hipStream_t)stream, *a, w, (float*)C,
+                (float*)absmax_out);
+    return hipGetLastError() == hipSuccess ? 0 : -4;
+  }
+  if (a->items == 0) return -2;
   const size_t lds = (size_t)(2 * DD * RP + 2 * DD * LDW + 64) * sizeof(float);
   static bool attr_done = false;
   if (!attr_done) {

@@ -331,13 +331,14 @@ class HipDevice:
         pl = self._pairs.get(key)
         if pl is None:
             pl = _lib.RowpassPlanStruct()
-            pl.dtype, pl.D, pl.nsites, pl.nS = dtype_code(dtype), rp.D, len(rp.sv), len(rp.s_groups)
+            pl.dtype, pl.D, pl.nsites = dtype_code(dtype), rp.D, len(rp.sv)
+            pl.nS = -1 if rp.s_groups is None else len(rp.s_groups)          # -1: the first row, no boundary tensor
             for i in range(5):
                 pl.sv[i], pl.sd[i] = rp.sv[i], rp.sd[i]
                 for j in range(4):
                     pl.w_strides[i][j] = rp.w_strides[i][j]
             pl.sh = rp.sh
-            for i, (d, sa_, sc_) in enumerate(rp.s_groups):
+            for i, (d, sa_, sc_) in enumerate(rp.s_groups or ()):
                 pl.dim_s[i], pl.sa_s[i], pl.sc_s[i] = d, sa_, sc_
             self._pairs[key] = pl
         ptr = lambda t: (t.data_ptr() if t is not None else None)
@@ -358,7 +359,8 @@ class HipDevice:
             e0 = self.torch.cuda.Event(enable_timing=True)
             e1 = self.torch.cuda.Event(enable_timing=True)
             e0.record()
-        _lib.check(self.lib.qamd_contract_rowpass(C.byref(pl), a.data_ptr(), wp, c.data_ptr(), sa, sw, so, self.stream()),
+        _lib.check(self.lib.qamd_contract_rowpass(C.byref(pl), None if a is None else a.data_ptr(), wp, c.data_ptr(), sa, sw, so,
+                                                  self.stream()),
                    "qamd_contract_rowpass")
         if prof is not None:
             e1.record()

@@ -176,6 +176,36 @@ class TreeExecutor:
                 i += ROWPASS_SITES
             else:
                 i += 1
+        # the FIRST row of a sweep: W0 . W1 (two site tensors), then three more absorptions -- four launches for a product of
+        # five small tensors along their bonds; one launch of the same entry without a boundary tensor
+        firsts = {}
+        i = 0
+        while i + ROWPASS_SITES - 1 <= len(plan):
+            if i in runs or any(k in runs for k in range(max(i - ROWPASS_SITES + 1, 0), i)):
+                i += 1
+                continue
+            chain = []          # (big or previous result, site, result, step): roles by identity, not by size -- the
+            for j in range(i, min(i + ROWPASS_SITES - 1, len(plan))):      # first row's tensors are all about as small
+                bs = big_small(plan[j])
+                if bs is None:
+                    break
+                if chain:
+                    prev = chain[-1][2]
+                    if prev not in bs[:2] or uses.get(prev, 0) != 1 or self.dep[bs[2]] != self.dep[chain[0][2]]:
+                        break
+                    bs = (prev, bs[1] if bs[0] == prev else bs[0]) + bs[2:]
+                chain.append(bs)
+            if len(chain) == ROWPASS_SITES - 1:
+                a0, b0 = chain[0][0], chain[0][1]
+                if len(self.layout[a0]) > len(self.layout[b0]):
+                    a0, b0 = b0, a0                                   # the corner site (two legs) starts the row
+                sites = [a0, b0] + [c_[1] for c_ in chain[1:]]
+                if plan_rowpass(None, [self.layout[w_] for w_ in sites], chain[-1][3].out_inds, size,
+                                self.dtype.name) is not None:
+                    firsts[i] = (chain, sites)
+                    i += ROWPASS_SITES - 1
+                    continue
+            i += 1
         # pass 2: a fused row whose result feeds the NEXT fused row (and nothing else) is free to write it in the order
         # that serves both kernels -- spectators and the new open leg outermost, the five new down legs innermost: the
         # producer then stores 5 KB runs and the consumer's work items read 31 KB contiguous each, instead of 24-byte runs
@@ -184,19 +214,35 @@ class TreeExecutor:
         by_big = {run[0][0]: i_ for i_, run in runs.items()}
         new_plan, new_info = [], []
         i = 0
+        def next_row_layout(res, lc):
+            """``lc`` reordered for a fused consumer: everything else outermost, the consumer's five up legs innermost"""
+            if res in by_big and uses.get(res, 0) == 1:
+                nxt_sites = set()
+                for r in runs[by_big[res]]:
+                    nxt_sites |= set(self.layout[r[1]])
+                downs = [ix for ix in lc if ix in nxt_sites]
+                if len(downs) == ROWPASS_SITES:
+                    return tuple(ix for ix in lc if ix not in nxt_sites) + tuple(downs)
+            return lc
+
         while i < len(plan):
+            if i in firsts:
+                chain, sites = firsts[i]
+                res = chain[-1][2]
+                rp = plan_rowpass(None, [self.layout[w_] for w_ in sites], next_row_layout(res, tuple(chain[-1][3].out_inds)),
+                                  size, self.dtype.name)
+                if rp is not None:
+                    self.layout[res] = rp.out_inds
+                    new_plan.append(("rowpass", None, tuple(sites), res, rp))
+                    new_info.append(StepInfo("rowpass", rp.mults, isz * (rp.c_size + ROWPASS_SITES * rp.D**3),
+                                             (1, rp.c_size // rp.D**2, rp.D**2, rp.D), self.dep[res]))
+                    i += ROWPASS_SITES - 1
+                    continue
             run = runs.get(i)
             rp = None
             if run is not None:
                 res = run[-1][2]
-                lc = tuple(run[-1][3].out_inds)
-                if res in by_big and uses.get(res, 0) == 1:
-                    nxt_sites = set()
-                    for r in runs[by_big[res]]:
-                        nxt_sites |= set(self.layout[r[1]])
-                    downs = [ix for ix in lc if ix in nxt_sites]              # the next row's up legs, in their order
-                    if len(downs) == ROWPASS_SITES:
-                        lc = tuple(ix for ix in lc if ix not in nxt_sites) + tuple(downs)
+                lc = next_row_layout(res, tuple(run[-1][3].out_inds))
                 rp = plan_rowpass(self.layout[run[0][0]], [self.layout[r[1]] for r in run], lc, size, self.dtype.name)
             if rp is not None:
                 res = run[-1][2]
@@ -287,7 +333,7 @@ class TreeExecutor:
         if k == "chain2":
             return (entry[1], entry[2], entry[3]), entry[4]
         if k == "rowpass":
-            return (entry[1],) + tuple(entry[2]), entry[3]
+            return (() if entry[1] is None else (entry[1],)) + tuple(entry[2]), entry[3]
         if k == "pairdot":
             return (entry[1], entry[2], entry[3]), entry[4]
         return (entry[1], entry[2]), entry[3]
@@ -546,7 +592,7 @@ class TreeExecutor:
             if entry[0] == "chain2":
                 return (entry[1], entry[2], entry[3])
             if entry[0] == "rowpass":
-                return (entry[1],) + tuple(entry[2])
+                return (() if entry[1] is None else (entry[1],)) + tuple(entry[2])
             if entry[0] == "pairdot":
                 return (entry[1], entry[2], entry[3])
             return (entry[1], entry[2])
@@ -659,14 +705,16 @@ class TreeExecutor:
                     x = Array.empty(rp.out_shape, self.dtype, dev)
                     ep = None
                     if exponent is not None:
-                        ep = tuple(dev.slots_row(slots, s_) if s_ in has_scale else None for s_ in (a,) + tuple(wids))
+                        ep = tuple(dev.slots_row(slots, s_) if (s_ is not None and s_ in has_scale) else None
+                                   for s_ in (a,) + tuple(wids))
                         ep = ep + (dev.slots_row(slots, res),)
                         has_scale.add(res)
-                    dev.contract_rowpass(rp, self.dtype, live[a]._buf, [live[w_]._buf for w_ in wids], x._buf, ep)
+                    dev.contract_rowpass(rp, self.dtype, None if a is None else live[a]._buf,
+                                         [live[w_]._buf for w_ in wids], x._buf, ep)
                     live[res] = x
                     if independent and cache is not None:
                         cache[res] = x
-                ids = (a,) + tuple(wids)
+                ids = (() if a is None else (a,)) + tuple(wids)
             elif entry[0] == "pairdot":
                 _, a, b, t, res, jstep, dstep, jres, join_first = entry
                 x = Array.empty(dstep.out_shape, self.dtype, dev)

@@ -428,7 +428,7 @@ class RowpassSpec:
     sv: tuple         # boundary-tensor strides of the five up legs
     sd: tuple         # result strides of the five new down legs
     sh: int           # result stride of the row's new open leg
-    s_groups: tuple   # spectators: groups (dim, stride_in_A, stride_in_C), outermost first
+    s_groups: tuple   # spectators: groups (dim, stride_in_A, stride_in_C), outermost first; None = the first row (no boundary tensor)
     w_strides: tuple  # per site: strides of (up, left bond, down, right bond) in the site tensor
     out_inds: tuple
     out_shape: tuple
@@ -458,6 +458,8 @@ def plan_rowpass(la, site_layouts, lc, size, dtype_name):
     consumed by the next site and everything else of the boundary tensor untouched (the spectators S)."""
     if len(site_layouts) != ROWPASS_SITES:
         return None
+    if la is None:
+        return _plan_rowfirst(site_layouts, tuple(lc), size, dtype_name)
     la, lc = tuple(la), tuple(lc)
     if len(set(la)) != len(la) or len(set(lc)) != len(lc):
         return None
@@ -511,6 +513,50 @@ def plan_rowpass(la, site_layouts, lc, size, dtype_name):
     return RowpassSpec(D=D, sv=tuple(sv), sd=tuple(sd), sh=sh, s_groups=tuple((d, st[0], st[1]) for d, st in gs),
                        w_strides=tuple(ws), out_inds=lc, out_shape=tuple(size[i] for i in lc), mults=mults,
                        a_size=prod(size[i] for i in la), c_size=c_size)
+
+
+def _plan_rowfirst(site_layouts, lc, size, dtype_name):
+    """The FIRST row of a sweep (``plan_rowpass(None, ...)``): no boundary tensor, the five site tensors -- the lattice edge,
+    no up legs -- multiplied along their bonds:  site 0: (d1, b1);  site c: (b_c, d, b_c+1);  site 4: (b4, d5, h)."""
+    if len(set(lc)) != len(lc):
+        return None
+    sc = dict(zip(lc, contig_strides(tuple(size[i] for i in lc))))
+    bond, D = None, None
+    sd, ws, sh, seen = [], [], None, set()
+    for c, lw in enumerate(site_layouts):
+        lw = tuple(lw)
+        if len(set(lw)) != len(lw) or len(lw) != (2 if bond is None else 3) or (bond is not None and bond not in lw) \
+                or seen & (set(lw) - {bond}):
+            return None
+        seen |= set(lw)
+        sw = dict(zip(lw, contig_strides(tuple(size[i] for i in lw))))
+        new = [ix for ix in lw if ix != bond]
+        D = size[new[0]] if D is None else D
+        if any(size[ix] != D for ix in lw):
+            return None
+        if c < ROWPASS_SITES - 1:
+            nb = [ix for ix in new if ix in site_layouts[c + 1]]
+            if len(nb) != 1:
+                return None
+            nbond = nb[0]
+            down = new[0] if new[1] == nbond else new[1]
+            if nbond in sc or down not in sc:
+                return None
+        else:
+            down, nbond = new
+            if down not in sc or nbond not in sc:
+                return None
+            sh = sc[nbond]
+        sd.append(sc[down])
+        ws.append((0, sw[bond] if bond is not None else 0, sw[down], sw[nbond]))
+        bond = nbond
+    if not rowpass_supported(dtype_name, D, ROWPASS_SITES) or len(lc) != ROWPASS_SITES + 1:
+        return None
+    if set(lc) != {ix for lw in site_layouts for ix in lw if ix in sc}:
+        return None
+    mults = D**3 + D**4 + D**5 + D**6 * D     # the four pairwise steps it replaces
+    return RowpassSpec(D=D, sv=(0,) * ROWPASS_SITES, sd=tuple(sd), sh=sh, s_groups=None, w_strides=tuple(ws), out_inds=lc,
+                       out_shape=tuple(size[i] for i in lc), mults=mults, a_size=0, c_size=prod(size[i] for i in lc))
 
 
 def plan_chain2(la, l1, lx, l2, lc, size, dtype_name, variants=True):

@@ -2398,6 +2398,27 @@ def check_rowpass(seed=41):
         dev.contract_rowpass(rp, np.dtype("float32"), xa._buf, [w._buf for w in xw], out._buf, None)
         got = out.to_numpy().astype(np.float64)
         assert_close(got, want, "float32")
+    # the FIRST row of a sweep: no boundary tensor, site tensors without up legs (the entry's nS = -1 form)
+    for _ in range(2):
+        downs = [f"d{i}" for i in range(5)]
+        bonds = [f"b{i}" for i in range(4)]
+        sdim1 = {ix: D for ix in downs + bonds + ["h"]}
+        sites1 = []
+        for c in range(5):
+            legs = [downs[c]] + ([bonds[c - 1]] if c else []) + ([bonds[c]] if c < 4 else ["h"])
+            sites1.append(tuple(rng.permutation(legs)))
+        lc1 = tuple(rng.permutation(downs + ["h"]))
+        rp1 = plan_rowpass(None, sites1, lc1, sdim1, "float32")
+        assert rp1 is not None and rp1.s_groups is None and rp1.out_inds == lc1
+        ws1 = [rand(rng, [D] * len(t), "float32") for t in sites1]
+        num1 = {ix: i for i, ix in enumerate(sdim1)}
+        want1 = np.einsum(*[x for w, t in zip(ws1, sites1) for x in (w.astype(np.float64), [num1[ix] for ix in t])],
+                          [num1[ix] for ix in lc1], optimize=True)
+        xw1 = [qa.asarray(w) for w in ws1]
+        out1 = qa.Array.empty(rp1.out_shape, "float32", dev)
+        dev.contract_rowpass(rp1, np.dtype("float32"), None, [w._buf for w in xw1], out1._buf, None)
+        assert_close(out1.to_numpy().astype(np.float64), want1, "float32")
+    assert plan_rowpass(None, sites1[:4] + [sites1[4] + ("extra",)], lc1, dict(sdim1, extra=6), "float32") is None
     # row structures the entry does not serve are refused at plan time: four sites, a bond of another size, a site that
     # takes its up leg from somewhere else
     assert plan_rowpass(tuple(la), sites[:4], lc, sdim, "float32") is None
@@ -2407,7 +2428,8 @@ def check_rowpass(seed=41):
 
 def check_row_fusion(shapes=((4, 10), (6, 10)), seed=3, blocks=(2, 3)):
     """Trees with fused rows (TreeExecutor._fuse_rows).  ``blocks``: the top-left R x 5 block of a 10-wide D = 6 lattice with
-    its cut legs open, absorbed site by site -- rows 2..R become one launch each, and between two fused rows the tensor takes
+    its cut legs open, absorbed site by site -- rows 1..R become one launch each (row 1 in the entry's form without a boundary
+    tensor), and between two fused rows the tensor takes
     the kernels' own order -- against numpy's fp64 einsum of the same block.  ``shapes``: the quadrant trees of whole
     Lx x 10 networks against the fp64 oracle and against the same tree with every step its own launch, plain and with
     strip_exponent."""
@@ -2427,7 +2449,7 @@ def check_row_fusion(shapes=((4, 10), (6, 10)), seed=3, blocks=(2, 3)):
         ssa = [(0, 1)] + [(n + k - 1, k + 1) for k in range(1, n - 1)]
         tree = qa.ContractionTree(sub_in, out, size, ssa_path=ssa)
         ex = qa.TreeExecutor(tree, "float32")
-        assert sum(1 for e in ex.plan if e[0] == "rowpass") == R - 1, [e[0] for e in ex.plan]
+        assert sum(1 for e in ex.plan if e[0] == "rowpass") == R, [e[0] for e in ex.plan]      # (row 1: the no-boundary form)
         num = {ix: i for i, ix in enumerate(size)}
         want = np.einsum(*[x for a, t in zip(sub_ar, sub_in) for x in (a, [num[ix] for ix in t])], [num[ix] for ix in out],
                          optimize=True)
@@ -2445,7 +2467,7 @@ def check_row_fusion(shapes=((4, 10), (6, 10)), seed=3, blocks=(2, 3)):
         xs = [qa.asarray(a.astype(np.float32)) for a in arrays]
         ex = qa.TreeExecutor(tree, "float32")
         nrow = sum(1 for e in ex.plan if e[0] == "rowpass")
-        assert nrow == 4 * (Lx // 2 - 1), (Lx, nrow)
+        assert nrow == 4 * (Lx // 2), (Lx, nrow)          # every row of every corner but the networks' last ones ... and row 1
         with qa.exec_options(fuse_rows=False):
             ex0 = qa.TreeExecutor(tree, "float32")
         assert not any(e[0] == "rowpass" for e in ex0.plan) and len(ex0.plan) > len(ex.plan)

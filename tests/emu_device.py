@@ -89,6 +89,24 @@ class EmuDevice:
         """Semantics of qamd_contract_rowpass (include/quimb_amd.h): five site absorptions, strided in and out."""
         self.calls["rowpass"] = self.calls.get("rowpass", 0) + 1
         D = rp.D
+        if rp.s_groups is None:           # the first row: no boundary tensor, site tensors without up legs
+            W = []
+            for i, st in enumerate(rp.w_strides):
+                dims = [(D if i else 1, st[1]), (D, st[2]), (D, st[3])]
+                W.append(ws[i][_offsets(dims, 1)].reshape(D if i else 1, D, D))       # [left, down, right]
+            X = np.einsum("xab,bcd,def,fgh,hij->acegij", W[0], W[1], W[2], W[3], W[4], optimize=True)   # [d1..d5, h]
+            if ep is not None:
+                scl = 1.0
+                for t in ep[1:6]:
+                    if t is not None and t.max() > 0:
+                        scl *= float(t.max())
+                X = X * np.asarray(1.0 / scl, dtype=X.real.dtype)
+                if ep[6] is not None and X.size:
+                    ep[6][0] = max(ep[6][0], np.max(np.abs(X)))
+            idx = _offsets([(D, s_) for s_ in rp.sd] + [(D, rp.sh)], 1)
+            assert len(np.unique(idx)) == idx.size
+            c[idx] = X.reshape(-1)
+            return
         os_a = _offsets([(d, sa) for d, sa, _ in rp.s_groups], 1)
         os_c = _offsets([(d, sc) for d, _, sc in rp.s_groups], 1)
         ov = _offsets([(D, s) for s in rp.sv], 1)

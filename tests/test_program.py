@@ -251,7 +251,7 @@ def test_program_full_size_quadrant_tree(hip):
         assert np.sign(m) == ref["sign"] and abs(np.log10(abs(m)) + e - ref["log10_abs"]) < np.log10(1.0 + 1e-6)
     names = [n for (_, _, n, _, _, _) in prog.timings(1)]
     assert sum(n.startswith("gemmk_kernel") for n in names) == 2, names
-    assert 40 <= prog.num_launches <= 130      # (94 with every step a launch of its own; 46 with rows 2-4 of every corner fused)
+    assert 30 <= prog.num_launches <= 130      # (94 with every step a launch of its own; 34 with rows 1-4 of every corner fused)
 
 
 @pytest.mark.gpu
