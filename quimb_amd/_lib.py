@@ -60,6 +60,7 @@ class RowpassPlanStruct(C.Structure):
         ("sv", C.c_int64 * 5), ("sd", C.c_int64 * 5), ("sh", C.c_int64),
         ("dim_s", C.c_int64 * 4), ("sa_s", C.c_int64 * 4), ("sc_s", C.c_int64 * 4),
         ("w_strides", (C.c_int64 * 4) * 5),
+        ("ed", C.c_int32 * 5), ("eh", C.c_int32), ("kernel", C.c_int32), ("pad_", C.c_int32),
     ]
 
 

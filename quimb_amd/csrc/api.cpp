@@ -1252,7 +1252,20 @@ extern "C" int qamd_contract_rowpass(const qamd_rowpass_plan* p, const void* A, 
   if (!qamd_rowpass_supported(p->dtype, p->D, p->nsites) || p->nS < -1 || p->nS > 4) return QAMD_EUNSUPPORTED;
   RowArgs a;
   memset(&a, 0, sizeof(a));
-  int64_t items = p->D;
+  bool full = true;
+  for (int i = 0; i < 5; ++i) {
+    const int32_t e = p->ed[i] ? p->ed[i] : p->D;
+    if (e < 1 || e > p->D) return QAMD_EINVAL;
+    a.ed[i] = (uint32_t)e;
+    full = full && e == p->D;
+  }
+  {
+    const int32_t e = p->eh ? p->eh : p->D;
+    if (e < 1 || e > p->D) return QAMD_EINVAL;
+    a.eh = (uint32_t)e;
+    full = full && e == p->D;
+  }
+  int64_t items = a.ed[0];
   for (int i = 0; i < 5; ++i) {
     if (!W[i]) return QAMD_EINVAL;
     a.sv[i] = p->sv[i];
@@ -1261,6 +1274,8 @@ extern "C" int qamd_contract_rowpass(const qamd_rowpass_plan* p, const void* A, 
   }
   a.sh = p->sh;
   a.nS = p->nS;
+  int64_t a_span = 1;       // elements the boundary tensor spans: rowq addresses it with 32-bit per-lane offsets
+  for (int i = 0; i < 5; ++i) a_span += (p->D - 1) * (p->sv[i] < 0 ? -p->sv[i] : p->sv[i]);
   for (int g = 0; g < p->nS; ++g) {
     if (p->dim_s[g] <= 0 || p->dim_s[g] >= (1ll << 31)) return QAMD_EINVAL;
     a.dimS[g] = (uint32_t)p->dim_s[g];
@@ -1270,7 +1285,18 @@ extern "C" int qamd_contract_rowpass(const qamd_rowpass_plan* p, const void* A, 
     if (items >= (1ll << 31)) return QAMD_EUNSUPPORTED;
   }
   a.items = p->nS < 0 ? 0 : (uint32_t)items;
-  const int rc = qamd_rowpass_launch(&a, A, W, C, scale_a, scale_w, absmax_out, stream);
+  int kernel = p->kernel;
+  if (p->nS < 0) kernel = 1;                               // the first row: rowfirst_kernel lives in rowpass.hip
+  else if (kernel == 0) kernel = 2;
+  if (kernel == 1 && !full) return QAMD_EUNSUPPORTED;
+  if (kernel == 2 || kernel == 3) {
+    for (int i = 0; i < 5; ++i)
+      if (p->sv[i] < 0) return QAMD_EUNSUPPORTED;
+    if (a_span >= (1ll << 31)) return QAMD_EUNSUPPORTED;
+    if (kernel == 3) a.pad2_ = 512;      // equal static shares instead of the item queue
+  }
+  const int rc = kernel >= 2 ? qamd_rowq_launch(&a, A, W, C, scale_a, scale_w, absmax_out, stream)
+                             : qamd_rowpass_launch(&a, A, W, C, scale_a, scale_w, absmax_out, stream);
   return rc == 0 ? QAMD_OK : (rc == -2 ? QAMD_EUNSUPPORTED : QAMD_ELAUNCH);
 }
 

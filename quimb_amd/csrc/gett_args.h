@@ -79,7 +79,8 @@ struct RowArgs {
   uint32_t dimS[4];
   int64_t sSa[4], sSc[4];
   int64_t ws[5][4];     // site tensor strides of (up, left, down, right); site 0 has no left leg, site 4's right leg is h
-  uint32_t items, pad2_;   // (number of S values) x 6
+  uint32_t items, pad2_;   // (number of S values) x (extent of d1)
+  uint32_t ed[5], eh;      // rowq.hip: extents (<= 6) of the new down legs d1..d5 and of the open leg h
 };
 
 struct KtabArgs {
@@ -106,6 +107,8 @@ int qamd_stream_launch(int dtype, int V, const StreamArgs* a, const void* A, con
                        void* stream);
 int qamd_rowpass_launch(const RowArgs* a, const void* A, const void* const* W, void* C, const void* scale_a,
                         const void* const* scale_w, void* absmax_out, void* stream);
+int qamd_rowq_launch(const RowArgs* a, const void* A, const void* const* W, void* C, const void* scale_a,
+                     const void* const* scale_w, void* absmax_out, void* stream);
 int qamd_sweep_launch_f32(int PS, const StreamArgs* a, const void* A, const void* B, void* C, const void* ktab,
                           const void* scale_a, const void* scale_b, void* absmax_out, void* stream);
 int qamd_sweep_launch_f64(int PS, const StreamArgs* a, const void* A, const void* B, void* C, const void* ktab,

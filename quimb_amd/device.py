@@ -340,6 +340,9 @@ class HipDevice:
             pl.sh = rp.sh
             for i, (d, sa_, sc_) in enumerate(rp.s_groups or ()):
                 pl.dim_s[i], pl.sa_s[i], pl.sc_s[i] = d, sa_, sc_
+            for i in range(5):
+                pl.ed[i] = rp.ed[i]
+            pl.eh, pl.kernel = rp.eh, rp.kernel
             self._pairs[key] = pl
         ptr = lambda t: (t.data_ptr() if t is not None else None)
         wp = (C.c_void_p * 5)(*[w.data_ptr() for w in ws])
@@ -348,7 +351,9 @@ class HipDevice:
         if ep is not None:
             sa, so = ptr(ep[0]), ptr(ep[6])
             sw = (C.c_void_p * 5)(*[ptr(t) for t in ep[1:6]])
-        name = f"rowpass_kernel<{rp.D}, {len(rp.sv)}>"
+        name = "rowfirst_kernel" if rp.s_groups is None else (
+            f"rowpass_kernel<{rp.D}, {len(rp.sv)}>" if rp.kernel == 1 else
+            f"rowq_kernel<{'true' if not any(rp.ed) and not rp.eh else 'false'}>")
         prof = self.profile
         if prof is not None and rp.mults < self.profile_min_mults:
             prof = None

@@ -23,7 +23,7 @@ import numpy as np
 from .array import Array, asarray, _coerce_dtype
 from .ops import _einsum_single, run_pair_step
 from .options import get_options
-from .pairwise import ROWPASS_SITES, plan_chain2, plan_pair, plan_rowpass, prod
+from .pairwise import ROWPASS_MAX_OUT, ROWPASS_SITES, plan_chain2, plan_pair, plan_rowpass, prod
 from .tree import ContractionTree
 
 
@@ -145,6 +145,7 @@ class TreeExecutor:
         if self.dtype != np.dtype("float32") or not self.options.fuse_rows:
             return
         plan, info = self.plan, self.info
+        rk = self.options.row_kernel     # "auto" / "quad": rowq.hip, rows of any size; "tile": rowpass.hip, small rows only
         uses = {}
         for e in plan:
             for o in self._entry_io(e)[0]:
@@ -170,8 +171,17 @@ class TreeExecutor:
                                            or self.dep[bs[2]] != self.dep[run[0][2]])):
                     break
                 run.append(bs)
-            if len(run) == ROWPASS_SITES and plan_rowpass(self.layout[run[0][0]], [self.layout[r[1]] for r in run],
-                                                           run[-1][3].out_inds, size, self.dtype.name) is not None:
+            rp = None
+            if len(run) == ROWPASS_SITES:
+                rp = plan_rowpass(self.layout[run[0][0]], [self.layout[r[1]] for r in run], run[-1][3].out_inds, size,
+                                  self.dtype.name, rk)
+            if rp is not None and rp.c_size > ROWPASS_MAX_OUT and i + ROWPASS_SITES < len(plan):
+                # a LARGE row (bandwidth, not latency) is only worth one launch when it is the whole row: the entry
+                # cannot start mid-row, so a wider row would be split 5 + rest and the rest would lose its fused pairs
+                nxt = big_small(plan[i + ROWPASS_SITES])
+                if nxt is not None and nxt[0] == run[-1][2] and set(self.layout[nxt[1]]) & set(self.layout[run[-1][1]]):
+                    rp = None
+            if rp is not None:
                 runs[i] = run
                 i += ROWPASS_SITES
             else:
@@ -213,6 +223,7 @@ class TreeExecutor:
         # it -- fused pairs, streaming kernels -- was planned against that.)
         by_big = {run[0][0]: i_ for i_, run in runs.items()}
         new_plan, new_info = [], []
+        relaid = set()          # results whose layout pass 2 changed from the step-by-step plan's
         i = 0
         def next_row_layout(res, lc):
             """``lc`` reordered for a fused consumer: everything else outermost, the consumer's five up legs innermost"""
@@ -222,16 +233,26 @@ class TreeExecutor:
                     nxt_sites |= set(self.layout[r[1]])
                 downs = [ix for ix in lc if ix in nxt_sites]
                 if len(downs) == ROWPASS_SITES:
-                    return tuple(ix for ix in lc if ix not in nxt_sites) + tuple(downs)
+                    new = tuple(ix for ix in lc if ix not in nxt_sites) + tuple(downs)
+                    # commit the new order only if the CONSUMER row still plans against it (with the layout its own
+                    # result will get): its separate steps were planned against the old order and could not be kept
+                    crun = runs[by_big[res]]
+                    clc = next_row_layout(crun[-1][2], tuple(crun[-1][3].out_inds))
+                    if plan_rowpass(new, [self.layout[r[1]] for r in crun], clc, size, self.dtype.name, rk) is not None:
+                        return new
             return lc
 
         while i < len(plan):
             if i in firsts:
                 chain, sites = firsts[i]
                 res = chain[-1][2]
-                rp = plan_rowpass(None, [self.layout[w_] for w_ in sites], next_row_layout(res, tuple(chain[-1][3].out_inds)),
-                                  size, self.dtype.name)
+                lc0 = tuple(chain[-1][3].out_inds)
+                rp = plan_rowpass(None, [self.layout[w_] for w_ in sites], next_row_layout(res, lc0), size, self.dtype.name)
+                if rp is None:
+                    rp = plan_rowpass(None, [self.layout[w_] for w_ in sites], lc0, size, self.dtype.name)
                 if rp is not None:
+                    if rp.out_inds != lc0:
+                        relaid.add(res)
                     self.layout[res] = rp.out_inds
                     new_plan.append(("rowpass", None, tuple(sites), res, rp))
                     new_info.append(StepInfo("rowpass", rp.mults, isz * (rp.c_size + ROWPASS_SITES * rp.D**3),
@@ -242,10 +263,19 @@ class TreeExecutor:
             rp = None
             if run is not None:
                 res = run[-1][2]
-                lc = next_row_layout(res, tuple(run[-1][3].out_inds))
-                rp = plan_rowpass(self.layout[run[0][0]], [self.layout[r[1]] for r in run], lc, size, self.dtype.name)
+                lc0 = tuple(run[-1][3].out_inds)
+                rp = plan_rowpass(self.layout[run[0][0]], [self.layout[r[1]] for r in run], next_row_layout(res, lc0), size,
+                                  self.dtype.name, rk)
+                if rp is None:
+                    rp = plan_rowpass(self.layout[run[0][0]], [self.layout[r[1]] for r in run], lc0, size, self.dtype.name, rk)
+                if rp is None and run[0][0] in relaid:
+                    # (cannot happen: next_row_layout re-planned this row against the new order before its producer
+                    # committed it) -- the separate steps were planned against the OLD order of the operand
+                    raise AssertionError("fused row: the consumer of a re-ordered row result no longer plans")
             if rp is not None:
                 res = run[-1][2]
+                if rp.out_inds != lc0:
+                    relaid.add(res)
                 self.layout[res] = rp.out_inds
                 new_plan.append(("rowpass", run[0][0], tuple(r[1] for r in run), res, rp))
                 new_info.append(StepInfo("rowpass", rp.mults, isz * (rp.a_size + rp.c_size + ROWPASS_SITES * rp.D**4),

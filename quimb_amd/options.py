@@ -33,6 +33,7 @@ class Options:
     hold_late: str = "auto"         #: hold later chains behind the first join's: "auto" | "0" | "1"   [QAMD_HOLD_LATE]
     program_join_order: bool = False  #: record launch programs in join order too                     [QAMD_PROGRAM_JOIN_ORDER]
     # ---- kernel pins (developer / test use; 0 / -1 / "auto" = the planner's choice) -----------------------------------
+    row_kernel: str = "auto"        #: fused row: "auto" (= "quad": every row, the last one included) | "quad" (rowq.hip) | "tile" (rowpass.hip: small rows only)  [QAMD_ROW_KERNEL]
     chain2_kernel: str = "auto"     #: fused pair: "auto" | "lds" (chain2.hip) | "reg" (chain2r.hip) | "quad" (chain2q.hip, any size)
     pair_kernel: int = 0            #: qamd_pair_plan.kernel on input: 0 auto, -1 tiled GETT, -2 no MFMA GEMM kernels   [QAMD_KERNEL]
     tile_cfg: int = -1              #: qamd_pair_plan.tile_cfg on input                                 [QAMD_TILE_CFG]
@@ -71,7 +72,7 @@ class Options:
             micro_arena=env.get("QAMD_MICRO_ARENA", "auto"), auto_program=on("QAMD_AUTO_PROGRAM", True),
             auto_program_max_bytes=int(env.get("QAMD_AUTO_PROGRAM_MAX_BYTES", str(4 << 30))),
             auto_program_total_bytes=int(env.get("QAMD_AUTO_PROGRAM_TOTAL_BYTES", str(16 << 30))),
-            debug=bool(env.get("QAMD_DEBUG")),
+            debug=bool(env.get("QAMD_DEBUG")), row_kernel=env.get("QAMD_ROW_KERNEL", "auto"),
         )
         c2 = "auto"
         if env.get("QAMD_CHAIN2R", "")[:1] == "0":

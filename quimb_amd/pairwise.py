@@ -435,9 +435,13 @@ class RowpassSpec:
     mults: int        # scalar multiplications of the five steps
     a_size: int
     c_size: int
+    ed: tuple = (0,) * 5   # extents of the new down legs (0 = D): shorter for the range-sliced cut bonds of a rank's share
+    eh: int = 0            # extent of the row's new open leg (0 = D)
+    kernel: int = 0        # qamd_rowpass_plan.kernel: 0 auto, 1 rowpass.hip (16x16x4 tiles), 2 rowq.hip (4x4x1 multi-block MFMA)
 
 ROWPASS_SITES = 5
-ROWPASS_MAX_OUT = 1 << 24      # elements of the row's result: beyond that a row is bandwidth, not latency (fused pairs)
+ROWPASS_MAX_OUT = 1 << 24      # rowpass.hip (kernel 1) only: beyond that a row is bandwidth, not latency, for ITS item rate
+ROW_KERNELS = {"auto": 0, "tile": 1, "quad": 2, "quad-static": 3}     # 3: rowq.hip without its item queue (what a capturing stream gets)
 
 
 def rowpass_supported(dtype_name, D, nsites):
@@ -445,7 +449,7 @@ def rowpass_supported(dtype_name, D, nsites):
     return dtype_name == "float32" and D == 6 and nsites == ROWPASS_SITES
 
 
-def plan_rowpass(la, site_layouts, lc, size, dtype_name):
+def plan_rowpass(la, site_layouts, lc, size, dtype_name, kernel=0):
     """Try to express FIVE consecutive site absorptions of a boundary sweep as ONE ``qamd_contract_rowpass``
     (csrc/rowpass.hip; quimb absorbs the row site by site, quimb/tensor/tn2d/core.py:1393-1402).  ``la``: layout of the
     boundary tensor the first site meets, ``site_layouts``: the five site tensors' layouts in absorption order, ``lc``:
@@ -460,13 +464,14 @@ def plan_rowpass(la, site_layouts, lc, size, dtype_name):
         return None
     if la is None:
         return _plan_rowfirst(site_layouts, tuple(lc), size, dtype_name)
+    kernel = ROW_KERNELS.get(kernel, kernel)
     la, lc = tuple(la), tuple(lc)
     if len(set(la)) != len(la) or len(set(lc)) != len(lc):
         return None
     sa = dict(zip(la, contig_strides(tuple(size[i] for i in la))))
     sc = dict(zip(lc, contig_strides(tuple(size[i] for i in lc))))
     cur, bond, D = set(la), None, None
-    sv, sd, ws, sh = [], [], [], None
+    sv, sd, ws, sh, ed, eh = [], [], [], None, [], None
     touched = set()
     for c, lw in enumerate(site_layouts):
         lw = tuple(lw)
@@ -480,8 +485,6 @@ def plan_rowpass(la, site_layouts, lc, size, dtype_name):
             return None
         up = ups[0]
         D = size[up] if D is None else D
-        if any(size[ix] != D for ix in lw):
-            return None
         if c < ROWPASS_SITES - 1:
             nb = [ix for ix in new if ix in site_layouts[c + 1]]       # the bond the NEXT site carries
             if len(nb) != 1:
@@ -491,10 +494,18 @@ def plan_rowpass(la, site_layouts, lc, size, dtype_name):
             if nbond in sc or down not in sc:
                 return None
         else:
-            down, nbond = new                                          # (d5, h): two open legs, either naming works
+            down, nbond = new                                          # (d5, h): two open legs, either naming works --
             if down not in sc or nbond not in sc:
                 return None
+            if sc[down] > sc[nbond]:                                   # -- the INNER one of the result is d5: rowq.hip copies
+                down, nbond = nbond, down                              # out whole (d2..d5) runs when they are contiguous
             sh = sc[nbond]
+            eh = size[nbond]
+        # up legs and bonds of one size D; the NEW open legs may be shorter (range-sliced cut bonds: quadrants.py)
+        if size[up] != D or (bond is not None and size[bond] != D) or size[down] > D or size[nbond] > D \
+                or (c < ROWPASS_SITES - 1 and size[nbond] != D):
+            return None
+        ed.append(size[down])
         sv.append(sa[up])
         sd.append(sc[down])
         ws.append((sw[up], sw[bond] if bond is not None else 0, sw[down], sw[nbond]))
@@ -506,13 +517,28 @@ def plan_rowpass(la, site_layouts, lc, size, dtype_name):
     gs = _fuse(spect, size, [sa, sc])
     n_s = prod(size[i] for i in spect)
     c_size = prod(size[i] for i in lc)
-    if len(gs) > 4 or c_size > ROWPASS_MAX_OUT or n_s * D >= 2**31:
+    full = all(e == D for e in ed) and eh == D
+    if kernel == 0:
+        kernel = 2
+    if len(gs) > 4 or n_s * D >= 2**31 or (kernel == 1 and (c_size > ROWPASS_MAX_OUT or not full)):
         return None
-    # multiplications of the five steps as they would have run one by one: D^7 for the first site, D^8 for each other
-    mults = n_s * (D**7 + (ROWPASS_SITES - 1) * D**8)
+    a_size = prod(size[i] for i in la)
+    if kernel in (2, 3) and (a_size >= 2**31 or c_size >= 2**40):
+        return None
+    # multiplications of the five steps as they would have run one by one (all legs D: D^7 for the first site, D^8 for each
+    # other): site c multiplies (columns: d_1..d_{c-1}, v_{c+1}..v_5) x (K: bond, v_c) x (N: d_c, next bond / h)
+    mults, cols = 0, D**4
+    for c in range(ROWPASS_SITES):
+        k = D if c == 0 else D * D
+        n = ed[c] * (eh if c == ROWPASS_SITES - 1 else D)
+        mults += cols * k * n
+        if c < ROWPASS_SITES - 1:
+            cols = cols // D * ed[c]
+    mults *= n_s
     return RowpassSpec(D=D, sv=tuple(sv), sd=tuple(sd), sh=sh, s_groups=tuple((d, st[0], st[1]) for d, st in gs),
                        w_strides=tuple(ws), out_inds=lc, out_shape=tuple(size[i] for i in lc), mults=mults,
-                       a_size=prod(size[i] for i in la), c_size=c_size)
+                       a_size=a_size, c_size=c_size, ed=tuple(0 if e == D else e for e in ed), eh=0 if eh == D else eh,
+                       kernel=kernel)
 
 
 def _plan_rowfirst(site_layouts, lc, size, dtype_name):

@@ -2372,32 +2372,78 @@ def check_rowpass(seed=41):
     rng = np.random.default_rng(seed)
     dev = qa.default_device()
     D = 6
-    for nspect in (1, 2, 3, 1):
+    # (kernel, spectators, sizes of the new legs d1..d5 + h, canonical layouts?)  "quad" = rowq.hip (4x4x1 MFMA, in-place
+    # image, rows of any size, new legs may be shorter: the range-sliced cut bonds of a rank's share), "tile" = rowpass.hip
+    cases = [(k, n, (6,) * 6, False) for k in ("quad", "tile") for n in (1, 2, 3, 1)]
+    cases += [("quad", 2, (6,) * 6, True), ("quad", 1, (3, 6, 6, 6, 6, 6), True), ("quad", 2, (3, 3, 6, 6, 6, 6), True),
+              ("quad", 1, (3, 3, 6, 6, 6, 6), False), ("quad", 2, (2, 6, 3, 6, 5, 4), False), ("quad", 1, (6, 6, 6, 6, 1, 6), False),
+              ("quad", 3, (6, 4, 6, 6, 6, 3), True)]
+    for kern, nspect, ext, canon in cases:
         spect = [f"s{i}" for i in range(nspect)]
         ups = [f"v{i}" for i in range(5)]
         downs = [f"d{i}" for i in range(5)]
         bonds = [f"b{i}" for i in range(4)]
-        sdim = {ix: D for ix in ups + downs + bonds + ["h"]}
+        sdim = {ix: D for ix in ups + bonds}
+        sdim.update(dict(zip(downs + ["h"], ext)))
         sdim.update({ix: int(rng.integers(2, 5)) for ix in spect})
-        la = list(rng.permutation(spect + ups))
+        la = spect + ups if canon else list(rng.permutation(spect + ups))
         sites = []
         for c in range(5):
             legs = [ups[c], downs[c]] + ([bonds[c - 1]] if c else []) + ([bonds[c]] if c < 4 else ["h"])
             sites.append(tuple(rng.permutation(legs)))
-        lc = tuple(rng.permutation(spect + downs + ["h"]))
-        rp = plan_rowpass(tuple(la), sites, lc, sdim, "float32")
-        assert rp is not None and rp.out_inds == lc
+        lc = tuple(["h"] + spect + downs) if canon else tuple(rng.permutation(spect + downs + ["h"]))
+        rp = plan_rowpass(tuple(la), sites, lc, sdim, "float32", kern)
+        assert rp is not None and rp.out_inds == lc and rp.kernel == {"quad": 2, "tile": 1}[kern]
         a = rand(rng, [sdim[i] for i in la], "float32")
         ws = [rand(rng, [sdim[i] for i in t], "float32") for t in sites]
         num = {ix: i for i, ix in enumerate(sdim)}
         sub = lambda t: [num[ix] for ix in t]
         want = np.einsum(a.astype(np.float64), sub(la), *[x for w, t in zip(ws, sites) for x in (w.astype(np.float64), sub(t))],
                          sub(lc), optimize=True)
+        # the multiplication count of the spec is the five steps' own (cotengra's contraction_cost of the chain)
+        cols, mults = D**4, 0
+        for c in range(5):
+            mults += cols * (D if c == 0 else D * D) * ext[c] * (ext[5] if c == 4 else D)
+            cols = cols // D * ext[c]
+        assert rp.mults == mults * math.prod(sdim[i] for i in spect)
         xa, xw = qa.asarray(a), [qa.asarray(w) for w in ws]
         out = qa.Array.empty(rp.out_shape, "float32", dev)
         dev.contract_rowpass(rp, np.dtype("float32"), xa._buf, [w._buf for w in xw], out._buf, None)
         got = out.to_numpy().astype(np.float64)
         assert_close(got, want, "float32")
+    # the tile kernel serves whole-size legs only; up legs and bonds must be of one size for both
+    assert plan_rowpass(tuple(la), sites, lc, sdim, "float32", "tile") is None
+    assert plan_rowpass(tuple(la), sites, lc, dict(sdim, v2=4), "float32") is None
+    sdim = {ix: D for ix in sdim}
+    # rows LARGER than one round of the chip (persistent workgroups walk several work items, drawn from the per-stream item
+    # queue or dealt as static shares): the last row of a corner sweep of the 10x10 network and a rank's range-sliced share
+    # of it, a sample of spectator values against numpy (S is a pure batch index of the row)
+    if getattr(dev, "name", "") == "hip":
+        for kern, ext in (("quad", (6,) * 6), ("quad-static", (6,) * 6), ("quad", (3, 3, 6, 6, 6, 6)), ("quad-static", (3, 6, 6, 6, 6, 6)),
+                          ("quad", (6,) * 6)):
+            spect = ["s0", "s1", "s2", "s3"]
+            sdim = {ix: D for ix in ups + bonds + spect}
+            sdim.update(dict(zip(downs + ["h"], ext)))
+            la = tuple(spect + ups)
+            sites = [tuple(rng.permutation([ups[c], downs[c]] + ([bonds[c - 1]] if c else []) + ([bonds[c]] if c < 4 else ["h"])))
+                     for c in range(5)]
+            lc = tuple(["h"] + spect + downs)
+            rp = plan_rowpass(la, sites, lc, sdim, "float32", kern)
+            assert rp is not None and rp.kernel == {"quad": 2, "quad-static": 3}[kern]
+            a = rand(rng, [sdim[i] for i in la], "float32")
+            ws = [rand(rng, [sdim[i] for i in t], "float32") for t in sites]
+            xa, xw = qa.asarray(a), [qa.asarray(w) for w in ws]
+            out = qa.Array.empty(rp.out_shape, "float32", dev)
+            out._buf.fill_(float("nan"))                         # an item nobody took would stay NaN
+            dev.contract_rowpass(rp, np.dtype("float32"), xa._buf, [w._buf for w in xw], out._buf, None)
+            got = out.to_numpy().astype(np.float64)
+            assert np.isfinite(got).all(), (kern, ext, int((~np.isfinite(got)).sum()))
+            num = {ix: i for i, ix in enumerate(sdim)}
+            sub = lambda t: [num[ix] for ix in t]
+            for s_ in [(0, 0, 0, 0), (5, 5, 5, 5)] + [tuple(int(v) for v in rng.integers(0, D, 4)) for _ in range(12)]:
+                want = np.einsum(a[s_].astype(np.float64), sub(ups), *[x for w, t in zip(ws, sites) for x in (w.astype(np.float64), sub(t))],
+                                 sub(["h"] + downs), optimize=True)
+                assert_close(got[(slice(None),) + s_], want, "float32")
     # the FIRST row of a sweep: no boundary tensor, site tensors without up legs (the entry's nS = -1 form)
     for _ in range(2):
         downs = [f"d{i}" for i in range(5)]

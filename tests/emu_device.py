@@ -112,9 +112,12 @@ class EmuDevice:
         ov = _offsets([(D, s) for s in rp.sv], 1)
         T = a[os_a[:, None] + ov[None, :]].reshape((len(os_a),) + (D,) * 5)            # [S, v1..v5]
         W = []
+        ed = [e or D for e in getattr(rp, "ed", (0,) * 5)]       # the new legs may be shorter than D (range-sliced cut bonds)
+        eh = getattr(rp, "eh", 0) or D
         for i, st in enumerate(rp.w_strides):
-            dims = [(D, st[0]), (D if i else 1, st[1]), (D, st[2]), (D, st[3])]
-            W.append(ws[i][_offsets(dims, 1)].reshape(D, D if i else 1, D, D))       # [up, left, down, right]
+            er = eh if i == 4 else D
+            dims = [(D, st[0]), (D if i else 1, st[1]), (ed[i], st[2]), (er, st[3])]
+            W.append(ws[i][_offsets(dims, 1)].reshape(D, D if i else 1, ed[i], er))       # [up, left, down, right]
         X = np.einsum("sabcde,axyz->sbcdeyz", T, W[0])[..., :, :]                      # site 0 (left extent 1 summed)
         # X[s, v2..v5, d1, b1] -> absorb sites 1..4
         X = np.einsum("sbcdeyz,bzpq->scdeypq", X, W[1])     # -> [s, v3, v4, v5, d1, d2, b2]
@@ -129,7 +132,7 @@ class EmuDevice:
             X = X * np.asarray(1.0 / scl, dtype=X.real.dtype)
             if ep[6] is not None and X.size:
                 ep[6][0] = max(ep[6][0], np.max(np.abs(X)))
-        od = _offsets([(D, s) for s in rp.sd] + [(D, rp.sh)], 1)
+        od = _offsets([(e, s) for e, s in zip(ed, rp.sd)] + [(eh, rp.sh)], 1)
         idx = os_c[:, None] + od[None, :]
         assert len(np.unique(idx)) == idx.size
         c[idx] = X.reshape(len(os_c), -1)
