@@ -104,6 +104,7 @@ SYMBOLS = [
     ("qamd_strip_exponent", C.c_int, [_vp, _i64, _i32, _vp, _vp, _vp]),
     ("qamd_absmax", C.c_int, [_vp, _vp, _i64, _i32, _vp]),
     ("qamd_microtree_run", C.c_int, [_i32, _vp, _i32, _vp, _vp, _vp, _i32, _vp, _i64, _vp, _i64, _i32, _vp]),
+    ("qamd_microtree_run_ex", C.c_int, [_i32, _vp, _i32, _vp, _vp, _vp, _i32, _vp, _i64, _vp, _i64, _i32, _i32, _vp]),
     ("qamd_unary", C.c_int, [_vp, _vp, _i64, _i32, _i32, _vp]),
     ("qamd_minmax", C.c_int, [_vp, _vp, _i64, _i32, _i32, _vp]),
     ("qamd_absmax_log10_sum_add", C.c_int, [_vp, _i64, _i32, _vp, _vp]),

@@ -261,6 +261,21 @@ static bool gemmd_config(const qamd_pair_plan* p, const PairDims& d, int64_t ali
 // ``ch`` = 16 ev rows, but (i) 4 l_in >= ch, so a chunk meets a handful of its pieces at most, (ii) A is contiguous across
 // a suffix of the M groups whose product R is a multiple of ch (chunks then never straddle a run of A), (iii) every piece
 // end falls on a 16-byte vector boundary of C (chunk starts are multiples of gcd(ch, l_in) rows).  Returns R (elements) or 0.
+// break mode of the streaming kernel's Z stores: entries (8 bytes each, in LDS) of the per-workgroup table of group starts --
+// the pieces of the innermost M group a workgroup's rows (4 waves x chunks_per_wave chunks of 16 V rows) can touch, + what
+// the last chunk looks up.  ONE formula for the plan-time LDS check (finalize) and the launch (fill_stream_args): the table
+// grows with M (chunks_per_wave), so a fixed allowance would let a very large M with a short group pass finalize and fail
+// at launch.
+static uint32_t stream_chunks_per_wave(int64_t M, int V) {
+  const uint64_t chunks = (uint64_t)((M + 16 * V - 1) / (16 * V));
+  const uint32_t target_waves = 256 * 4 * 3;
+  const uint64_t cpw = (chunks + target_waves - 1) / target_waves;
+  return (uint32_t)(cpw < 1 ? 1 : cpw);
+}
+static uint32_t stream_zb_groups(int64_t M, int V, int64_t l_in) {
+  return (uint32_t)((uint64_t)stream_chunks_per_wave(M, V) * 4 * 16 * V / (uint64_t)l_in + 3 + 16 * V / l_in + 2);
+}
+
 static int64_t z_break_run(const qamd_pair_plan* p, int ev, int64_t d_in) {
   const int64_t ch = 16 * ev;
   if (p->nm < 2 || p->sa_m[p->nm - 1] != 1) return 0;
@@ -358,8 +373,9 @@ extern "C" int qamd_pair_plan_finalize(qamd_pair_plan* p, int64_t align_a, int64
       bool ok = true;
       for (int i = 0; i + 1 < p->nm; ++i) ok = ok && (p->sc_m[i] % ev == 0);
       for (int i = 0; i < p->nn; ++i) ok = ok && (p->sc_n[i] < d_in || p->sc_n[i] % ev == 0);
-      // (+ the table of group starts in break mode: 2 KiB reserved)
-      ok = ok && (stream_lds_bytes(d.K, d.N, es) + 4 * (d.N + d_in) * 16 * ev * es + (l_in % (16 * ev) ? 2048 : 0) <= 80 * 1024);
+      // (+ the table of group starts in break mode, sized exactly as the launch will size it)
+      const int64_t zb_bytes = l_in % (16 * ev) ? 8ll * stream_zb_groups(d.M, ev, l_in) : 0;
+      ok = ok && (stream_lds_bytes(d.K, d.N, es) + 4 * (d.N + d_in) * 16 * ev * es + zb_bytes <= 80 * 1024);
       if (ok) { kern = 2; vc = ev; }
     }
     if (!kern && base_ok && p->sc_m[p->nm - 1] == 1 && stream_lds_bytes(d.K, d.N, es) <= 64 * 1024) {
@@ -557,13 +573,10 @@ static void fill_stream_args(const qamd_pair_plan* p, const PairDims& d, StreamA
     }
   }
   s.chunks = (uint32_t)((d.M + 16 * V - 1) / (16 * V));
-  const uint32_t target_waves = 256 * 4 * 3;
-  s.chunks_per_wave = (s.chunks + target_waves - 1) / target_waves;
-  if (s.chunks_per_wave < 1) s.chunks_per_wave = 1;
+  s.chunks_per_wave = stream_chunks_per_wave(d.M, V);
   uint32_t waves = (s.chunks + s.chunks_per_wave - 1) / s.chunks_per_wave;
   s.grid = (waves + 3) / 4;
-  if (s.c_break)      // pieces of the innermost group a workgroup's rows (4 waves x chunks_per_wave chunks) can touch, + what the
-    s.zb_groups = (uint32_t)((uint64_t)s.chunks_per_wave * 4 * 16 * V / s.l_in + 3 + 16 * V / s.l_in + 2);   // last chunk looks up
+  if (s.c_break) s.zb_groups = stream_zb_groups(d.M, V, s.l_in);      // (the size finalize counted into its LDS check)
 }
 
 static int launch_stream(const qamd_pair_plan* p, const PairDims& d, const void* A, const void* B, void* C,
@@ -1305,16 +1318,26 @@ extern "C" int qamd_contract_rowpass(const qamd_rowpass_plan* p, const void* A, 
 // ---------------------------------------------------------------------------
 extern "C" int qamd_microtree_launch(int dtype, const qamd_micro_step* steps_dev, int nsteps, const int32_t* etab,
                                      const int32_t* ktab, const void* const* inputs_dev, int ninputs, void* arena_dev,
-                                     int64_t arena_elems, void* out_dev, int64_t out_elems, int ninst, void* stream);
+                                     int64_t arena_elems, void* out_dev, int64_t out_elems, int ninst, int wide,
+                                     void* stream);
+
+extern "C" int qamd_microtree_run_ex(int32_t dtype, const qamd_micro_step* steps_dev, int32_t nsteps, const int32_t* etab_dev,
+                                     const int32_t* ktab_dev, const void* const* inputs_dev, int32_t ninputs, void* arena_dev,
+                                     int64_t arena_elems, void* out_dev, int64_t out_elems, int32_t ninst, int32_t flags,
+                                     void* stream) {
+  if (!steps_dev || !etab_dev || !ktab_dev || !inputs_dev || !out_dev || nsteps <= 0 || ninputs <= 0 || ninst <= 0)
+    return QAMD_EINVAL;
+  if (dtype < 0 || dtype > 3 || (flags & ~QAMD_MICRO_WIDE)) return QAMD_EUNSUPPORTED;
+  const int wide = (flags & QAMD_MICRO_WIDE) && (dtype == QAMD_F32 || dtype == QAMD_C64);
+  if (!arena_dev && arena_elems * (int64_t)kEsize[dtype] * (wide ? 2 : 1) > QAMD_MICRO_LDS_ARENA_BYTES) return QAMD_EINVAL;
+  int rc = qamd_microtree_launch(dtype, steps_dev, nsteps, etab_dev, ktab_dev, inputs_dev, ninputs, arena_dev, arena_elems,
+                                 out_dev, out_elems, ninst, wide, stream);
+  return rc == 0 ? QAMD_OK : (rc == -2 ? QAMD_EUNSUPPORTED : QAMD_ELAUNCH);
+}
 
 extern "C" int qamd_microtree_run(int32_t dtype, const qamd_micro_step* steps_dev, int32_t nsteps, const int32_t* etab_dev,
                                   const int32_t* ktab_dev, const void* const* inputs_dev, int32_t ninputs, void* arena_dev,
                                   int64_t arena_elems, void* out_dev, int64_t out_elems, int32_t ninst, void* stream) {
-  if (!steps_dev || !etab_dev || !ktab_dev || !inputs_dev || !out_dev || nsteps <= 0 || ninputs <= 0 || ninst <= 0)
-    return QAMD_EINVAL;
-  if (dtype < 0 || dtype > 3) return QAMD_EUNSUPPORTED;
-  if (!arena_dev && arena_elems * (int64_t)kEsize[dtype] > QAMD_MICRO_LDS_ARENA_BYTES) return QAMD_EINVAL;
-  int rc = qamd_microtree_launch(dtype, steps_dev, nsteps, etab_dev, ktab_dev, inputs_dev, ninputs, arena_dev, arena_elems,
-                                 out_dev, out_elems, ninst, stream);
-  return rc == 0 ? QAMD_OK : (rc == -2 ? QAMD_EUNSUPPORTED : QAMD_ELAUNCH);
+  return qamd_microtree_run_ex(dtype, steps_dev, nsteps, etab_dev, ktab_dev, inputs_dev, ninputs, arena_dev, arena_elems,
+                               out_dev, out_elems, ninst, 0, stream);
 }

@@ -13,6 +13,7 @@
 // cores to do.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 #include "micro_args.h"
 
 #define QAMD_LAUNCH(...) do { (void)hipGetLastError(); hipLaunchKernelGGL(__VA_ARGS__); } while (0)
@@ -41,20 +42,36 @@ template <typename R> struct MElem<R, true> {
 // Software pipeline over steps: while step i computes, the header of step i+1 (wave-uniform -> scalar
 // loads), its first KREG k-offset pairs (scalar) and this thread's first address triple are already on
 // their way, so the dependent chain per step is  barrier -> operand reads -> FMAs -> result write.
-template <typename R, bool CPLX, bool LDSARENA>
+//
+// WIDE (fp32 / complex64 trees): the INTERMEDIATES are carried in double precision -- inputs are read as they are, every
+// step accumulates in fp64 and stores fp64 into the arena, the root is rounded once on its way out.  A circuit amplitude is
+// ~900 chained steps cancelling down to |a| ~ 2^-26: rounded to fp32 after every step they cost 0.7-2.1e-6 relative
+// (numpy's own complex64 evaluation of the same tree: 1.4e-6), more than north_star's 1e-6; the kernel is latency-bound
+// (~1 us per dependent step), so the wider arithmetic is free.
+template <typename R, bool CPLX, bool LDSARENA, bool WIDE>
 __global__ __launch_bounds__(256) void microtree_kernel(const qamd_micro_step* __restrict__ steps, int nsteps,
                                                         const int32_t* __restrict__ etab,
                                                         const int32_t* __restrict__ ktab,
                                                         const void* const* __restrict__ inputs, int ninputs,
                                                         void* __restrict__ arena, int64_t arena_elems,
                                                         void* __restrict__ out, int64_t out_elems) {
-  typedef typename MElem<R, CPLX>::type E;
+  typedef typename MElem<R, CPLX>::type E;                         // element of the inputs and of the result
+  typedef typename std::conditional<WIDE, double, R>::type RW;
+  typedef typename MElem<RW, CPLX>::type W;                        // element of the intermediates and of the accumulator
   constexpr int KREG = 8;
   extern __shared__ __attribute__((aligned(16))) char mt_lds[];
   const int tid = threadIdx.x;
   const void* const* my_in = inputs + (int64_t)blockIdx.x * ninputs;
-  E* my_arena = LDSARENA ? reinterpret_cast<E*>(mt_lds) : reinterpret_cast<E*>(arena) + (int64_t)blockIdx.x * arena_elems;
+  W* my_arena = LDSARENA ? reinterpret_cast<W*>(mt_lds) : reinterpret_cast<W*>(arena) + (int64_t)blockIdx.x * arena_elems;
   E* my_out = reinterpret_cast<E*>(out) + (int64_t)blockIdx.x * out_elems;
+  auto widen = [](const E& x) -> W {
+    if constexpr (CPLX) return W{(RW)x.re, (RW)x.im};
+    else return (RW)x;
+  };
+  auto narrow = [](const W& x) -> E {
+    if constexpr (CPLX) return E{(R)x.re, (R)x.im};
+    else return (R)x;
+  };
 
   struct Pre {               // everything of a step that can be fetched before its operands exist
     qamd_micro_step h;
@@ -79,24 +96,29 @@ __global__ __launch_bounds__(256) void microtree_kernel(const qamd_micro_step* _
   for (int si = 0; si < nsteps; ++si) {
     if (si + 1 < nsteps) fetch(si + 1, nxt);
     const qamd_micro_step& s = cur.h;
-    const E* A = s.a_kind ? my_arena + s.a_ref : reinterpret_cast<const E*>(my_in[s.a_ref]);
-    const E* B = s.b_kind ? my_arena + s.b_ref : reinterpret_cast<const E*>(my_in[s.b_ref]);
-    E* C = s.c_off >= 0 ? my_arena + s.c_off : my_out;
+    // operands: an input tensor (E) or an intermediate in the arena (W) -- wave-uniform per step
+    const E* Ai = s.a_kind ? nullptr : reinterpret_cast<const E*>(my_in[s.a_ref]);
+    const E* Bi = s.b_kind ? nullptr : reinterpret_cast<const E*>(my_in[s.b_ref]);
+    const W* Aw = my_arena + (s.a_kind ? s.a_ref : 0);
+    const W* Bw = my_arena + (s.b_kind ? s.b_ref : 0);
+    auto lda = [&](int32_t o) -> W { return s.a_kind ? Aw[o] : widen(Ai[o]); };
+    auto ldb = [&](int32_t o) -> W { return s.b_kind ? Bw[o] : widen(Bi[o]); };
     for (uint32_t e = tid; e < s.total; e += 256) {
       int32_t oa = cur.t0, ob = cur.t1, oc = cur.t2;
       if (e != (uint32_t)tid) {
         const int32_t* t = etab + 3 * (int64_t)(s.eoff + e);
         oa = t[0]; ob = t[1]; oc = t[2];
       }
-      E acc = MElem<R, CPLX>::zero();
+      W acc = MElem<RW, CPLX>::zero();
       // (prefetching the VALUES of input-kind operands one step ahead was measured slower: it lengthens the
       //  serial load chain of the prefetch itself, which then bounds the step time)
 #pragma unroll
       for (int k = 0; k < KREG; ++k)
-        if ((uint32_t)k < s.K) MElem<R, CPLX>::fma(acc, A[oa + cur.ka[k]], B[ob + cur.kb[k]]);
+        if ((uint32_t)k < s.K) MElem<RW, CPLX>::fma(acc, lda(oa + cur.ka[k]), ldb(ob + cur.kb[k]));
       for (uint32_t k = KREG; k < s.K; ++k)
-        MElem<R, CPLX>::fma(acc, A[oa + ktab[2 * (s.koff + k)]], B[ob + ktab[2 * (s.koff + k) + 1]]);
-      C[oc] = acc;
+        MElem<RW, CPLX>::fma(acc, lda(oa + ktab[2 * (s.koff + k)]), ldb(ob + ktab[2 * (s.koff + k) + 1]));
+      if (s.c_off >= 0) my_arena[s.c_off + oc] = acc;
+      else my_out[oc] = narrow(acc);
     }
     if (!LDSARENA) __threadfence_block();
     __syncthreads();
@@ -108,37 +130,42 @@ __global__ __launch_bounds__(256) void microtree_kernel(const qamd_micro_step* _
 
 using namespace qamd;
 
-template <typename R, bool CP>
+template <typename R, bool CP, bool WIDE>
 static int launch_microtree(bool lds, size_t lds_bytes, const qamd_micro_step* steps_dev, int nsteps,
                             const int32_t* etab, const int32_t* ktab, const void* const* inputs_dev, int ninputs, void* arena_dev, int64_t arena_elems,
                             void* out_dev, int64_t out_elems, int ninst, hipStream_t st) {
   if (lds) {
-    (void)hipFuncSetAttribute((const void*)microtree_kernel<R, CP, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    (void)hipFuncSetAttribute((const void*)microtree_kernel<R, CP, true, WIDE>, hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)lds_bytes);
-    QAMD_LAUNCH((microtree_kernel<R, CP, true>), dim3(ninst), dim3(256), lds_bytes, st, steps_dev, nsteps, etab, ktab,
+    QAMD_LAUNCH((microtree_kernel<R, CP, true, WIDE>), dim3(ninst), dim3(256), lds_bytes, st, steps_dev, nsteps, etab, ktab,
                 inputs_dev, ninputs, arena_dev, arena_elems, out_dev, out_elems);
   } else {
-    QAMD_LAUNCH((microtree_kernel<R, CP, false>), dim3(ninst), dim3(256), 0, st, steps_dev, nsteps, etab, ktab,
+    QAMD_LAUNCH((microtree_kernel<R, CP, false, WIDE>), dim3(ninst), dim3(256), 0, st, steps_dev, nsteps, etab, ktab,
                 inputs_dev, ninputs, arena_dev, arena_elems, out_dev, out_elems);
   }
   return hipGetLastError() == hipSuccess ? 0 : -4;
 }
 
-// arena_dev == NULL: the arena (arena_elems elements per instance) is carved out of LDS
+// arena_dev == NULL: the arena (arena_elems elements per instance) is carved out of LDS.  wide (F32 / C64 only): the
+// arena's elements are the double-precision counterparts (8 / 16 bytes).
 extern "C" int qamd_microtree_launch(int dtype, const qamd_micro_step* steps_dev, int nsteps, const int32_t* etab,
                                      const int32_t* ktab, const void* const* inputs_dev, int ninputs, void* arena_dev,
-                                     int64_t arena_elems, void* out_dev, int64_t out_elems, int ninst, void* stream) {
+                                     int64_t arena_elems, void* out_dev, int64_t out_elems, int ninst, int wide,
+                                     void* stream) {
   hipStream_t st = (hipStream_t)stream;
   if (nsteps <= 0 || ninst <= 0) return -1;
   static const size_t esz[4] = {4, 8, 8, 16};
   if (dtype < 0 || dtype > 3) return -2;
+  if (dtype == 1 || dtype == 3) wide = 0;       // already double precision
   const bool lds = arena_dev == nullptr && arena_elems > 0;
-  const size_t lds_bytes = lds ? (size_t)arena_elems * esz[dtype] : 0;
+  const size_t lds_bytes = lds ? (size_t)arena_elems * esz[dtype] * (wide ? 2 : 1) : 0;
   if (lds_bytes > QAMD_MICRO_LDS_ARENA_BYTES) return -2;
+#define QAMD_MT_ARGS lds, lds_bytes, steps_dev, nsteps, etab, ktab, inputs_dev, ninputs, arena_dev, arena_elems, out_dev, out_elems, ninst, st
   switch (dtype) {
-    case 0: return launch_microtree<float, false>(lds, lds_bytes, steps_dev, nsteps, etab, ktab, inputs_dev, ninputs, arena_dev, arena_elems, out_dev, out_elems, ninst, st);
-    case 1: return launch_microtree<double, false>(lds, lds_bytes, steps_dev, nsteps, etab, ktab, inputs_dev, ninputs, arena_dev, arena_elems, out_dev, out_elems, ninst, st);
-    case 2: return launch_microtree<float, true>(lds, lds_bytes, steps_dev, nsteps, etab, ktab, inputs_dev, ninputs, arena_dev, arena_elems, out_dev, out_elems, ninst, st);
-    default: return launch_microtree<double, true>(lds, lds_bytes, steps_dev, nsteps, etab, ktab, inputs_dev, ninputs, arena_dev, arena_elems, out_dev, out_elems, ninst, st);
+    case 0: return wide ? launch_microtree<float, false, true>(QAMD_MT_ARGS) : launch_microtree<float, false, false>(QAMD_MT_ARGS);
+    case 1: return launch_microtree<double, false, false>(QAMD_MT_ARGS);
+    case 2: return wide ? launch_microtree<float, true, true>(QAMD_MT_ARGS) : launch_microtree<float, true, false>(QAMD_MT_ARGS);
+    default: return launch_microtree<double, true, false>(QAMD_MT_ARGS);
   }
+#undef QAMD_MT_ARGS
 }

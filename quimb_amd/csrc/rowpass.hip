@@ -280,11 +280,9 @@ extern "C" int qamd_rowpass_launch(const RowArgs* a, const void* A, const void* 
   }
   if (a->items == 0) return -2;
   const size_t lds = (size_t)(2 * DD * RP + 2 * DD * LDW + 64) * sizeof(float);
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute((const void*)rowpass_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_done = true;
-  }
+  // (per launch, as stream.hip / gemmd.hip do: the attribute belongs to the CURRENT device, and a process-wide flag would
+  // leave a second GPU of the process without it -- and be a data race between threads)
+  (void)hipFuncSetAttribute((const void*)rowpass_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   QAMD_LAUNCH(rowpass_kernel, dim3(a->items), dim3(256), lds, (hipStream_t)stream, *a, w, (const float*)A, (float*)C,
               (const float*)scale_a, (float*)absmax_out);
   return hipGetLastError() == hipSuccess ? 0 : -4;

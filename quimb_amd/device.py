@@ -10,6 +10,7 @@ default device without the HIP library or without a GPU raises.
 import ctypes as C
 import os
 
+import contextlib
 import threading
 
 import numpy as np
@@ -112,14 +113,35 @@ class HipDevice:
         self.profile = None
         #: launches below this many multiplications are not bracketed by events when ``profile`` is a list
         self.profile_min_mults = 0
-        opts = get_options()      # developer pins, captured once per device object (quimb_amd/options.py)
-        self.force_tile_cfg = int(opts.tile_cfg)
-        self.force_split_k = int(opts.split_k)
+        # Kernel pins (quimb_amd/options.py: pair_kernel / tile_cfg / split_k / micro_arena).  Who decides, in this order:
+        # (1) the executor / expression that is running on this thread -- it installs the options it CAPTURED WHEN BUILT for
+        # the duration of its run (``pinned``); (2) these attributes when a script set them (None = not set); (3) the
+        # thread's current options at the time of the call (a bare ``qa.tensordot`` under ``with qa.options(...)``).
+        self.force_tile_cfg = None
+        self.force_split_k = None
         #: 0 = auto (streaming kernel where eligible), -1 = always the tiled GETT kernel
-        self.force_kernel = int(opts.pair_kernel)
+        self.force_kernel = None
         #: fused-pair kernel pin: "auto" | "lds" | "reg" | "quad" (QAMD_CHAIN2_FORCE_* flag bits of the plan)
-        self.force_chain2 = opts.chain2_kernel
-        self.micro_arena = opts.micro_arena
+        self.force_chain2 = get_options().chain2_kernel
+        self.micro_arena = None
+
+    def _pins(self):
+        """(pair_kernel, tile_cfg, split_k, micro_arena) in force for THIS call (see ``__init__``)."""
+        o = getattr(self._rec_tls, "pins", None) or get_options()
+        pick = lambda dev_value, opt_value: opt_value if dev_value is None else dev_value
+        return (int(pick(self.force_kernel, o.pair_kernel)), int(pick(self.force_tile_cfg, o.tile_cfg)),
+                int(pick(self.force_split_k, o.split_k)), pick(self.micro_arena, o.micro_arena))
+
+    @contextlib.contextmanager
+    def pinned(self, options):
+        """The kernel pins of ``options`` (what an executor captured when it was built) for the calls this thread makes
+        inside the block."""
+        old = getattr(self._rec_tls, "pins", None)
+        self._rec_tls.pins = options
+        try:
+            yield
+        finally:
+            self._rec_tls.pins = old
 
     # ---- memory ---------------------------------------------------------
     def empty(self, n, dtype):
@@ -206,14 +228,15 @@ class HipDevice:
     # ---- pairwise contraction ---------------------------------------------
     def compile_pair(self, spec, dtype, align_a=16, align_b=16, align_c=16):
         code = dtype_code(dtype)
-        key = (spec, code, align_a, align_b, self.force_tile_cfg, self.force_split_k, align_c, self.force_kernel)
+        kernel, tile_cfg, split_k, _ = self._pins()
+        key = (spec, code, align_a, align_b, tile_cfg, split_k, align_c, kernel)
         cp = self._pairs.get(key)
         if cp is not None:
             return cp
         p = fill_plan_struct(spec, code)
-        p.tile_cfg = self.force_tile_cfg
-        p.split_k = self.force_split_k
-        p.kernel = self.force_kernel
+        p.tile_cfg = tile_cfg
+        p.split_k = split_k
+        p.kernel = kernel
         _lib.check(
             self.lib.qamd_pair_plan_finalize(C.byref(p), align_a, align_b, align_c), "qamd_pair_plan_finalize"
         )
@@ -632,17 +655,20 @@ class HipDevice:
         steps_dev, etab_dev, ktab_dev = plan
         ninst = int(table.shape[0])
         ptrs = torch.from_numpy(np.ascontiguousarray(table, dtype=np.int64)).to(self.tdev, non_blocking=False)
-        mode = getattr(self, "micro_arena", "auto")      # auto | lds | global
+        mode = self._pins()[3]                            # auto | lds | global
         use_lds = mt.lds_ok and (mode == "lds" or (mode == "auto" and ninst <= 2 * 256))
-        arena = None if use_lds else self.empty(max(mt.arena_elems * ninst, 1), mt.dtype)
+        wide = bool(getattr(mt, "wide", False))
+        wdt = {np.dtype("float32"): np.dtype("float64"), np.dtype("complex64"): np.dtype("complex128")}.get(np.dtype(mt.dtype), mt.dtype) \
+            if wide else mt.dtype
+        arena = None if use_lds else self.empty(max(mt.arena_elems * ninst, 1), wdt)
         _lib.check(
-            self.lib.qamd_microtree_run(
+            self.lib.qamd_microtree_run_ex(
                 dtype_code(mt.dtype), steps_dev.data_ptr(), len(mt.steps), etab_dev.data_ptr(), ktab_dev.data_ptr(),
                 ptrs.data_ptr(), mt.ninputs,
                 None if use_lds else arena.data_ptr(), int(mt.arena_elems), out.data_ptr(), int(mt.out_elems), ninst,
-                self.stream(),
+                1 if wide else 0, self.stream(),
             ),
-            "qamd_microtree_run",
+            "qamd_microtree_run_ex",
         )
         # the pointer table, the arena and every input must outlive the asynchronous launch
         self._micro_keep = (ptrs, arena, keep)

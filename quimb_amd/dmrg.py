@@ -257,7 +257,10 @@ class DMRG2:
             nrm2 = float(np.real(ops.tensordot(th.conj(), th, axes=([0], [0])).item()))
             return loc_en, float(np.real(ops.tensordot(th.conj(), hv, axes=([0], [0])).item())) / nrm2
         if self.split == "rand" and max_bond and 0 < max_bond + self.split_opts.get("oversample", 10) < min(m.shape):
-            so = dict(oversample=10, num_iterations=0, method_lorthog="qr:cholesky", method_reduced="svd:eig")
+            # (the Gram route squares the condition number: double precision only, as in ``_canonize_to``; a single-precision
+            # sketch takes Householder QR -- and ``linalg._orth`` checks whichever Cholesky basis it is given)
+            dbl = self.dtype in (np.dtype("float64"), np.dtype("complex128"))
+            so = dict(oversample=10, num_iterations=0, method_lorthog="qr:cholesky" if dbl else "qr", method_reduced="svd:eig")
             so.update(self.split_opts)
             if so["oversample"] == 0:
                 # the reference's ``svd:rand`` with a sketch no wider than the bond (decomp.py:1808-1815, :1836-1843): the

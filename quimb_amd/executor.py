@@ -18,6 +18,8 @@ This is the MI355X replacement for the per-step python loop inside
 
 import os
 
+import contextlib
+
 import numpy as np
 
 from .array import Array, asarray, _coerce_dtype
@@ -484,10 +486,15 @@ class TreeExecutor:
         # CU's LDS and matrix pipe) and ends shortly after it, so this pays only when the join is long: the 7 ms joins of the
         # whole 10x10 D=6 network (4.96 rounds of tiles) gain 0.2 ms per step (two corner sweeps in 1.03 ms instead of four
         # in 1.85 ms, the join 0.25 ms slower), the 3.5 / 1.8 / 0.95 ms joins of a rank of 2 / 4 / 8 LOSE 0.2-0.35 ms
-        # (measured, round 4).  options.hold_late = "0" / "1" forces it off / on.
+        # (measured, round 4).  Round 6: with every row of a corner one MFMA-bound launch (rowq.hip: a corner is 5 launches
+        # and ~0.35 ms instead of 0.8) a held chain no longer gets onto a CU before the join's tail -- its first launch waits
+        # out the whole join -- and all four corners up front cost less than the hold ever hid: 15.8 ms held, 14.7 ms not
+        # (profiles/r06_hold_late.txt).  "auto" therefore holds only plans WITHOUT fused rows; "0" / "1" force it off / on.
         self.hold_late = None
         hold = self.options.hold_late
-        if len(anchors) > 1 and hold != "0" and (hold == "1" or self.info[anchors[0]].mults >= HOLD_LATE_MIN_MULTS):
+        fused_rows = any(e[0] == "rowpass" for e in self.plan)
+        if len(anchors) > 1 and hold != "0" and (hold == "1" or (self.info[anchors[0]].mults >= HOLD_LATE_MIN_MULTS
+                                                                  and not fused_rows)):
             first = anchors[0]
             early = sorted({self.lanes[i] for i in range(n) if need[i] == first and i != first})
             late = sorted({self.lanes[i] for i in range(n) if need[i] is not None and need[i] != first} - set(early) - {0})
@@ -568,8 +575,12 @@ class TreeExecutor:
         dev = inputs[0]._dev
         # (a launch-program recording never touches torch's streams)
         home = dev.torch.cuda.current_stream(dev.tdev) if hasattr(dev, "torch") and getattr(dev, "record", None) is None else None
+        # the kernel pins this executor CAPTURED WHEN BUILT (options.pair_kernel / tile_cfg / split_k), not whatever the
+        # thread's options are at call time (quimb_amd/options.py; the plan interpreter of the CPU tests has no pins)
+        pinned = dev.pinned(self.options) if hasattr(dev, "pinned") else contextlib.nullcontext()
         try:
-            return self._run_core_impl(inputs, exponent, cache, only_independent, lanes)
+            with pinned:
+                return self._run_core_impl(inputs, exponent, cache, only_independent, lanes)
         finally:
             if home is not None:
                 dev.torch.cuda.set_stream(home)      # lanes switch the current stream: always hand the caller's back

@@ -285,9 +285,35 @@ def _randn(dev, shape, dtype, seed):
     return Array(dev, t.reshape(-1), tuple(shape), dtype)
 
 
+#: how far from the identity ``Q^H Q`` may be (max-norm, in units of the dtype's eps) for a Cholesky-QR basis to be
+#: accepted as orthonormal by ``orth_cholesky_checked``
+ORTH_DEFECT_EPS = 1000.0
+
+
+def orth_cholesky_checked(y):
+    """An orthonormal basis of the columns of ``y`` by CholeskyQR2, CHECKED: the Gram route squares the condition number, so
+    on an ill-conditioned sketch (fp32 with a spectral decay of 1e-3 already, fp64 beyond 1e-8) even the refined ``Q`` is
+    far from an isometry -- and everything downstream (canonical forms, <H> / sum s^2) assumes one.  The defect of the
+    FINAL factor is measured (one more small GETT launch); beyond ``ORTH_DEFECT_EPS`` eps, or when a Cholesky
+    factorisation fails outright, the basis comes from Householder QR instead (``linalg.qr``: rocSOLVER geqrf / orgqr).
+    Returns ``(Q, used_fallback)``."""
+    from . import ops
+
+    y = y if isinstance(y, Array) else Array.from_numpy(np.asarray(y))
+    eps = float(np.finfo(np.dtype(y.dtype)).eps)
+    try:
+        Q = qr_via_cholesky(y, shift=True, refine="auto")[0]
+        defect = _gram_defect(ops.tensordot(Q.conj(), Q, axes=([0], [0])))
+        if np.isfinite(defect) and defect <= ORTH_DEFECT_EPS * eps:
+            return Q, False
+    except (np.linalg.LinAlgError, RuntimeError, FloatingPointError):
+        pass          # potrf refused the (shifted) Gram matrix: not positive definite to working precision
+    return qr(y)[0], True
+
+
 def _orth(y, method):
     if method in ("qr:cholesky", "cholesky"):
-        return qr_via_cholesky(y, shift=True, refine="auto")[0]
+        return orth_cholesky_checked(y)[0]
     if method == "qr":
         return qr(y)[0]
     if method in ("svd:eig", "eig", "svd"):

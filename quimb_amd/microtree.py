@@ -125,7 +125,12 @@ class MicroTree:
         #: the arena fits the LDS budget of one workgroup (QAMD_MICRO_LDS_ARENA_BYTES): dependent steps hand over
         #: through LDS instead of L2 -- the latency mode; large batches may prefer the global arena (more
         #: workgroups resident per CU)
-        self.lds_ok = 0 < arena * self.dtype.itemsize <= 112 * 1024
+        #: fp32 / complex64 trees carry their INTERMEDIATES in double precision (``qamd_microtree_run_ex`` with
+        #: QAMD_MICRO_WIDE; ``Options.micro_wide``, captured here): the arena's elements are then twice as large
+        self.wide = bool(get_options().micro_wide) and self.dtype.itemsize in (4, 8) and self.dtype in (
+            np.dtype("float32"), np.dtype("complex64"))
+        self.arena_itemsize = self.dtype.itemsize * (2 if self.wide else 1)
+        self.lds_ok = 0 < arena * self.arena_itemsize <= 112 * 1024
         self.flops = sum((8 if self.dtype.kind == "c" else 2) * s["spec"].mults for s in steps)
         self._packed = None
 

@@ -46,6 +46,7 @@ class Options:
     # ---- expressions --------------------------------------------------------------------------------------------------
     fold_constants: bool = True     #: contract constant-only sub-trees once                            [QAMD_FOLD_CONSTANTS]
     microtree: bool = True          #: trees of many small tensors walked by the device in one launch   [QAMD_MICROTREE]
+    micro_wide: bool = True         #: fp32 / complex64 micro-trees carry their intermediates in fp64            [QAMD_MICRO_WIDE]
     micro_arena: str = "auto"       #: "auto" | "lds" | "global"                                        [QAMD_MICRO_ARENA]
     auto_program: bool = True       #: record a launch program on the 3rd call of an expression         [QAMD_AUTO_PROGRAM]
     auto_program_max_bytes: int = 4 << 30      #: [QAMD_AUTO_PROGRAM_MAX_BYTES]
@@ -69,7 +70,7 @@ class Options:
             lanes=on("QAMD_LANES", True), slice_graph=on("QAMD_SLICE_GRAPH", True), lane_trace=bool(env.get("QAMD_LANE_TRACE")),
             program_own_lane0=on("QAMD_PROGRAM_OWN_LANE0", False),
             fold_constants=on("QAMD_FOLD_CONSTANTS", True), microtree=on("QAMD_MICROTREE", True),
-            micro_arena=env.get("QAMD_MICRO_ARENA", "auto"), auto_program=on("QAMD_AUTO_PROGRAM", True),
+            micro_wide=on("QAMD_MICRO_WIDE", True), micro_arena=env.get("QAMD_MICRO_ARENA", "auto"), auto_program=on("QAMD_AUTO_PROGRAM", True),
             auto_program_max_bytes=int(env.get("QAMD_AUTO_PROGRAM_MAX_BYTES", str(4 << 30))),
             auto_program_total_bytes=int(env.get("QAMD_AUTO_PROGRAM_TOTAL_BYTES", str(16 << 30))),
             debug=bool(env.get("QAMD_DEBUG")), row_kernel=env.get("QAMD_ROW_KERNEL", "auto"),

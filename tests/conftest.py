@@ -103,3 +103,8 @@ def pytest_terminal_summary(terminalreporter):
         terminalreporter.write_line("achieved parity (worst relative error seen, bar in tests/checks.py:RTOL):")
         for k, (err, where) in sorted(checks.WORST.items()):
             terminalreporter.write_line(f"  {k:>12}: {err:.3e}  ({where})")
+    if getattr(checks, "WORST_ELEM", None):
+        terminalreporter.write_line(f"element-wise (worst |got - want| / (|want| + {checks.ELEM_FLOOR} max|want|) seen, bar "
+                                    f"{checks.ELEM_FACTOR:g} x RTOL):")
+        for k, (err, where) in sorted(checks.WORST_ELEM.items()):
+            terminalreporter.write_line(f"  {k:>12}: {err:.3e}  ({where})")

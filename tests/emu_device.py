@@ -293,7 +293,8 @@ class EmuDevice:
         """Semantics of qamd_microtree_run: walk the plan step by step for every instance."""
         for ii in range(table.shape[0]):
             xs = [self._handles[int(h)] for h in table[ii]]
-            arena = np.zeros(max(mt.arena_elems, 1), dtype=mt.dtype)
+            wdt = np.result_type(mt.dtype, np.float64) if getattr(mt, "wide", False) else mt.dtype    # QAMD_MICRO_WIDE
+            arena = np.zeros(max(mt.arena_elems, 1), dtype=wdt)
             for s in mt.steps:
                 sp = s["spec"]
                 A = arena[s["a"][1]:] if s["a"][0] else xs[s["a"][1]]
@@ -304,7 +305,7 @@ class EmuDevice:
                 ok_a, ok_b = _offsets(sp.k, 1), _offsets(sp.k, 2)
                 a4 = A[ob_a[:, None, None] + om_a[None, :, None] + ok_a[None, None, :]]      # [b, m, k]
                 b4 = B[ob_b[:, None, None] + ok_b[None, :, None] + on_b[None, None, :]]      # [b, k, n]
-                c = np.einsum("bmk,bkn->bmn", a4, b4)
+                c = np.einsum("bmk,bkn->bmn", a4.astype(wdt), b4.astype(wdt))
                 oc = ob_c[:, None, None] + om_c[None, :, None] + on_c[None, None, :]
                 if s["c_off"] < 0:
                     out[ii * mt.out_elems + oc] = c

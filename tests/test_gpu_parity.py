@@ -642,3 +642,9 @@ def test_two_sided_full_size(hip):
     for k in (0,):
         m, e = TwoSidedContraction(inputs, size, 10, 10, "float32", sliced_cols=k)(arrays, strip_exponent=True)
         assert m == ref["sign"] and abs(e - ref["log10_abs"]) < np.log10(1.0 + 1e-6), (k, m, e)
+
+
+@pytest.mark.gpu
+def test_orth_cholesky_checked(hip):
+    """a Cholesky-QR basis is checked and falls back to Householder QR when it is not orthonormal."""
+    checks.check_orth_cholesky_checked()

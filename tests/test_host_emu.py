@@ -472,3 +472,8 @@ def test_rowpass_on_the_plan_interpreter(emu):
     for first, second in pairs:
         assert second[4].sv == (1296, 216, 36, 6, 1) and first[4].sd[:4] == (1296, 216, 36, 6)
 
+
+
+def test_orth_cholesky_checked(emu):
+    """a Cholesky-QR basis is checked and falls back to Householder QR when it is not orthonormal."""
+    checks.check_orth_cholesky_checked()

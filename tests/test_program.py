@@ -82,15 +82,19 @@ def test_recording_the_quadrant_tree(recdev, dtype, strip):
 
 
 def test_later_chains_are_held_behind_the_first_joins_chains(recdev, monkeypatch):
-    """A long first join (the 7 ms joins of the whole 10x10 D=6 network) has the later join's corner sweeps run BESIDE it:
-    they wait for the first join's own chains, not for the join.  A rank's shorter joins do not (measured: they lose).
-    The rule, its override, and the waits a recorded program carries for it."""
+    """A long first join (the 7 ms joins of the whole 10x10 D=6 network) MAY have the later join's corner sweeps run BESIDE
+    it: they wait for the first join's own chains, not for the join.  Round 6: that pays only for plans WITHOUT fused rows
+    (with rowq.hip a corner is five MFMA-bound launches that no longer fit beside a join: 15.8 ms held, 14.7 ms not,
+    profiles/r06_hold_late.txt), and never for a rank's shorter joins (measured: they lose).  The rule, its overrides, and
+    the waits a recorded program carries for it."""
     import quimb_amd.executor as qe
     from bench import build_network
     from quimb_amd.quadrants import QuadrantRank, QuadrantSharding
 
     arrays, inputs, size = build_network(10, 10, 6, 7, "float32")
-    ex = qa.TreeExecutor(qa.ContractionTree(inputs, (), size, path=qa.quadrant_path_2d(10, 10)), "float32")
+    tree10 = qa.ContractionTree(inputs, (), size, path=qa.quadrant_path_2d(10, 10))
+    assert qa.TreeExecutor(tree10, "float32").hold_late is None          # every row of every corner is one launch: no hold
+    ex = qa.TreeExecutor(tree10, "float32", options=qa.get_options().replace(fuse_rows=False))
     pos, late, early = ex.hold_late
     assert ex.plan[pos][0] == "pair" and ex.info[pos].mults == 7776**3 and ex.lanes[pos] == 0
     assert len(late) == 2 and len(early) == 2 and not set(late) & set(early) and 0 in early
@@ -251,7 +255,7 @@ def test_program_full_size_quadrant_tree(hip):
         assert np.sign(m) == ref["sign"] and abs(np.log10(abs(m)) + e - ref["log10_abs"]) < np.log10(1.0 + 1e-6)
     names = [n for (_, _, n, _, _, _) in prog.timings(1)]
     assert sum(n.startswith("gemmk_kernel") for n in names) == 2, names
-    assert 30 <= prog.num_launches <= 130      # (94 with every step a launch of its own; 34 with rows 1-4 of every corner fused)
+    assert 20 <= prog.num_launches <= 130      # (94 with every step a launch of its own; 34 with rows 1-4 of every corner fused; 26 with every row one launch)
 
 
 @pytest.mark.gpu
