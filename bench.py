@@ -23,6 +23,7 @@ events on the launch stream) and ``cpu_baseline`` (numpy/OpenBLAS port of the sw
 
 import argparse
 import json
+import math
 import os
 import sys
 import time
@@ -94,13 +95,17 @@ def _result_with_parity(res, args):
     return out
 
 
-def cpu_baseline(D, Ly, seed, rows=3, repeats=5):
+def cpu_baseline(D, Ly, seed, rows=3, repeats=5, Lx=10, full=True, full_budget_s=240.0):
     """quimb's numpy path restated (oracle/np_oracle.py: per step tensordot through OpenBLAS, strip_exponent) on a
     BOUNDED sample of the same workload: the top ``rows`` rows of the same 10-wide network, same site-by-site
     sweep (rows = 3: one full-size interior row between a first and a last row; the whole network takes ~9 minutes on
     the host: ``full_network_seconds`` quotes the recorded fp64 run of tests/golden/make_full_size_oracle.py).  The BLAS thread count is swept on the 2-row sample first (threadpoolctl; the default of one thread
     per core oversubscribes the skinny 6^9 x 36 x 36 products), then the sample is timed ``repeats`` times after
-    one warm-up at the best count and the MEDIAN is reported, with the thread count next to the core count."""
+    one warm-up at the best count and the MEDIAN is reported, with the thread count next to the core count.
+    ``full`` (round 6): the WHOLE ``Lx`` x ``Ly`` network once through the same oracle, fp32, same sweep tree, at the swept
+    thread count, on THIS host -- ``value`` is then the whole workload's rate and ``full_network_seconds`` is measured beside
+    the GPU number, the sample stays as ``sample_value``; skipped (and said so) when the sample predicts more than
+    ``full_budget_s`` seconds, so that the default run still ends within minutes."""
     from oracle import np_oracle as orc
     import quimb_amd as qa
 
@@ -135,7 +140,7 @@ def cpu_baseline(D, Ly, seed, rows=3, repeats=5):
     run(big, best_th)                                           # warm-up (page faults, BLAS thread pool)
     times = sorted(run(big, best_th) for _ in range(repeats))
     med = times[len(times) // 2]
-    return {
+    out = {
         "value": big[3] / med / 1e12,
         "unit": "TFLOP/s",
         "cores": cores,
@@ -144,9 +149,29 @@ def cpu_baseline(D, Ly, seed, rows=3, repeats=5):
         "sample": f"{rows}x{Ly} D={D} fp32 top-rows sweep of the same network ({big[3]:.3e} of the headline's FLOP), numpy "
                   f"tensordot / OpenBLAS, median of {repeats} after one warm-up: {med:.2f} s (all: "
                   f"{', '.join(f'{t:.2f}' for t in times)})",
+        "sample_value": big[3] / med / 1e12,
         "thread_sweep_2row_seconds": {str(k): round(v, 2) for k, v in sweep.items()},
         **_full_network_record(seed),
     }
+    if full:
+        whole = sample(Lx)
+        predicted = whole[3] / (big[3] / med)
+        if predicted <= full_budget_s:
+            t_full = run(whole, best_th)             # ONE run: the workload itself, not a sample of it
+            out.update({
+                "value": whole[3] / t_full / 1e12,
+                "full_network_seconds": t_full,
+                "full_network_flop": whole[3],
+                "full_network_note": f"whole {Lx}x{Ly} D={D} network, fp32 numpy oracle (oracle/np_oracle.py), site-by-site sweep "
+                                     f"tree, ONE run on this host at {best_th} of {cores} threads; `value` is this run's rate, "
+                                     f"`sample_value` the {rows}-row sample's",
+            })
+            rec = _full_network_record(seed)
+            if rec:
+                out["full_network_seconds_build_container_fp64"] = rec["full_network_seconds"]
+        else:
+            out["full_network_skipped"] = f"the sample predicts {predicted:.0f} s > {full_budget_s:.0f} s budget: `value` is the sample's rate"
+    return out
 
 
 def _full_network_record(seed):
@@ -300,6 +325,7 @@ def main():
     ap.add_argument("--two-sided", action="store_true", help="round 2's branch decomposition (top / bottom half sweeps on two rank groups)")
     ap.add_argument("--seed", type=int, default=7)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-cpu-full", action="store_true", help="cpu_baseline: the bounded 3-row sample only, not the whole network once (~70 s of host time)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the configs #2 / #5 numbers and the scaling projection (N = 1)")
     ap.add_argument("--tree", choices=["auto", "sweep", "quadrant"], default="auto",
                     help="N = 1 contraction tree: the site-by-site boundary sweep (min-FLOP, HBM-bound), the four-quadrant "
@@ -643,7 +669,13 @@ def main():
             try:
                 import secondary as _sec
 
-                secondary = _sec.measure(qa, sync)
+                # (the headline network itself goes along: BASELINE's literal config #3 -- the COMPRESSED boundary-MPS sweep at a
+                # stated chi -- is timed on it, its truncation error quoted against the exact value this run just computed)
+                par_ = _result_with_parity(res, args)
+                secondary = _sec.measure(qa, sync, headline={
+                    "arrays": xs, "Lx": args.Lx, "Ly": args.Ly, "D": args.D,
+                    "exact_log10_abs_this_run": (math.log10(abs(res[0])) + res[1]) if res and res[0] else None,
+                    "fp64_oracle_log10_abs": par_.get("fp64_oracle_log10_abs")})
             except Exception as err:
                 secondary = {"error": f"{type(err).__name__}: {err}"}
             projection = {"note": "ONE GPU timing the busiest rank's share of an N-rank job (same code path as --gpus N minus "
@@ -673,7 +705,7 @@ def main():
                     del qr_, loc_
                 except Exception as err:
                     projection[str(w_)] = {"error": f"{type(err).__name__}: {err}"}
-        cpu = None if (args.no_cpu or world > 1 or emulate) else cpu_baseline(args.D, args.Ly, args.seed)   # N=1 only
+        cpu = None if (args.no_cpu or world > 1 or emulate) else cpu_baseline(args.D, args.Ly, args.seed, Lx=args.Lx, full=not args.no_cpu_full)   # N=1 only
         nsl = plan.nslices if mode == "two_sided" else tree.nslices
         if mode == "single":
             workload, par = "unsliced, 1 GPU", "single"

@@ -346,7 +346,7 @@ int qamd_microtree_run(int32_t dtype, const qamd_micro_step* steps_dev, int32_t 
  * precision -- every step accumulates in fp64, the arena's elements are 8 / 16 bytes (arena_dev, when given, must hold
  * ninst x arena_elems of THOSE; the LDS budget is checked against them), the inputs and the result keep the tree's dtype.
  * ~900 chained fp32 steps of a circuit amplitude (BASELINE config #2) lose 1-2e-6 to per-step rounding; this mode holds
- * the reference's 1e-6 at no cost in time (the walk is latency-bound).  flags = 0 is qamd_microtree_run. */
+ * the reference's 1e-6 (measured 3e-8) at 1.35 us per dependent step instead of 0.96.  flags = 0 is qamd_microtree_run. */
 #define QAMD_MICRO_WIDE 1
 int qamd_microtree_run_ex(int32_t dtype, const qamd_micro_step* steps_dev, int32_t nsteps, const int32_t* etab_dev,
                           const int32_t* ktab_dev, const void* const* inputs_dev, int32_t ninputs, void* arena_dev,

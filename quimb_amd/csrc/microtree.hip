@@ -46,8 +46,9 @@ template <typename R> struct MElem<R, true> {
 // WIDE (fp32 / complex64 trees): the INTERMEDIATES are carried in double precision -- inputs are read as they are, every
 // step accumulates in fp64 and stores fp64 into the arena, the root is rounded once on its way out.  A circuit amplitude is
 // ~900 chained steps cancelling down to |a| ~ 2^-26: rounded to fp32 after every step they cost 0.7-2.1e-6 relative
-// (numpy's own complex64 evaluation of the same tree: 1.4e-6), more than north_star's 1e-6; the kernel is latency-bound
-// (~1 us per dependent step), so the wider arithmetic is free.
+// (numpy's own complex64 evaluation of the same tree: 1.4e-6), more than north_star's 1e-6.  Measured on config #2: 3e-8
+// instead of 1.75e-6, at 1.35 us per dependent step instead of 0.96 (16-byte LDS elements, fp64 FMA chains): 1.2 ms per
+// amplitude instead of 0.86.  Parity comes first; Options.micro_wide = False is the per-step-rounding walk.
 template <typename R, bool CPLX, bool LDSARENA, bool WIDE>
 __global__ __launch_bounds__(256) void microtree_kernel(const qamd_micro_step* __restrict__ steps, int nsteps,
                                                         const int32_t* __restrict__ etab,

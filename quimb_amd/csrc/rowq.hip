@@ -86,8 +86,10 @@ __device__ __forceinline__ acc4 rq_mfma(float a, float b, acc4 c, int abid) {
 }
 
 // ACONT: the up legs v2..v5 are one contiguous run of the boundary tensor (site 1 loads 12-byte vectors).
-// FULL: d2..d5 and h of size 6 and the result's (d2..d5) one contiguous, 16-byte aligned run -- the column maps and the
-// copy-out are compile-time; otherwise the extents e[] (d1..d5, h) are runtime and the copy-out is element-wise.
+// FULL: d3..d5 and h of size 6 and the result's (d2..d5) one contiguous, 16-byte aligned run -- the column maps are
+// compile-time (d1 only counts the items, d2 is the outermost column digit: a rank's range-sliced share shortens exactly
+// these two) and the copy-out moves whole 16-byte vectors; otherwise the extents e[] (d1..d5, h) are runtime and the copy-out
+// is element-wise.
 // a global load as  global_load_dword v, v_off, s[base:base+1]: the base stays in SGPRs, the per-lane part is 32 bits
 typedef const __attribute__((address_space(1))) char* rq_gptr_t;
 __device__ __forceinline__ float rq_gload(uint64_t sbase, uint32_t voff) {
@@ -162,7 +164,7 @@ __global__ __launch_bounds__(256, 3) void rowq_kernel(const RowArgs p, const Row
   }
   uint32_t ext[6];                                                  // extents of d1..d5, h
 #pragma unroll
-  for (int c = 0; c < 5; ++c) ext[c] = (FULL && c > 0) ? D : p.ed[c];    // (d1 only counts the items: always runtime)
+  for (int c = 0; c < 5; ++c) ext[c] = (FULL && c > 1) ? D : p.ed[c];    // (d1 only counts the items, d2 is the OUTERMOST column digit of the later sites: both always runtime)
   ext[5] = FULL ? D : p.eh;
   const int blk = lane >> 2, li = lane & 3;
 
@@ -186,7 +188,7 @@ __global__ __launch_bounds__(256, 3) void rowq_kernel(const RowArgs p, const Row
       const int t = idx / DD, k = idx - t * DD, row = 4 * t + li;
       const int dd = row / D, bp = row - dd * D, b = k / D, v = k - b * D;
       bool ok = t < 9;
-      if (!FULL) ok = ok && (uint32_t)dd < ext[c] && (c < 4 || (uint32_t)bp < ext[5]);
+      if (!FULL || c == 1) ok = ok && (uint32_t)dd < ext[c] && (c < 4 || (uint32_t)bp < ext[5]);
       const uint32_t off = ok ? v * s0 + b * s1 + dd * s2 + bp * s3 : 0u;
       tmp[R] = RQ_ABL(32) ? 0.5f : Wc[off];
       tmp[R] = ok ? tmp[R] * scale : 0.f;
@@ -294,6 +296,7 @@ __global__ __launch_bounds__(256, 3) void rowq_kernel(const RowArgs p, const Row
     int tidv = tid;
     asm volatile("" : "+v"(tidv));
     const int lanev = tidv & 63;
+    const uint32_t rot = kitem + (blockIdx.x >> 3);
     // ---- site 1: st[b1][v2..v5] = sum_v1 W1[v1, d1, b1] T[S, v1, v2..v5]
     {
       float w0s[DD];                                                // [v1][b1] of this item's d1: 9 broadcast reads
@@ -360,8 +363,11 @@ __global__ __launch_bounds__(256, 3) void rowq_kernel(const RowArgs p, const Row
 #pragma unroll
       for (int s = 2; s <= 5; ++s)
         if (s != c) ncols *= (s < c ? ext[s - 1] : (uint32_t)D);
-      const uint32_t j0 = 64u * wave + lanev;
-      if (64u * wave < ncols) {
+      // (fewer than four column tiles -- a sliced d2 halves the columns of sites 3..5 -- would leave the same SIMDs idle
+      // in every workgroup of the CU: the tile -> wave map rotates with the item and the workgroup)
+      const uint32_t wrot = (wave + rot) & 3u;
+      const uint32_t j0 = 64u * wrot + lanev;
+      if (64u * wrot < ncols) {
         uint32_t j = j0 < ncols ? j0 : 0, f = 0;
 #pragma unroll
         for (int s = 5; s >= 2; --s)
@@ -399,7 +405,7 @@ __global__ __launch_bounds__(256, 3) void rowq_kernel(const RowArgs p, const Row
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             rq_touch<7, NF - 7>(cur);
           }
-          if (FULL || 12u * g < nrow) {
+          if ((FULL && c != 2) || 12u * g < nrow) {
             acc4 acc[3];
 #pragma unroll
             for (int t = 0; t < 3; ++t) acc[t] = acc4{0, 0, 0, 0};
@@ -418,7 +424,7 @@ __global__ __launch_bounds__(256, 3) void rowq_kernel(const RowArgs p, const Row
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                   const int row = 4 * (3 * g + t) + r, dd = row / D, bp = row - dd * D;
-                  if (FULL || ((uint32_t)dd < ext[c - 1] && (c < 5 || (uint32_t)bp < ext[5])))
+                  if ((FULL && c != 2) || ((uint32_t)dd < ext[c - 1] && (c < 5 || (uint32_t)bp < ext[5])))
                     RQ_DS_WRITE(fa, acc[t][r], (bp * SB + dd * sc) * 4);
                 }
             }
@@ -433,12 +439,13 @@ __global__ __launch_bounds__(256, 3) void rowq_kernel(const RowArgs p, const Row
     // ---- copy-out: st[h][d2..d5] -> C[ccur + h sh + ...]: the image is read into registers, released (barrier), and the
     // stores drain under the next item's first site
     if (FULL) {
-      constexpr int NV = D * (SB / 4), NP = (NV + 255) / 256;       // 1944 vectors: 324 per h
+      constexpr int NP = (D * (SB / 4) + 255) / 256;                // at most 1944 vectors: 54 e2 per h
+      const int vph = 54 * (int)ext[1], NV = D * vph;
       vec4 ov[NP];
 #pragma unroll
       for (int i = 0; i < NP; ++i) {
         const int q = tidv + 256 * i;
-        const int h = q / (SB / 4), r4 = q - h * (SB / 4);
+        const int h = q / vph, r4 = q - h * vph;
         if (q < NV) ov[i] = *reinterpret_cast<const vec4*>(st + h * SB + 4 * r4);
       }
       rq_barrier();
@@ -446,7 +453,7 @@ __global__ __launch_bounds__(256, 3) void rowq_kernel(const RowArgs p, const Row
 #pragma unroll
       for (int i = 0; i < NP; ++i) {
         const int q = tidv + 256 * i;
-        const int h = q / (SB / 4), r4 = q - h * (SB / 4);
+        const int h = q / vph, r4 = q - h * vph;
         if (q < NV) {
           const vec4 v = ov[i];
           if (!RQ_ABL(1)) *reinterpret_cast<vec4*>(C + ccur + (int64_t)h * p.sh + 4 * r4) = v;
@@ -549,7 +556,7 @@ extern "C" int qamd_rowq_launch(const RowArgs* a, const void* A, const void* con
   bool full = a->eh == D;
   for (int c = 0; c < 5; ++c) {
     if (a->ed[c] < 1 || a->ed[c] > (uint32_t)D) return -2;
-    full = full && (c == 0 || a->ed[c] == (uint32_t)D);
+    full = full && (c <= 1 || a->ed[c] == (uint32_t)D);
   }
   if (a->eh < 1 || a->eh > (uint32_t)D) return -2;
   // the vector copy-out: (d2..d5) one contiguous run in C, every run 16-byte aligned

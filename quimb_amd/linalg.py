@@ -218,14 +218,16 @@ def _gram_defect(g):
     return float((t - torch.eye(t.shape[0], dtype=t.dtype, device=t.device)).abs().max().item())
 
 
-def qr_via_cholesky(x, shift=True, refine=False):
+def qr_via_cholesky(x, shift=True, refine=False, return_defect=False):
     """``(Q, R)`` of a tall 2-d array (m >= n) from the Cholesky factor of its Gram matrix -- the reference's
     ``qr_via_cholesky`` (decomp.py:2359-2420): ``G = x^H x`` (one GETT launch), ``G = R^H R`` (potrf on n x n),
     ``Q = x R^-1`` (a triangular solve).  Orthogonality of Q degrades as cond(x)^2 eps (and by the regularising shift);
     ``refine`` repeats the step on Q (CholeskyQR2: orthogonal to eps for cond(x) < eps^-1/2) and folds the second
     triangle into R; ``refine="auto"`` forms ``Q^H Q`` (the Gram matrix the second pass would factor anyway), reads its
     distance from the identity back and runs the second pass only if that exceeds 100 eps -- a well-conditioned input
-    pays one extra GETT launch instead of a second potrf + trsm.  R has a positive real diagonal by construction."""
+    pays one extra GETT launch instead of a second potrf + trsm.  R has a positive real diagonal by construction.
+    ``return_defect``: also return max |Q^H Q - I| of the returned Q where ``refine="auto"`` measured it on the way (the
+    one-pass case), else None."""
     from . import ops
 
     x = x if isinstance(x, Array) else Array.from_numpy(np.asarray(x))
@@ -233,16 +235,21 @@ def qr_via_cholesky(x, shift=True, refine=False):
     L = cholesky_regularized(g, shift=shift)                    # g = L L^H  ->  R = L^H
     R = ops.transpose(L.conj(), (1, 0))
     Q = solve_triangular(R, x, lower=False, left=False)         # Q R = x
+    defect = None           # max |Q^H Q - I| of the factor that is RETURNED, where this routine has measured it
     if refine == "auto":
         g2 = ops.tensordot(Q.conj(), Q, axes=([0], [0]))
-        if _gram_defect(g2) > 100.0 * float(np.finfo(np.dtype(x.dtype)).eps):
+        defect = _gram_defect(g2)
+        if defect > 100.0 * float(np.finfo(np.dtype(x.dtype)).eps):
             L2 = cholesky_regularized(g2, shift=shift)
             R2 = ops.transpose(L2.conj(), (1, 0))
             Q = solve_triangular(R2, Q, lower=False, left=False)
             R = ops.tensordot(R2, R, axes=([1], [0]))
+            defect = None   # (a second pass ran: its result has not been measured)
     elif refine:
         Q, R2 = qr_via_cholesky(Q, shift=shift, refine=False)
         R = ops.tensordot(R2, R, axes=([1], [0]))
+    if return_defect:
+        return Q, R, defect
     return Q, R
 
 
@@ -302,8 +309,10 @@ def orth_cholesky_checked(y):
     y = y if isinstance(y, Array) else Array.from_numpy(np.asarray(y))
     eps = float(np.finfo(np.dtype(y.dtype)).eps)
     try:
-        Q = qr_via_cholesky(y, shift=True, refine="auto")[0]
-        defect = _gram_defect(ops.tensordot(Q.conj(), Q, axes=([0], [0])))
+        # (a well-conditioned sketch was measured on the way -- one pass, its defect already read back: nothing extra)
+        Q, _, defect = qr_via_cholesky(y, shift=True, refine="auto", return_defect=True)
+        if defect is None:
+            defect = _gram_defect(ops.tensordot(Q.conj(), Q, axes=([0], [0])))
         if np.isfinite(defect) and defect <= ORTH_DEFECT_EPS * eps:
             return Q, False
     except (np.linalg.LinAlgError, RuntimeError, FloatingPointError):

@@ -11,12 +11,26 @@ exist; it exits 0 with a loud SKIPPED line where they do not, so it can sit in a
       (infer_backend == top-level module name of the class), ``register()`` overrides are picked up
   B2  cotengra ``implementation=(tensordot, einsum)``: tuple order and call signatures
   B3  ``ContractionTree.from_any(<real cotengra ContractionTree>)``: path, cost and width agree
-  then the whole of tests/golden/dropin_check.py with ``--stack real``.
+  then the whole of tests/golden/dropin_check.py with ``--stack real`` -- quimb's own TensorNetwork.contract / fuse /
+  split / contract_boundary / Circuit.amplitude on ``quimb_amd.Array`` data -- on every device asked for.
+
+    python scripts/verify_real_stack.py [--device auto|emu|hip|both]
+
+``auto`` (default): the MI355X if one is visible, else the numpy plan interpreter; ``both``: the interpreter first, then
+the HIP device (the leg no build box has been able to run: ``--device hip --stack real``).  Needs three wheels next to
+this repository's own requirements (numpy, torch-rocm): ``quimb`` (any version whose tensor_core.py matches
+/root/reference: 1.10+), ``autoray==0.10.1`` and ``cotengra==0.8.2`` (the reference's pins, pixi.lock:67,70) -- plus
+quimb's own hard imports (numba, cytoolz or toolz, tqdm, psutil).
 """
+import argparse
 import importlib
 import os
 import subprocess
 import sys
+
+_ap = argparse.ArgumentParser(description=__doc__.split("\n")[0])
+_ap.add_argument("--device", choices=["auto", "emu", "hip", "both"], default="auto")
+ARGS = _ap.parse_args()
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -47,11 +61,14 @@ try:
     have_gpu = torch.cuda.is_available()
 except Exception:
     have_gpu = False
-if not have_gpu:
+if ARGS.device in ("hip", "both") and not have_gpu:
+    sys.exit("--device %s asked for, but no GPU is visible" % ARGS.device)
+devices = {"auto": ["hip" if have_gpu else "emu"], "emu": ["emu"], "hip": ["hip"], "both": ["emu", "hip"]}[ARGS.device]
+if devices[0] == "emu":
     from emu_device import EmuDevice
 
     qd.set_default_device(EmuDevice())
-print(f"autoray {autoray.__version__}, cotengra {ctg.__version__}, device: {'hip' if have_gpu else 'emu'}")
+print(f"autoray {autoray.__version__}, cotengra {ctg.__version__}, devices: {devices} (B1-B3 below on {devices[0]})")
 
 # ---- B1: dispatch -------------------------------------------------------------------------------------------
 assert qab.register() == "quimb_amd"
@@ -88,10 +105,12 @@ assert np.allclose(got.to_numpy(), want, rtol=1e-10)
 print("B3 cotengra tree loader: ok")
 
 # ---- quimb's own code on the backend ----------------------------------------------------------------------------------
-res = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "golden", "dropin_check.py"), "--stack", "real",
-                      "--device", "hip" if have_gpu else "emu"], capture_output=True, text=True)
-print(res.stdout[-3000:])
-if res.returncode != 0 or "DROPIN OK" not in res.stdout:
-    print(res.stderr[-4000:])
-    sys.exit("drop-in check with the real stack FAILED")
-print("REAL STACK OK")
+for dev_name in devices:
+    print(f"---- tests/golden/dropin_check.py --stack real --device {dev_name}")
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "golden", "dropin_check.py"), "--stack", "real",
+                          "--device", dev_name], capture_output=True, text=True)
+    print(res.stdout[-3000:])
+    if res.returncode != 0 or "DROPIN OK" not in res.stdout:
+        print(res.stderr[-4000:])
+        sys.exit(f"drop-in check with the real stack FAILED on device {dev_name}")
+print("REAL STACK OK (" + ", ".join(devices) + ")")

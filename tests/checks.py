@@ -28,10 +28,10 @@ WORST = {}
 #:     |got_i - want_i| / (|want_i| + ELEM_FLOOR * max|want|),
 #: -- entries above ELEM_FLOOR of the largest are judged relative to themselves, the floor keeps exact zeros and
 #: cancelled entries finite (an fp32 fma chain's error scales with sum |a||b|, not with the entry) -- and asserts
-#: ELEM_FACTOR * RTOL on it: together with the max-norm assert that is 2.5x tighter than the max-norm alone on every
+#: ELEM_FACTOR * RTOL on it (worst seen on the device: 9.3e-7 fp32, 9.0e-7 complex64): together with the max-norm assert that is 5x tighter than the max-norm alone on every
 #: entry below a tenth of the largest.  The worst figure seen is reported next to the max-norm one.
 ELEM_FLOOR = 0.1
-ELEM_FACTOR = 4.0
+ELEM_FACTOR = 2.0
 WORST_ELEM = {}
 
 
@@ -947,7 +947,7 @@ def check_microtree_config2():
     # ~6e-8 per step accumulating over the ~30 steps on the deepest root-to-leaf chain and the final cancellation): a
     # complex64 evaluation that ROUNDS EVERY STEP cannot hold north_star's 1e-6 on this network (rounds 3-5: 1.75e-6 on
     # the device, asserted at 1e-5).  Round 6: the device walks the tree with its INTERMEDIATES in double precision
-    # (microtree.hip WIDE: inputs and result stay complex64, the walk is latency-bound, the time is the same) and is held
+    # (microtree.hip WIDE: inputs and result stay complex64; 1.35 us per step instead of 0.96) and is held
     # to 1e-6; the per-step-rounding mode (Options.micro_wide = False) stays at its 1e-5.
     lo = orc.oracle_array_contract(arrays, inputs, (), path=tree.get_path())
     err_np = abs(lo - ref) / abs(ref)
