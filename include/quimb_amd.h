@@ -200,7 +200,7 @@ typedef struct {
   int64_t dim_s[4], sa_s[4], sc_s[4];
   int64_t w_strides[5][4];
   int32_t ed[5], eh;      /* extents of the new legs d1..d5, h (0 = D) */
-  int32_t kernel, pad_;   /* 0 auto, 1 rowpass_kernel, 2 rowq_kernel, 3 rowq_kernel with static shares */
+  int32_t kernel, pad_;   /* 0 auto, 1 rowpass_kernel, 2 rowq_kernel, 3 rowq_kernel with static shares, 4 / 5 rowq_kernel priority experiments */
 } qamd_rowpass_plan;
 int qamd_rowpass_supported(int32_t dtype, int32_t D, int32_t nsites);
 int qamd_contract_rowpass(const qamd_rowpass_plan* plan, const void* A, const void* const* W, void* C, const void* scale_a,

@@ -1302,11 +1302,15 @@ extern "C" int qamd_contract_rowpass(const qamd_rowpass_plan* p, const void* A, 
   if (p->nS < 0) kernel = 1;                               // the first row: rowfirst_kernel lives in rowpass.hip
   else if (kernel == 0) kernel = 2;
   if (kernel == 1 && !full) return QAMD_EUNSUPPORTED;
-  if (kernel == 2 || kernel == 3) {
+  if (kernel >= 2 && kernel <= 5) {
     for (int i = 0; i < 5; ++i)
       if (p->sv[i] < 0) return QAMD_EUNSUPPORTED;
     if (a_span >= (1ll << 31)) return QAMD_EUNSUPPORTED;
     if (kernel == 3) a.pad2_ = 512;      // equal static shares instead of the item queue
+    if (kernel == 4) a.pad2_ = 1024;     // no wave priorities (experiments)
+    if (kernel == 5) a.pad2_ = 128;      // the other workgroup -> priority map (experiments)
+  } else if (kernel != 1) {
+    return QAMD_EUNSUPPORTED;
   }
   const int rc = kernel >= 2 ? qamd_rowq_launch(&a, A, W, C, scale_a, scale_w, absmax_out, stream)
                              : qamd_rowpass_launch(&a, A, W, C, scale_a, scale_w, absmax_out, stream);

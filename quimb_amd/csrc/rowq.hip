@@ -156,8 +156,8 @@ __global__ __launch_bounds__(256, 3) void rowq_kernel(const RowArgs p, const Row
   }
   // distinct wave priorities for the workgroups that share a CU: they run identical code from the same start, and with
   // equal priority their MFMA phases and their LDS / global phases coincide (probe: 265 -> 241 us on the last row)
-  if (!RQ_ABL(1024)) {
-    const uint32_t pr = RQ_ABL(128) ? (blockIdx.x >> 8) % 3 : (blockIdx.x >> 3) % 3;
+  if (!(p.pad2_ & 1024u)) {     // (RowArgs.pad2_ bits 1024 / 128: no priorities / the other workgroup -> priority map; plan.kernel 4 / 5)
+    const uint32_t pr = (p.pad2_ & 128u) ? (blockIdx.x >> 8) % 3 : (blockIdx.x >> 3) % 3;
     if (pr == 0) __builtin_amdgcn_s_setprio(0);
     else if (pr == 1) __builtin_amdgcn_s_setprio(1);
     else __builtin_amdgcn_s_setprio(2);

@@ -441,7 +441,8 @@ class RowpassSpec:
 
 ROWPASS_SITES = 5
 ROWPASS_MAX_OUT = 1 << 24      # rowpass.hip (kernel 1) only: beyond that a row is bandwidth, not latency, for ITS item rate
-ROW_KERNELS = {"auto": 0, "tile": 1, "quad": 2, "quad-static": 3}     # 3: rowq.hip without its item queue (what a capturing stream gets)
+ROW_KERNELS = {"auto": 0, "tile": 1, "quad": 2, "quad-static": 3,     # 3: rowq.hip without its item queue (what a capturing stream gets)
+               "quad-noprio": 4, "quad-prio8": 5}                       # 4 / 5: experiments with the wave priorities of rowq.hip
 
 
 def rowpass_supported(dtype_name, D, nsites):
@@ -523,7 +524,7 @@ def plan_rowpass(la, site_layouts, lc, size, dtype_name, kernel=0):
     if len(gs) > 4 or n_s * D >= 2**31 or (kernel == 1 and (c_size > ROWPASS_MAX_OUT or not full)):
         return None
     a_size = prod(size[i] for i in la)
-    if kernel in (2, 3) and (a_size >= 2**31 or c_size >= 2**40):
+    if kernel in (2, 3, 4, 5) and (a_size >= 2**31 or c_size >= 2**40):
         return None
     # multiplications of the five steps as they would have run one by one (all legs D: D^7 for the first site, D^8 for each
     # other): site c multiplies (columns: d_1..d_{c-1}, v_{c+1}..v_5) x (K: bond, v_c) x (N: d_c, next bond / h)

@@ -11,9 +11,11 @@ out, tag = sys.argv[1], sys.argv[2]
 def rows(path):
     dur, pmc = {}, {}
     for ln in open(path):
-        m = re.match(r"^(\S.*?\S)\s+(\d+)\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)\s*$", ln)
+        # kernel  calls  total_ms  avg_us  [median_us]  min_us  max_us  pct
+        m = re.match(r"^(\S.*?\S)\s+(\d+)\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)(?:\s+([\d.]+))?\s*$", ln)
         if m:
-            dur[m.group(1)] = (int(m.group(2)), float(m.group(3)), float(m.group(4)))
+            med = float(m.group(5)) if m.group(8) is not None else None
+            dur[m.group(1)] = (int(m.group(2)), float(m.group(3)), float(m.group(4)), med)
             continue
         m = re.match(r"^(\S.*?\S)\s+([A-Z_0-9a-z]+)\s+(\d+)\s+([\d.]+)\s+([\d.]+)\s*$", ln)
         if m:
@@ -66,6 +68,7 @@ res = {
               "separate passes, same bench command); durations from profiles/%s_bench_stats.txt" % tag,
     "launches_profiled": launches,
     "rocprof_avg_launch_us": kd[1][2],
+    "rocprof_median_launch_us": kd[1][3],
     "bench_hip_event_avg_launch_us": roof["avg_launch_ms"] * 1e3,
     "fetch_size_kb_per_launch": fetch_kb,
     "write_size_kb_per_launch": write_kb,
