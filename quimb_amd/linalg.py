@@ -235,16 +235,22 @@ def qr_via_cholesky(x, shift=True, refine=False, return_defect=False):
     L = cholesky_regularized(g, shift=shift)                    # g = L L^H  ->  R = L^H
     R = ops.transpose(L.conj(), (1, 0))
     Q = solve_triangular(R, x, lower=False, left=False)         # Q R = x
-    defect = None           # max |Q^H Q - I| of the factor that is RETURNED, where this routine has measured it
+    defect = None           # max |Q^H Q - I| of the factor that is RETURNED, where this routine knows it
     if refine == "auto":
         g2 = ops.tensordot(Q.conj(), Q, axes=([0], [0]))
         defect = _gram_defect(g2)
-        if defect > 100.0 * float(np.finfo(np.dtype(x.dtype)).eps):
+        eps_ = float(np.finfo(np.dtype(x.dtype)).eps)
+        if defect > 100.0 * eps_:
+            first = defect
             L2 = cholesky_regularized(g2, shift=shift)
             R2 = ops.transpose(L2.conj(), (1, 0))
             Q = solve_triangular(R2, Q, lower=False, left=False)
             R = ops.tensordot(R2, R, axes=([1], [0]))
-            defect = None   # (a second pass ran: its result has not been measured)
+            # CholeskyQR2: a first factor with ||Q1^H Q1 - I||_2 < 1/2 (here bounded by n x the max-norm that was read back)
+            # has cond(Q1) < sqrt(3), and the second pass then leaves O(eps) -- no need to measure it again.  Otherwise the
+            # result is NOT known to be orthonormal (None): the checked caller measures it and falls back if need be.
+            n_ = g2.shape[0]
+            defect = 100.0 * eps_ if np.isfinite(first) and first * n_ <= 0.5 else None     # (nominal: as good as a one-pass accept)
     elif refine:
         Q, R2 = qr_via_cholesky(Q, shift=shift, refine=False)
         R = ops.tensordot(R2, R, axes=([1], [0]))
@@ -292,16 +298,19 @@ def _randn(dev, shape, dtype, seed):
     return Array(dev, t.reshape(-1), tuple(shape), dtype)
 
 
-#: how far from the identity ``Q^H Q`` may be (max-norm, in units of the dtype's eps) for a Cholesky-QR basis to be
-#: accepted as orthonormal by ``orth_cholesky_checked``
-ORTH_DEFECT_EPS = 1000.0
+#: how far from the identity ``Q^H Q`` may be (max-norm, in units of n x the dtype's eps, n = number of columns: the
+#: rounding level of an n-column Gram matrix) for a Cholesky-QR basis to be accepted as orthonormal by
+#: ``orth_cholesky_checked``.  (A flat 1000 eps sent every third chi = 512 fp64 split of a DMRG sweep to geqrf / orgqr --
+#: 14 ms instead of 2.7 -- for defects of 1-3e-13.)
+ORTH_DEFECT_EPS = 100.0
 
 
 def orth_cholesky_checked(y):
     """An orthonormal basis of the columns of ``y`` by CholeskyQR2, CHECKED: the Gram route squares the condition number, so
     on an ill-conditioned sketch (fp32 with a spectral decay of 1e-3 already, fp64 beyond 1e-8) even the refined ``Q`` is
     far from an isometry -- and everything downstream (canonical forms, <H> / sum s^2) assumes one.  The defect of the
-    FINAL factor is measured (one more small GETT launch); beyond ``ORTH_DEFECT_EPS`` eps, or when a Cholesky
+    FINAL factor is measured (one more small GETT launch, unless the passes themselves established it); beyond
+    ``ORTH_DEFECT_EPS`` x n x eps, or when a Cholesky
     factorisation fails outright, the basis comes from Householder QR instead (``linalg.qr``: rocSOLVER geqrf / orgqr).
     Returns ``(Q, used_fallback)``."""
     from . import ops
@@ -313,7 +322,7 @@ def orth_cholesky_checked(y):
         Q, _, defect = qr_via_cholesky(y, shift=True, refine="auto", return_defect=True)
         if defect is None:
             defect = _gram_defect(ops.tensordot(Q.conj(), Q, axes=([0], [0])))
-        if np.isfinite(defect) and defect <= ORTH_DEFECT_EPS * eps:
+        if np.isfinite(defect) and defect <= ORTH_DEFECT_EPS * y.shape[1] * eps:
             return Q, False
     except (np.linalg.LinAlgError, RuntimeError, FloatingPointError):
         pass          # potrf refused the (shifted) Gram matrix: not positive definite to working precision

@@ -27,6 +27,12 @@ pass() {  # name, rocprof args...
   sed -i "s#/tmp/qprof_$n#rocprofv3 $* -- bench.py --steps 5 --warmup 2 --no-cpu --no-secondary#" $OUT/${TAG}_bench_$n.txt
 }
 pass stats --kernel-trace --stats
+# the same step replayed as a launch program (one host call): under the profiler the Python launch loop falls behind the
+# device, so the later corners' launches land BESIDE the first join and stretch it; replayed, the step has the shape of an
+# unprofiled run (every corner queued before the first join) and both join launches agree with the bench's HIP events
+CMD_SAVE="$CMD"; CMD="$CMD --launch program"
+pass stats_program --kernel-trace --stats
+CMD="$CMD_SAVE"
 pass fetch --kernel-trace --pmc FETCH_SIZE
 pass write --kernel-trace --pmc WRITE_SIZE
 pass mfma  --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE

@@ -1493,7 +1493,7 @@ def check_orth_cholesky_checked():
             Q, fell_back = linalg.orth_cholesky_checked(qa.asarray(y))
             q = Q.to_numpy().astype(np.complex128 if np.dtype(dtype).kind == "c" else np.float64)
             defect = np.max(np.abs(q.conj().T @ q - np.eye(n)))
-            assert defect <= 2 * linalg.ORTH_DEFECT_EPS * eps, (dtype, decay, defect, fell_back)
+            assert defect <= 2 * linalg.ORTH_DEFECT_EPS * n * eps, (dtype, decay, defect, fell_back)
             if decay == 1.0:
                 assert not fell_back, (dtype, "a well-conditioned sketch keeps the Cholesky route")
             # the basis spans the well-resolved part of the sketch's column space (directions above sqrt(eps) of the largest)
