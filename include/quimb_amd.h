@@ -185,7 +185,8 @@ int qamd_contract_chain2(const qamd_chain2_plan* plan, const void* A, const void
  * served: nothing yet); the NEW legs may be shorter: ed[c] <= D values of d_c, eh <= D of h (0 = D) -- the range-sliced cut
  * bonds of one rank's share of a sharded contraction.  kernel: 0 = the library's choice, 1 = csrc/rowpass.hip (16x16x4 tiles,
  * two LDS images; needs every extent = D), 2 = csrc/rowq.hip (4x4x1 multi-block MFMA, one in-place image; rows of any size;
- * rows larger than one round of the chip hand their work items out through a per-stream queue), 3 = the same without the queue.  S = every other index of A, as up to 4 groups (dim_s, A strides sa_s, C strides sc_s, outermost first); sv / sd / sh:
+ * persistent workgroups with equal static shares of the work items), 3 = the same with a per-(device, stream) item queue
+ * (the only entry that keeps state between calls: a 64-byte counter slot per stream, re-armed by the launch itself).  S = every other index of A, as up to 4 groups (dim_s, A strides sa_s, C strides sc_s, outermost first); sv / sd / sh:
  * element strides of the up legs in A and of the new down legs / the row's new open leg in C; w_strides[c] = element strides
  * of site c's (up, left bond, down, right bond) legs in W[c] (site 0 has no left bond, site 4's right bond is h).  A, C and
  * the W[c] are read and written in place at those strides: the call consumes and produces exactly the layouts the five
@@ -200,7 +201,7 @@ typedef struct {
   int64_t dim_s[4], sa_s[4], sc_s[4];
   int64_t w_strides[5][4];
   int32_t ed[5], eh;      /* extents of the new legs d1..d5, h (0 = D) */
-  int32_t kernel, pad_;   /* 0 auto, 1 rowpass_kernel, 2 rowq_kernel, 3 rowq_kernel with static shares, 4 / 5 rowq_kernel priority experiments */
+  int32_t kernel, pad_;   /* 0 auto, 1 rowpass_kernel, 2 rowq_kernel, 3 rowq_kernel with the item queue, 4 / 5 rowq_kernel priority experiments */
 } qamd_rowpass_plan;
 int qamd_rowpass_supported(int32_t dtype, int32_t D, int32_t nsites);
 int qamd_contract_rowpass(const qamd_rowpass_plan* plan, const void* A, const void* const* W, void* C, const void* scale_a,

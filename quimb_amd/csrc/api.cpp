@@ -1306,7 +1306,7 @@ extern "C" int qamd_contract_rowpass(const qamd_rowpass_plan* p, const void* A, 
     for (int i = 0; i < 5; ++i)
       if (p->sv[i] < 0) return QAMD_EUNSUPPORTED;
     if (a_span >= (1ll << 31)) return QAMD_EUNSUPPORTED;
-    if (kernel == 3) a.pad2_ = 512;      // equal static shares instead of the item queue
+    if (kernel == 3) a.pad2_ = 512;      // the per-stream item queue instead of equal static shares
     if (kernel == 4) a.pad2_ = 1024;     // no wave priorities (experiments)
     if (kernel == 5) a.pad2_ = 128;      // the other workgroup -> priority map (experiments)
   } else if (kernel != 1) {

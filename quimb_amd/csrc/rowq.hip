@@ -139,10 +139,10 @@ __global__ __launch_bounds__(256, 3) void rowq_kernel(const RowArgs p, const Row
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   // ---- this workgroup's items: workgroups are dealt to the XCDs round-robin, XCD x takes the items [x * per, (x + 1) * per)
-  // (the up to six items of one S then share that XCD's L2).  With a queue (rows larger than one round of the chip) its
-  // workgroups draw them one by one from the XCD's counter -- the MFMA pipe serves the OLDEST wave first, so workgroups that
-  // share a CU advance at very different speeds and equal static shares end 27 % apart --, the index for the item after
-  // next drawn a whole item ahead of its use; without one (small rows, stream capture) they take contiguous equal shares.
+  // (the up to six items of one S then share that XCD's L2), its workgroups contiguous equal shares of them.  With a queue
+  // (opt-in, plan.kernel 3; rows larger than one round of the chip) they draw them one by one from the XCD's counter instead
+  // -- the MFMA pipe serves the OLDEST wave first, so workgroups that share a CU advance at very different speeds and static
+  // shares end 27 % apart --, the index for the item after next drawn a whole item ahead of its use.
   uint32_t it, it_end, xlo, nx;
   const uint32_t xcd = blockIdx.x & 7;
   {
@@ -513,7 +513,7 @@ using namespace qamdq;
 #include <mutex>
 #include <utility>
 
-// The item queue of a large row: nine counters (one per XCD + finished workgroups), re-armed by the launch's last workgroup.
+// The item queue of a large row (opt-in): nine counters (one per XCD + finished workgroups), re-armed by the launch's last workgroup.
 // Launches on ONE stream are ordered, so a (device, stream) pair owns one 64-byte slot for good; a capturing stream gets
 // none (the captured node could replay beside an eager launch on the same stream): the kernel then deals equal static shares.
 static uint32_t* rq_queue_for(hipStream_t st) {
@@ -575,7 +575,10 @@ extern "C" int qamd_rowq_launch(const RowArgs* a, const void* A, const void* con
   uint32_t* queue = nullptr;
   if (grid > 768) {
     grid = 768;
-    if (!(a->pad2_ & 512)) queue = rq_queue_for((hipStream_t)stream);     // (bit 512: equal static shares, for the probe)
+    // (bit 512 = plan.kernel 3: draw the items from the per-stream queue instead of dealing equal static shares.  The queue
+    // evens out the workgroups' finishing times -- the MFMA pipe serves the oldest wave first -- but the step is the same
+    // 14.7 ms either way (profiles/r06_rowq_variants.txt), so the default keeps the library free of per-stream state.)
+    if (a->pad2_ & 512) queue = rq_queue_for((hipStream_t)stream);
   }
 #define QAMD_RQ_GO(F, AC)                                                                                          \
   QAMD_LAUNCH((rowq_kernel<F, AC>), dim3(grid), dim3(256), lds, (hipStream_t)stream, *a, w, (const float*)A, (float*)C, \

@@ -6,7 +6,7 @@ rng = np.random.default_rng(1)
 D = 6
 ups = [f"v{i}" for i in range(5)]; downs = [f"d{i}" for i in range(5)]; bonds = [f"b{i}" for i in range(4)]
 spect = ["s0", "s1", "s2", "s3"]
-for kern in ("quad-static", "quad"):
+for kern in ("quad-queue", "quad"):
     sdim = {ix: D for ix in ups + bonds + spect + downs + ["h"]}
     la = tuple(spect + ups)
     sites = [tuple([ups[c]] + ([bonds[c - 1]] if c else []) + [downs[c]] + ([bonds[c]] if c < 4 else ["h"])) for c in range(5)]

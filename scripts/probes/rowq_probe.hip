@@ -132,7 +132,7 @@ int main(int argc, char** argv) {
     return 0;
   }
 #endif
-  const int abl[] = {0, 512, 1024, 1024 | 512, 128, 128 | 512, 1, 2, 4, 8, 16, 28, 64, 1 | 2 | 8 | 16 | 32, 127 & ~64};
+  const int abl[] = {0, 512, 1024, 1024 | 512, 128, 128 | 512, 1, 2, 4, 8, 16, 28, 64, 1 | 2 | 8 | 16 | 32, 127 & ~64};   // 512: with the item queue
   for (uint32_t items : {(uint32_t)(S * 6), 768u, 256u}) {
     p.items = items;
     for (int ab : abl) {
@@ -149,6 +149,6 @@ int main(int argc, char** argv) {
       printf("items %5u ablate %3d: %8.1f us per launch\n", items, ab, 1000.0 * ms / reps);
     }
   }
-  printf("(bits: 1 no result stores, 2 no loads of A, 4 no MFMAs in sites 2-5, 8 no LDS state reads, 16 no LDS state writes, 32 no gather of W, 64 return after site 1)\n");
+  printf("(bits: 512 item queue instead of static shares, 1024 no wave priorities, 128 the other priority map; 1 no result stores, 2 no loads of A, 4 no MFMAs in sites 2-5, 8 no LDS state reads, 16 no LDS state writes, 32 no gather of W, 64 return after site 1)\n");
   return 0;
 }

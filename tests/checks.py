@@ -2501,10 +2501,10 @@ def check_rowpass(seed=41):
     assert plan_rowpass(tuple(la), sites, lc, dict(sdim, v2=4), "float32") is None
     sdim = {ix: D for ix in sdim}
     # rows LARGER than one round of the chip (persistent workgroups walk several work items, drawn from the per-stream item
-    # queue or dealt as static shares): the last row of a corner sweep of the 10x10 network and a rank's range-sliced share
+    # opt-in queue or dealt as static shares): the last row of a corner sweep of the 10x10 network and a rank's range-sliced share
     # of it, a sample of spectator values against numpy (S is a pure batch index of the row)
     if getattr(dev, "name", "") == "hip":
-        for kern, ext in (("quad", (6,) * 6), ("quad-static", (6,) * 6), ("quad", (3, 3, 6, 6, 6, 6)), ("quad-static", (3, 6, 6, 6, 6, 6)),
+        for kern, ext in (("quad", (6,) * 6), ("quad-queue", (6,) * 6), ("quad", (3, 3, 6, 6, 6, 6)), ("quad-queue", (3, 6, 6, 6, 6, 6)),
                           ("quad", (6,) * 6)):
             spect = ["s0", "s1", "s2", "s3"]
             sdim = {ix: D for ix in ups + bonds + spect}
@@ -2514,7 +2514,7 @@ def check_rowpass(seed=41):
                      for c in range(5)]
             lc = tuple(["h"] + spect + downs)
             rp = plan_rowpass(la, sites, lc, sdim, "float32", kern)
-            assert rp is not None and rp.kernel == {"quad": 2, "quad-static": 3}[kern]
+            assert rp is not None and rp.kernel == {"quad": 2, "quad-queue": 3}[kern]
             a = rand(rng, [sdim[i] for i in la], "float32")
             ws = [rand(rng, [sdim[i] for i in t], "float32") for t in sites]
             xa, xw = qa.asarray(a), [qa.asarray(w) for w in ws]
