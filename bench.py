@@ -13,12 +13,14 @@ amplitude (single-layer 10x10 D=6 tensor network, fp32), MI355X.
   the data path, ONE RCCL all-gather of (mantissa, exponent) pairs at the join; strong scaling: ``value`` = the
   one-rank tree's FLOPs / max-over-ranks time.  (256 slices are not reachable with all-6 bonds; ``--sliced`` keeps
   round 1's 216 single-value slices of the sweep, ``--two-sided`` round 2's branch decomposition.)
-* N == 1 also reports: ``secondary`` (BASELINE configs #2 and #5: circuit amplitude, DMRG2 matvec / local update),
+* N == 1 also reports: ``secondary`` (BASELINE configs #2, #3 as worded -- the compressed boundary-MPS sweep at a stated
+  chi, on the headline's tensors -- and #5: circuit amplitude, DMRG2 matvec / local update / sweeps),
   ``scaling_projection`` (the busiest rank's share of the N = 2 / 4 / 8 jobs timed on this one GPU) and
   ``cpu_baseline``.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with the extra ``roofline`` (dominant kernel, HIP
-events on the launch stream) and ``cpu_baseline`` (numpy/OpenBLAS port of the sweep on a bounded sample) objects.
+events on the launch stream) and ``cpu_baseline`` (numpy/OpenBLAS port of the sweep: a bounded sample to pick the thread
+count, then the WHOLE network once on this host, ~70 s) objects.
 """
 
 import argparse
