@@ -317,8 +317,8 @@ def _dry_run_setup():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--Lx", type=int, default=10)
     ap.add_argument("--Ly", type=int, default=10)
     ap.add_argument("--D", type=int, default=6)

@@ -1307,8 +1307,8 @@ extern "C" int qamd_contract_rowpass(const qamd_rowpass_plan* p, const void* A, 
       if (p->sv[i] < 0) return QAMD_EUNSUPPORTED;
     if (a_span >= (1ll << 31)) return QAMD_EUNSUPPORTED;
     if (kernel == 3) a.pad2_ = 512;      // the per-stream item queue instead of equal static shares
-    if (kernel == 4) a.pad2_ = 1024;     // no wave priorities (experiments)
-    if (kernel == 5) a.pad2_ = 128;      // the other workgroup -> priority map (experiments)
+    if (kernel == 4) a.pad2_ = 1024;     // wave priorities by (workgroup / 8) % 3 (experiments)
+    if (kernel == 5) a.pad2_ = 128;      // wave priorities by (workgroup / 256) % 3 (experiments)
   } else if (kernel != 1) {
     return QAMD_EUNSUPPORTED;
   }

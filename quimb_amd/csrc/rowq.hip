@@ -154,9 +154,12 @@ __global__ __launch_bounds__(256, 3) void rowq_kernel(const RowArgs p, const Row
     it_end = xlo + (uint32_t)(((uint64_t)(slot + 1) * nx) / nslot);
     if (!queue && it >= it_end) return;
   }
-  // distinct wave priorities for the workgroups that share a CU: they run identical code from the same start, and with
-  // equal priority their MFMA phases and their LDS / global phases coincide (probe: 265 -> 241 us on the last row)
-  if (!(p.pad2_ & 1024u)) {     // (RowArgs.pad2_ bits 1024 / 128: no priorities / the other workgroup -> priority map; plan.kernel 4 / 5)
+  // Experiment (plan.kernel 4 / 5 = RowArgs.pad2_ bits 1024 / 128): distinct wave priorities for the workgroups that share a
+  // CU -- they run identical code from the same start, and with equal priority their MFMA phases and their LDS / global
+  // phases tend to coincide.  Which workgroups share a CU is the dispatcher's business, though: on the last row alone the two
+  // maps below were 257 / 267 us against 287 without in one run and 303 / 249 against 263 in another, and in the step
+  // (four corners side by side) nothing at all (profiles/r06_rowq_variants.txt).  Off by default.
+  if (p.pad2_ & (1024u | 128u)) {
     const uint32_t pr = (p.pad2_ & 128u) ? (blockIdx.x >> 8) % 3 : (blockIdx.x >> 3) % 3;
     if (pr == 0) __builtin_amdgcn_s_setprio(0);
     else if (pr == 1) __builtin_amdgcn_s_setprio(1);

@@ -442,7 +442,7 @@ class RowpassSpec:
 ROWPASS_SITES = 5
 ROWPASS_MAX_OUT = 1 << 24      # rowpass.hip (kernel 1) only: beyond that a row is bandwidth, not latency, for ITS item rate
 ROW_KERNELS = {"auto": 0, "tile": 1, "quad": 2, "quad-queue": 3,      # 3: rowq.hip with its per-stream item queue (opt-in)
-               "quad-noprio": 4, "quad-prio8": 5}                       # 4 / 5: experiments with the wave priorities of rowq.hip
+               "quad-prio3": 4, "quad-prio8": 5}                       # 4 / 5: experiments with the wave priorities of rowq.hip
 
 
 def rowpass_supported(dtype_name, D, nsites):

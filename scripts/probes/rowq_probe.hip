@@ -149,6 +149,6 @@ int main(int argc, char** argv) {
       printf("items %5u ablate %3d: %8.1f us per launch\n", items, ab, 1000.0 * ms / reps);
     }
   }
-  printf("(bits: 512 item queue instead of static shares, 1024 no wave priorities, 128 the other priority map; 1 no result stores, 2 no loads of A, 4 no MFMAs in sites 2-5, 8 no LDS state reads, 16 no LDS state writes, 32 no gather of W, 64 return after site 1)\n");
+  printf("(bits: 512 item queue instead of static shares, 1024 / 128 wave priorities by (workgroup / 8) %% 3 / (workgroup / 256) %% 3; 1 no result stores, 2 no loads of A, 4 no MFMAs in sites 2-5, 8 no LDS state reads, 16 no LDS state writes, 32 no gather of W, 64 return after site 1)\n");
   return 0;
 }

@@ -27,7 +27,7 @@ F="--offload-arch=gfx950 -O3 -std=c++17 -mllvm -pragma-unroll-threshold=10000000
 } > $O/r06_rowq_probe.txt 2>&1
 {
   echo "# bench.py --steps 30 --warmup 3 --no-cpu --no-secondary with QAMD_ROW_KERNEL = ... (ms per step, TFLOP/s)"
-  for rk in quad quad-queue quad-noprio quad-prio8 tile; do
+  for rk in quad quad-queue quad-prio3 quad-prio8 tile; do
     echo "== $rk"
     QAMD_ROW_KERNEL=$rk timeout 150 python bench.py --steps 30 --warmup 3 --no-cpu --no-secondary 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(round(d['ms_per_step'],3), round(d['value'],2))"
   done

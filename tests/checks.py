@@ -2115,6 +2115,43 @@ def check_dmrg_local_update_full_chi(chi=512, dtype="float64", nmv=8):
     assert err <= (1e-10 if np.dtype(dtype) == np.float64 else 2e-5), err
 
 
+def check_kernel_pins_follow_the_executor():
+    """ADVICE r5 (device.py): the kernel pins of ``Options`` (pair_kernel / tile_cfg / split_k) are what the EXECUTOR captured
+    when it was built -- not what the device object saw when it was created, nor what the thread's options are when the
+    executor is called.  A big x small step runs on the streaming kernel by default and on the tiled GETT kernel under
+    ``pair_kernel = -1``; both executors are built first and called afterwards, outside any scope."""
+    rng = np.random.default_rng(9)
+    a, b = rand(rng, (128, 128, 16), "float32"), rand(rng, (16, 16), "float32")
+    tree = qa.ContractionTree([("a", "b", "k"), ("k", "n")], ("a", "b", "n"), {"a": 128, "b": 128, "k": 16, "n": 16}, path=[(0, 1)])
+    dev = qa.default_device()
+    assert hasattr(dev, "pinned")
+    ex_auto = qa.TreeExecutor(tree, "float32")
+    with qa.exec_options(pair_kernel=-1):
+        ex_tiled = qa.TreeExecutor(tree, "float32")
+        assert ex_tiled.options.pair_kernel == -1
+    want = np.einsum("abk,kn->abn", a.astype(np.float64), b.astype(np.float64))
+    names = {}
+    for label, ex in (("auto", ex_auto), ("tiled", ex_tiled), ("auto", ex_auto)):
+        dev.profile = []
+        try:
+            got = ex([a, b]).to_numpy()
+            names[label] = [n for (_, _, n, _, _, _) in dev.profile]
+        finally:
+            dev.profile = None
+        assert_close(got, want, "float32")
+    assert all(n.startswith("gett") for n in names["tiled"]), names
+    assert not any(n.startswith("gett_kernel") for n in names["auto"]), names       # the streaming / sweep kernel
+    # a bare op sees the thread's CURRENT options
+    with qa.exec_options(pair_kernel=-1):
+        dev.profile = []
+        try:
+            qa.tensordot(qa.asarray(a), qa.asarray(b), axes=([2], [0]))
+            bare = [n for (_, _, n, _, _, _) in dev.profile]
+        finally:
+            dev.profile = None
+    assert all(n.startswith("gett") for n in bare), bare
+
+
 def check_advice_low_items():
     """Array / Array, scalar / Array, integer powers (true division, elementwise); svd_via_eig on a rank-deficient
     matrix returns isometric factors (fewer columns); DMRG2.solve updates only the schedule it is given."""

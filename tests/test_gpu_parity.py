@@ -648,3 +648,8 @@ def test_two_sided_full_size(hip):
 def test_orth_cholesky_checked(hip):
     """a Cholesky-QR basis is checked and falls back to Householder QR when it is not orthonormal."""
     checks.check_orth_cholesky_checked()
+
+
+def test_kernel_pins_follow_the_executor(hip):
+    """an executor built under ``exec_options(pair_kernel=...)`` keeps that pin when it runs later."""
+    checks.check_kernel_pins_follow_the_executor()
