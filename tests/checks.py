@@ -2121,15 +2121,15 @@ def check_kernel_pins_follow_the_executor():
     executor is called.  A big x small step runs on the streaming kernel by default and on the tiled GETT kernel under
     ``pair_kernel = -1``; both executors are built first and called afterwards, outside any scope."""
     rng = np.random.default_rng(9)
-    a, b = rand(rng, (128, 128, 16), "float32"), rand(rng, (16, 16), "float32")
-    tree = qa.ContractionTree([("a", "b", "k"), ("k", "n")], ("a", "b", "n"), {"a": 128, "b": 128, "k": 16, "n": 16}, path=[(0, 1)])
+    a, b = rand(rng, (16, 128, 128), "float32"), rand(rng, (16, 16), "float32")       # A[k, (a, b)]: the free bundle stride-1
+    tree = qa.ContractionTree([("k", "a", "b"), ("k", "n")], ("n", "a", "b"), {"a": 128, "b": 128, "k": 16, "n": 16}, path=[(0, 1)])
     dev = qa.default_device()
     assert hasattr(dev, "pinned")
     ex_auto = qa.TreeExecutor(tree, "float32")
     with qa.exec_options(pair_kernel=-1):
         ex_tiled = qa.TreeExecutor(tree, "float32")
         assert ex_tiled.options.pair_kernel == -1
-    want = np.einsum("abk,kn->abn", a.astype(np.float64), b.astype(np.float64))
+    want = np.einsum("kab,kn->nab", a.astype(np.float64), b.astype(np.float64))
     names = {}
     for label, ex in (("auto", ex_auto), ("tiled", ex_tiled), ("auto", ex_auto)):
         dev.profile = []
@@ -2145,7 +2145,7 @@ def check_kernel_pins_follow_the_executor():
     with qa.exec_options(pair_kernel=-1):
         dev.profile = []
         try:
-            qa.tensordot(qa.asarray(a), qa.asarray(b), axes=([2], [0]))
+            qa.tensordot(qa.asarray(b), qa.asarray(a), axes=([0], [0]))
             bare = [n for (_, _, n, _, _, _) in dev.profile]
         finally:
             dev.profile = None
