@@ -413,12 +413,9 @@ static int launch_one(const GettArgs& a, const void* A, const void* B, void* C, 
                       hipStream_t st) {
   constexpr int BM = 64 * TA, BN = 64 * TB;
   const size_t lds = (size_t)NS * 16 * (BM + BN) * sizeof(float) + (size_t)(BM + BN) * sizeof(int64_t);
-  static bool attr_done = false;
-  if (!attr_done && lds > 64 * 1024) {
+  if (lds > 64 * 1024)      // (per launch: the attribute belongs to the CURRENT device; a process-wide flag would skip a second GPU)
     (void)hipFuncSetAttribute((const void*)gemmk_kernel<TA, TB, NS, MINW, DOT>, hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)lds);
-    attr_done = true;
-  }
   const unsigned grid = a.tiles_m * a.tiles_n * a.B;
   QAMD_LAUNCH((gemmk_kernel<TA, TB, NS, MINW, DOT>), dim3(grid), dim3(256), lds, st, a, (const float*)A, (const float*)B,
               (float*)C, (const float*)sa, (const float*)sb, (float*)amax);
