@@ -171,6 +171,10 @@ static bool gemmk_config(const qamd_pair_plan* p, const PairDims& d, int64_t ali
   return tiles >= 96 || pin != 0;
 }
 
+// kernel 7 (gemmh.hip, defined beside its launcher below)
+static bool gemmh_config(const qamd_pair_plan* p, const PairDims& d, int pin, int& ta, int& tb);
+static int64_t gemmh_workspace_bytes(const qamd_pair_plan* p, const PairDims& d);
+
 // ---- gemmd.hip eligibility and tile choice (fp64, LDS-DMA ring, either operand layout) -----------------------------
 // An operand is FREE-contiguous (its innermost free group is stride-1: granules of two consecutive free elements) or
 // K-contiguous (its innermost K group is stride-1: granules of two consecutive k).  Either way the granule group has
@@ -298,10 +302,11 @@ extern "C" int qamd_pair_plan_finalize(qamd_pair_plan* p, int64_t align_a, int64
   if (rc) return rc;
   // the caller's explicit pins (the ONLY way to steer the choice: nothing below reads the environment):
   //   kernel  0 auto | -1 tiled GETT | -2 auto without the MFMA GEMM kernels | -5 / -6 gemmk / gemmd with the tile named by
-  //   tile_cfg = 16 ta + tb (where the kernel can run the shape at all; otherwise the automatic choice)
+  //   tile_cfg = 16 ta + tb (where the kernel can run the shape at all; otherwise the automatic choice) | -7 split products on
+  //   the f16 matrix pipe (gemmh.hip) for the fp32 GEMM-shaped joins large enough to pay for the split pass, auto elsewhere
   const int pin_kernel = p->kernel;
   int pin_gemm = 0;
-  if (pin_kernel == -5 || pin_kernel == -6) {
+  if (pin_kernel == -5 || pin_kernel == -6 || pin_kernel == -7) {
     if (p->tile_cfg > 0) pin_gemm = 10 * (p->tile_cfg / 16) + p->tile_cfg % 16;
     p->tile_cfg = -1;
     p->kernel = 0;
@@ -403,6 +408,13 @@ extern "C" int qamd_pair_plan_finalize(qamd_pair_plan* p, int64_t align_a, int64
     // kernel 5 (gemmk.hip): GEMM-shaped, both operands "k-outer" (free bundle stride-1), fp32
     if (p->kernel == 0 && kern == 0 && p->tile_cfg < 0 && pin_kernel != -2) {
       int ta = 0, tb = 0;
+      // kernel 7 (gemmh.hip): opt-in, the same shapes as kernel 5 with B == 1
+      if (pin_kernel == -7 && gemmh_config(p, d, pin_gemm, ta, tb)) {
+        p->kernel = 7;
+        p->tile_cfg = 16 * ta + tb;
+        p->split_k = 1;
+        return QAMD_OK;
+      }
       if (pin_kernel != -6 && gemmk_config(p, d, align_a, align_b, align_c, pin_kernel == -5 ? pin_gemm : 0, ta, tb)) {
         p->kernel = 5;
         p->tile_cfg = 16 * ta + tb;
@@ -509,6 +521,7 @@ static int64_t c_extent(const qamd_pair_plan* p) {
 extern "C" int64_t qamd_pair_workspace_bytes(const qamd_pair_plan* p) {
   PairDims d;
   if (pair_dims(p, d)) return -1;
+  if (p->kernel == 7) return gemmh_workspace_bytes(p, d);
   if (p->split_k <= 1) return 0;
   return (int64_t)p->split_k * d.B * d.M * d.N * kEsize[p->dtype];
 }
@@ -607,17 +620,10 @@ extern "C" int qamd_gemmk_dot_launch(int ta, int tb, const GettArgs* a, const vo
 extern "C" int qamd_gemmk_dot_finish(void* out, const void* partial, int n, const void* scale_a, const void* scale_b,
                                      const void* scale_t, void* absmax_out, void* stream);
 
-// dot_T != NULL: the result is not stored but multiplied with the tensor at dot_T (C's layout) and summed -- one double
-// per workgroup into dot_partial (qamd_contract_pair_dot); C is then only consulted for its alignment class (= dot_T's)
-static int launch_gemmk(const qamd_pair_plan* p, const PairDims& d, const void* A, const void* B, void* C,
-                        const qamd_epilogue* ep, void* stream, const void* dot_T = nullptr, void* dot_partial = nullptr,
-                        int* tiles_out = nullptr) {
-  if (dot_T) C = const_cast<void*>(dot_T);
-  const int ta = p->tile_cfg / 16, tb = p->tile_cfg % 16;
-  if (ta < 2 || ta > 4 || tb < 2 || tb > 4 || p->dtype != QAMD_F32 || p->nk != 1 || !A || !B || !C) return QAMD_EINVAL;
-  if (((uintptr_t)A & 15) || ((uintptr_t)B & 15)) return QAMD_EINVAL;
+// the kernel-role view of a GEMM-shaped plan (gemmk.hip / gemmh.hip): "m" = rows of the MFMA result, "n" = its lanes (C's
+// contiguous side); the operands swap roles when C's stride-1 index lives in the M bundle
+static void gemm_role_args(const qamd_pair_plan* p, const PairDims& d, int ta, int tb, const void* C, GettArgs& a) {
   const bool swap = !p->c_ncontig;
-  GettArgs a;
   memset(&a, 0, sizeof(a));
   a.nb = p->nb;
   for (int i = 0; i < p->nb; ++i) {
@@ -626,7 +632,6 @@ static int launch_gemmk(const qamd_pair_plan* p, const PairDims& d, const void* 
     a.sb_b[i] = swap ? p->sa_b[i] : p->sb_b[i];
     a.sc_b[i] = p->sc_b[i];
   }
-  // kernel roles: "m" = rows of the MFMA result, "n" = its lanes (C's contiguous side)
   const int nm = swap ? p->nn : p->nm, nn = swap ? p->nm : p->nn;
   const int64_t* dm = swap ? p->dim_n : p->dim_m;  const int64_t* dn = swap ? p->dim_m : p->dim_n;
   const int64_t* sam = swap ? p->sb_n : p->sa_m;   const int64_t* sbn = swap ? p->sa_m : p->sb_n;
@@ -652,11 +657,103 @@ static int launch_gemmk(const qamd_pair_plan* p, const PairDims& d, const void* 
     }
     a.vec_c = v;
   }
+}
+
+// dot_T != NULL: the result is not stored but multiplied with the tensor at dot_T (C's layout) and summed -- one double
+// per workgroup into dot_partial (qamd_contract_pair_dot); C is then only consulted for its alignment class (= dot_T's)
+static int launch_gemmk(const qamd_pair_plan* p, const PairDims& d, const void* A, const void* B, void* C,
+                        const qamd_epilogue* ep, void* stream, const void* dot_T = nullptr, void* dot_partial = nullptr,
+                        int* tiles_out = nullptr) {
+  if (dot_T) C = const_cast<void*>(dot_T);
+  const int ta = p->tile_cfg / 16, tb = p->tile_cfg % 16;
+  if (ta < 2 || ta > 4 || tb < 2 || tb > 4 || p->dtype != QAMD_F32 || p->nk != 1 || !A || !B || !C) return QAMD_EINVAL;
+  if (((uintptr_t)A & 15) || ((uintptr_t)B & 15)) return QAMD_EINVAL;
+  const bool swap = !p->c_ncontig;
+  GettArgs a;
+  gemm_role_args(p, d, ta, tb, C, a);
   if (tiles_out) *tiles_out = (int)(a.tiles_m * a.tiles_n * a.B);
   if (dot_T) return dot_partial ? qamd_gemmk_dot_launch(ta, tb, &a, swap ? B : A, swap ? A : B, dot_T, dot_partial, stream) : 0;
   const void* sa = ep ? (swap ? ep->scale_b : ep->scale_a) : nullptr;
   const void* sb = ep ? (swap ? ep->scale_a : ep->scale_b) : nullptr;
   return qamd_gemmk_launch(ta, tb, &a, swap ? B : A, swap ? A : B, C, sa, sb, ep ? ep->absmax_out : nullptr, stream);
+}
+
+// ---- kernel 7 (gemmh.hip): the same joins as split products on the f16 matrix pipe (opt-in: plan.kernel = -7 on input) --------
+// workspace: [0, 16) the two operands' (scale, 1 / scale) pairs, [256, 512) / [512, 768) absmax slots for operands that
+// bring none, [1024, ..) the kernel-role "m" operand's images, then the "n" operand's (each a multiple of 256 bytes)
+static const int kGemmhTiles[6][2] = {{4, 4}, {3, 4}, {4, 3}, {3, 3}, {2, 4}, {4, 2}};
+static int64_t gemmh_kpad(int64_t K) { return (K + 31) / 32 * 32; }
+
+static bool gemmh_config(const qamd_pair_plan* p, const PairDims& d, int pin, int& ta, int& tb) {
+  if (p->dtype != QAMD_F32 || p->nk != 1 || p->nb != 0 || d.B != 1 || p->a_kcontig || p->b_kcontig) return false;
+  if (p->nm < 1 || p->nn < 1 || p->sa_m[p->nm - 1] != 1 || p->sb_n[p->nn - 1] != 1) return false;
+  if (p->sa_k[0] <= 0 || p->sb_k[0] <= 0) return false;
+  // (worth two extra passes over the operands only where the product dominates them; a pinned tile waives the floors down
+  // to what the kernel needs: two 32-k stages)
+  if (d.M >= (1ll << 31) || d.N >= (1ll << 31) || d.K >= (1ll << 31) || d.K < 33) return false;
+  if (!pin && (d.K < 256 || d.M < 256 || d.N < 256)) return false;
+  const bool swap = !p->c_ncontig;
+  const int64_t M = swap ? d.N : d.M, N = swap ? d.M : d.N;
+  double best = 0;
+  ta = tb = 0;
+  for (const auto& t : kGemmhTiles) {
+    if (pin && pin != 10 * t[0] + t[1]) continue;
+    const int64_t tiles = ((M + 64 * t[0] - 1) / (64 * t[0])) * ((N + 64 * t[1] - 1) / (64 * t[1]));
+    // rounds of one tile per CU (one workgroup per CU: 130 KB of LDS); the larger tile re-reads less
+    const double cost = (double)((tiles + kNumCU - 1) / kNumCU) * t[0] * t[1] * (1.0 + 0.02 * (16 - t[0] * t[1]) / 16.0);
+    if (!ta || cost < best) { best = cost; ta = t[0]; tb = t[1]; }
+  }
+  return ta != 0;
+}
+
+static int64_t gemmh_workspace_bytes(const qamd_pair_plan* p, const PairDims& d) {
+  const int ta = p->tile_cfg / 16, tb = p->tile_cfg % 16;
+  const bool swap = !p->c_ncontig;
+  const int64_t M = swap ? d.N : d.M, N = swap ? d.M : d.N;
+  const int64_t mpad = (M + 64 * ta - 1) / (64 * ta) * (64 * ta), npad = (N + 64 * tb - 1) / (64 * tb) * (64 * tb);
+  return 1024 + qamd_gemmh_image_bytes(mpad, gemmh_kpad(d.K)) + qamd_gemmh_image_bytes(npad, gemmh_kpad(d.K));
+}
+
+static int launch_gemmh(const qamd_pair_plan* p, const PairDims& d, const void* A, const void* B, void* C, void* ws,
+                        int64_t ws_bytes, const qamd_epilogue* ep, void* stream, const void* dot_T = nullptr,
+                        void* dot_partial = nullptr, int* tiles_out = nullptr) {
+  if (dot_T) C = const_cast<void*>(dot_T);
+  const int ta = p->tile_cfg / 16, tb = p->tile_cfg % 16;
+  if (ta < 2 || ta > 4 || tb < 2 || tb > 4 || p->dtype != QAMD_F32 || p->nk != 1 || p->nb != 0 || !A || !B || !C) return QAMD_EINVAL;
+  if (!ws || ws_bytes < gemmh_workspace_bytes(p, d) || ((uintptr_t)ws & 15)) return QAMD_EWORKSPACE;
+  const bool swap = !p->c_ncontig;
+  GettArgs a;
+  gemm_role_args(p, d, ta, tb, C, a);
+  a.Kloop = (uint32_t)gemmh_kpad(d.K);
+  if (tiles_out) *tiles_out = (int)(a.tiles_m * a.tiles_n);
+  SplitArgs sm, sn;
+  memset(&sm, 0, sizeof(sm));
+  memset(&sn, 0, sizeof(sn));
+  sm.ng = a.nm; sn.ng = a.nn;
+  for (int i = 0; i < a.nm; ++i) { sm.dim[i] = a.dim_m[i]; sm.stride[i] = a.sa_m[i]; }
+  for (int i = 0; i < a.nn; ++i) { sn.dim[i] = a.dim_n[i]; sn.stride[i] = a.sb_n[i]; }
+  sm.sk = a.sa_k0; sn.sk = a.sb_k0;
+  sm.X = a.M; sm.Xpad = a.tiles_m * 64 * ta; sn.X = a.N; sn.Xpad = a.tiles_n * 64 * tb;
+  sm.K = sn.K = a.K; sm.KG = sn.KG = a.Kloop / 8;
+  char* w = (char*)ws;
+  float* hdr_m = (float*)w;
+  float* hdr_n = hdr_m + 2;
+  char* img_m = w + 1024;
+  char* img_n = img_m + qamd_gemmh_image_bytes(sm.Xpad, a.Kloop);
+  const void* Am = swap ? B : A;
+  const void* Bn = swap ? A : B;
+  const void* slots_m = ep ? (swap ? ep->scale_b : ep->scale_a) : nullptr;
+  const void* slots_n = ep ? (swap ? ep->scale_a : ep->scale_b) : nullptr;
+  int rc;
+  // an operand without exponent slots (a plain tensordot): its absmax is taken here, but the result is then NOT divided by it
+  const void* split_m = slots_m;
+  const void* split_n = slots_n;
+  if (!split_m) { if ((rc = qamd_gemmh_absmax_launch(&sm, Am, w + 256, stream))) return rc; split_m = w + 256; }
+  if (!split_n) { if ((rc = qamd_gemmh_absmax_launch(&sn, Bn, w + 512, stream))) return rc; split_n = w + 512; }
+  if ((rc = qamd_gemmh_split_launch(&sm, Am, split_m, hdr_m, img_m, stream))) return rc;
+  if ((rc = qamd_gemmh_split_launch(&sn, Bn, split_n, hdr_n, img_n, stream))) return rc;
+  if (dot_T) return dot_partial ? qamd_gemmh_dot_launch(ta, tb, &a, img_m, img_n, dot_T, hdr_m, hdr_n, dot_partial, stream) : 0;
+  return qamd_gemmh_launch(ta, tb, &a, img_m, img_n, C, slots_m, slots_n, hdr_m, hdr_n, ep ? ep->absmax_out : nullptr, stream);
 }
 
 extern "C" int qamd_gemmd_launch(int ta, int tb, const GettArgs* a, int swap, const void* A, const void* B, void* C,
@@ -709,10 +806,7 @@ static int launch_gemmd(const qamd_pair_plan* p, const PairDims& d, const void* 
 }
 
 // ---- a join consumed by one inner product (the closing step of a two-sided / four-quadrant contraction) -------------
-extern "C" int64_t qamd_pair_dot_workspace_bytes(const qamd_pair_plan* p) {
-  if (!p || p->kernel != 5) return 0;
-  PairDims d;
-  if (pair_dims(p, d)) return 0;
+static int64_t dot_partial_bytes(const qamd_pair_plan* p, const PairDims& d) {
   const int ta = p->tile_cfg / 16, tb = p->tile_cfg % 16;
   if (ta < 2 || ta > 4 || tb < 2 || tb > 4) return 0;
   const bool swap = !p->c_ncontig;
@@ -720,11 +814,21 @@ extern "C" int64_t qamd_pair_dot_workspace_bytes(const qamd_pair_plan* p) {
   return (int64_t)sizeof(double) * d.B * ((M + 64 * ta - 1) / (64 * ta)) * ((N + 64 * tb - 1) / (64 * tb));
 }
 
+// kernel 7: the partial sums (rounded up to 256 bytes) are followed by the split product's own workspace
+extern "C" int64_t qamd_pair_dot_workspace_bytes(const qamd_pair_plan* p) {
+  if (!p || (p->kernel != 5 && p->kernel != 7)) return 0;
+  PairDims d;
+  if (pair_dims(p, d)) return 0;
+  const int64_t part = dot_partial_bytes(p, d);
+  if (part <= 0 || p->kernel == 5) return part;
+  return (part + 255) / 256 * 256 + gemmh_workspace_bytes(p, d);
+}
+
 extern "C" int qamd_contract_pair_dot(const qamd_pair_plan* p, const void* A, const void* B, const void* T, void* out_dev,
                                       void* ws, int64_t ws_bytes, const qamd_epilogue* ep, const void* scale_t,
                                       void* stream) {
   if (!p || !A || !B || !T || !out_dev) return QAMD_EINVAL;
-  if (p->kernel != 5 || p->dtype != QAMD_F32) return QAMD_EUNSUPPORTED;
+  if ((p->kernel != 5 && p->kernel != 7) || p->dtype != QAMD_F32) return QAMD_EUNSUPPORTED;
   if (qamdp_recording()) return qamdp_rec_pair_dot(p, A, B, T, out_dev, ws, ws_bytes, ep, scale_t);
   PairDims d;
   int rc = pair_dims(p, d);
@@ -733,7 +837,12 @@ extern "C" int qamd_contract_pair_dot(const qamd_pair_plan* p, const void* A, co
   if (need <= 0) return QAMD_EINVAL;
   if (!ws || ws_bytes < need) return QAMD_EWORKSPACE;
   int tiles = 0;
-  rc = launch_gemmk(p, d, A, B, nullptr, nullptr, stream, T, ws, &tiles);
+  if (p->kernel == 7) {
+    const int64_t part = (dot_partial_bytes(p, d) + 255) / 256 * 256;
+    rc = launch_gemmh(p, d, A, B, nullptr, (char*)ws + part, ws_bytes - part, ep, stream, T, ws, &tiles);
+  } else {
+    rc = launch_gemmk(p, d, A, B, nullptr, nullptr, stream, T, ws, &tiles);
+  }
   if (rc) return rc;
   return qamd_gemmk_dot_finish(out_dev, ws, tiles, ep ? ep->scale_a : nullptr, ep ? ep->scale_b : nullptr, scale_t,
                                ep ? ep->absmax_out : nullptr, stream);
@@ -748,6 +857,7 @@ extern "C" int qamd_contract_pair_ex(const qamd_pair_plan* p, const void* A, con
   if (rc) return rc;
   if (p->dtype != QAMD_F32 && p->dtype != QAMD_F64) return QAMD_EUNSUPPORTED;
   if (p->kernel == 5) return launch_gemmk(p, d, A, B, C, ep, stream);
+  if (p->kernel == 7) return launch_gemmh(p, d, A, B, C, ws, ws_bytes, ep, stream);
   if (p->kernel == 6) return launch_gemmd(p, d, A, B, C, ktab, ws, ws_bytes, ep, stream);
   if (p->tile_cfg < 0 || p->tile_cfg >= kNumTileCfg || p->split_k < 1) return QAMD_EINVAL;
   if (!A || !B || !C || !ktab) return QAMD_EINVAL;
@@ -1092,6 +1202,10 @@ extern "C" int qamd_pair_describe(const qamd_pair_plan* p, char* buf, int32_t bu
     const int ta = p->tile_cfg / 16, tb = p->tile_cfg % 16;
     const bool two = ta * tb == 12 || ta * tb == 9;   // (gemmk.hip, QAMD_GEMMK_CASES: two-stage ring, two workgroups per CU)
     snprintf(buf, buflen, "gemmk_kernel<%d, %d, %d, %d>", ta, tb, two ? 2 : 3, (two || ta * tb <= 6) ? 2 : 1);
+    return QAMD_OK;
+  }
+  if (p->kernel == 7) {
+    snprintf(buf, buflen, "gemmh_kernel<%d, %d> f16x3", p->tile_cfg / 16, p->tile_cfg % 16);
     return QAMD_OK;
   }
   if (p->kernel == 6) {

@@ -1,0 +1,411 @@
+// gemmh.hip -- the fp32 GEMM-shaped joins on the f16 matrix pipe: split products ("f16x3"), gfx950 only.  OPT-IN
+// (qamd_pair_plan.kernel = -7 on input; quimb_amd.Options.join_arith = "f16x3"): the default stays gemmk.hip on the fp32 MFMA.
+//
+//   C[m, n] = alpha * sum_k A[k, m] * B[k, n]                       (operands fp32, k-outer, as gemmk.hip takes them)
+//
+// An fp32 value x, scaled by a power of two so that the operand's largest magnitude sits in [2^14, 2^15), is written as
+//   x = h1 + h2 + e,   h1 = fp16(x), h2 = fp16(x - h1),   |e| <= 2^-24 |x|   (two round-to-nearest steps of 11 bits each,
+// the residual x - h1 is exact in fp32), for every |x| >= 2^-18 of the operand's maximum; smaller entries lose relative
+// but not absolute accuracy (absolute error <= 2^-25 * 2^-15 of the maximum).  Then
+//   a * b = a1 b1 + a1 b2 + a2 b1   - dropped: a2 b2 <= 2^-24 |a b| -
+// and every one of the three products is EXACT in the fp32 accumulator's input (11 x 11 bits): three passes of
+// v_mfma_f32_32x32x16_f16 (2.5 PFLOP/s dense: 16 x the fp32 MFMA rate) with fp32 accumulation give a result whose error is
+// the fp32 accumulation error plus <= 3 * 2^-24 per term -- measured against fp64 on the operands of the 10x10 D=6 joins it is
+// indistinguishable from the fp32 MFMA kernel's (tests/checks.py check_gemmh).  No bf16 (8 bits: six
+// products for the same accuracy), no TF32-like truncation.
+//
+//  * split_kernel: ONE pass over an operand (any strides the fp32 kernels accept): scale from the tensor's absmax slots,
+//    both halves written as tile-ready images  P[half][k / 8][x][8 k]  (16 bytes per (k-group, x); x padded with zeros to
+//    whole workgroup tiles, K to a multiple of 32): a 1 KiB LDS-DMA piece is 64 consecutive x of one k-group, and a
+//    32x32x16 fragment read (lane = x, 8 consecutive k per half wave) is one conflict-free ds_read_b128.
+//  * gemmh_kernel: gemmk.hip's recipe on the f16 instruction: 2 x 2 waves, wave tile (32 TA) x (32 TB), operands
+//    HBM/L2 -> LDS by LDS-DMA only, a two-stage ring of 32-k stages (64 KB each at 256 x 256), ONE barrier per stage at its
+//    last k-step, the next step's fragments read behind the first MFMA of the current one, the request for stage t + 2
+//    one piece behind each MFMA after the barrier.  Per 16-k step a wave reads 2 (TA + TB) fragments and issues
+//    3 TA TB MFMAs (a1 b2, a2 b1, a1 b1 -- small terms first).
+//  * epilogue as gemmk.hip's: alpha * 2^-(ea + eb), absmax slot, or (DOT) the closing inner product with T.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "gett_args.h"
+
+#define QAMD_LAUNCH(...) do { (void)hipGetLastError(); hipLaunchKernelGGL(__VA_ARGS__); } while (0)
+
+namespace qamdh {
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef float acc16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ int64_t hdecomp(uint32_t idx, int n, const uint32_t* dims, const int64_t* strides) {
+  int64_t off = 0;
+  for (int g = n - 1; g >= 0; --g) {
+    uint32_t d = dims[g];
+    uint32_t q = idx / d, r = idx - q * d;
+    off += (int64_t)r * strides[g];
+    idx = q;
+  }
+  return off;
+}
+
+// max over a tensor's 64 absmax slots (one per lane, wave reduction)
+__device__ __forceinline__ float hread_scale(const float* slots, int lane) {
+  static_assert(QAMD_SLOTS == 64, "one slot per lane");
+  if (!slots) return 1.f;
+  float m = slots[lane];
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) m = fmaxf(m, __shfl_xor(m, d, 64));
+  return m > 0.f ? m : 1.f;
+}
+
+__device__ __forceinline__ void hglds(const char* src, char* dst) {
+  __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+}
+
+// ---- absmax of a strided fp32 operand into 64 slots (only when the caller has none: plain tensordot without exponents) --------
+__global__ __launch_bounds__(256) void habsmax_kernel(const SplitArgs p, const float* __restrict__ X, float* __restrict__ slots) {
+  const uint32_t x = blockIdx.x * 256 + threadIdx.x;
+  float m = 0.f;
+  if (x < p.X) {
+    const int64_t off = hdecomp(x, p.ng, p.dim, p.stride);
+    for (uint32_t k = blockIdx.y; k < p.K; k += gridDim.y) m = fmaxf(m, fabsf(X[(int64_t)k * p.sk + off]));
+  }
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) m = fmaxf(m, __shfl_xor(m, d, 64));
+  if ((threadIdx.x & 63) == 0)
+    atomicMax(reinterpret_cast<unsigned int*>(slots) + ((blockIdx.x * 4 + (threadIdx.x >> 6) + blockIdx.y) % QAMD_SLOTS), __float_as_uint(m));
+}
+
+// ---- the split pass ---------------------------------------------------------------------------------------------------------
+// hdr[0] = the power of two the operand was multiplied by, hdr[1] = its inverse.  Grid (ceil(Xpad / 256), k-group chunks).
+__global__ __launch_bounds__(256) void split_kernel(const SplitArgs p, const float* __restrict__ X, const float* __restrict__ slots,
+                                                    float* __restrict__ hdr, h8* __restrict__ P) {
+  const int lane = threadIdx.x & 63;
+  const float m = hread_scale(slots, lane);
+  int q = 0;
+  (void)frexpf(m, &q);                                 // m = f 2^q, f in [0.5, 1)  ->  m 2^(15 - q) in [2^14, 2^15)
+  const bool fin = m > 0.f && m < 3.0e38f;
+  const float scale = fin ? ldexpf(1.f, 15 - q) : 1.f;
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+    hdr[0] = scale;
+    hdr[1] = fin ? ldexpf(1.f, q - 15) : 1.f;
+  }
+  const uint32_t x = blockIdx.x * 256 + threadIdx.x;
+  if (x >= p.Xpad) return;
+  const bool valid = x < p.X;
+  const float* src = X + (valid ? hdecomp(x, p.ng, p.dim, p.stride) : 0);
+  const uint32_t per = (p.KG + gridDim.y - 1) / gridDim.y;
+  const uint32_t kg0 = blockIdx.y * per, kg1 = (kg0 + per < p.KG) ? kg0 + per : p.KG;
+  h8* P1 = P + x;
+  h8* P2 = P + (int64_t)p.KG * p.Xpad + x;
+#pragma unroll 2
+  for (uint32_t kg = kg0; kg < kg1; ++kg) {
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const uint32_t k = 8 * kg + j;
+      v[j] = (valid && k < p.K) ? src[(int64_t)k * p.sk] * scale : 0.f;
+    }
+    h8 a, b;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const _Float16 h = (_Float16)v[j];
+      a[j] = h;
+      b[j] = (_Float16)(v[j] - (float)h);
+    }
+    P1[(int64_t)kg * p.Xpad] = a;
+    P2[(int64_t)kg * p.Xpad] = b;
+  }
+}
+
+// ---- the product --------------------------------------------------------------------------------------------------------------
+// p.tiles_m / tiles_n: the tile grid (the images are padded to it), p.Kloop: K rounded up to 32 (the images' k extent),
+// p.M / p.N: the valid extents (epilogue), C addressed through p.dim_m / sc_m / dim_n / sc_n as in gemmk.hip.
+template <int TA, int TB, bool DOT>
+__global__ __launch_bounds__(256, 1) void gemmh_kernel(const GettArgs p, const char* __restrict__ PA, const char* __restrict__ PB,
+                                                       float* __restrict__ C, const float* __restrict__ scale_a,
+                                                       const float* __restrict__ scale_b, const float* __restrict__ hdrA,
+                                                       const float* __restrict__ hdrB, float* __restrict__ absmax_out) {
+  constexpr int BM = 64 * TA, BN = 64 * TB;
+  constexpr int SA = 2 * 4 * BM * 16, SB = 2 * 4 * BN * 16, STAGE = SA + SB;   // bytes: [half][4 k-groups][x][16]
+  constexpr int NP = 2 * TA + 2 * TB;                                           // LDS-DMA pieces per wave and stage
+  extern __shared__ __attribute__((aligned(16))) char hsmem[];
+  char* stages = hsmem;
+  int64_t* offCm = reinterpret_cast<int64_t*>(hsmem + 2 * STAGE);
+  int64_t* offCn = offCm + BM;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+
+  // ---- tile coordinates: each XCD a contiguous run of the tile sequence, bands of 4 tile rows (as gemmk.hip) ----------------
+  const uint32_t per_batch = p.tiles_m * p.tiles_n;
+  const uint32_t pid = blockIdx.x;
+  uint32_t tm, tn;
+  {
+    const uint32_t xcd = pid & 7, idx = pid >> 3;
+    const uint32_t q = per_batch >> 3, r = per_batch & 7;
+    const uint32_t s = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    const uint32_t band = 4 * p.tiles_n;
+    const uint32_t first_m = (s / band) * 4;
+    const uint32_t gsz = (p.tiles_m - first_m) < 4 ? (p.tiles_m - first_m) : 4;
+    const uint32_t in_band = s % band;
+    tm = first_m + in_band % gsz;
+    tn = in_band / gsz;
+  }
+  const uint32_t m0 = tm * BM, n0 = tn * BN;
+  for (int i = tid; i < BM + BN; i += 256) {
+    if (i < BM) {
+      uint32_t g = m0 + i;
+      offCm[i] = hdecomp(g < p.M ? g : p.M - 1, p.nm, p.dim_m, p.sc_m);
+    } else {
+      uint32_t g = n0 + (i - BM);
+      offCn[i - BM] = hdecomp(g < p.N ? g : p.N - 1, p.nn, p.dim_n, p.sc_n);
+    }
+  }
+
+  // ---- LDS-DMA sources: wave w always fetches k-group w of a stage; piece (c, half): 64 rows x 16 bytes -----------------------
+  const int64_t Mpad = (int64_t)p.tiles_m * BM, Npad = (int64_t)p.tiles_n * BN;
+  const int64_t KG = p.Kloop >> 3;
+  const int64_t halfA = KG * Mpad * 16, halfB = KG * Npad * 16;
+  const int64_t stepA = 4 * Mpad * 16, stepB = 4 * Npad * 16;
+  const char* baseA = PA + ((int64_t)wave * Mpad + m0) * 16;
+  const char* baseB = PB + ((int64_t)wave * Npad + n0) * 16;
+  const uint32_t lane16 = 16u * lane;
+  const int ntiles = (int)(KG >> 2);
+
+  // piece q of a wave's NP: q < 2 TA: A piece (c = q / 2, half = q % 2), else B piece likewise
+#define QH_PIECE(q_, st_)                                                                                            \
+  do {                                                                                                               \
+    if ((q_) < 2 * TA) {                                                                                             \
+      constexpr int c_ = ((q_) < 2 * TA ? (q_) : 0) / 2, h_ = (q_) % 2;                                              \
+      hglds(baseA + (h_ ? halfA : 0) + c_ * 1024 + lane16, stages + (st_) * STAGE + ((h_ * 4 + wave) * BM + 64 * c_) * 16); \
+    } else {                                                                                                         \
+      constexpr int c_ = ((q_) < 2 * TA ? 0 : (q_) - 2 * TA) / 2, h_ = (q_) % 2;                                     \
+      hglds(baseB + (h_ ? halfB : 0) + c_ * 1024 + lane16, stages + (st_) * STAGE + SA + ((h_ * 4 + wave) * BN + 64 * c_) * 16); \
+    }                                                                                                                \
+  } while (0)
+
+  acc16 acc[TA][TB];
+#pragma unroll
+  for (int i = 0; i < TA; ++i)
+#pragma unroll
+    for (int j = 0; j < TB; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+  const int l31 = lane & 31, kh = lane >> 5;
+  const int aoff = (kh * BM + wm * (32 * TA) + l31) * 16;
+  const int boff = SA + (kh * BN + wn * (32 * TB) + l31) * 16;
+
+  h8 fa[2][2][TA], fb[2][2][TB];     // [buffer][half][sub-tile]
+  // fragments of 16-k step j_ of stage st_ into buffer b_
+#define QH_FRAGS(b_, st_, j_)                                                                                        \
+  do {                                                                                                               \
+    const char* As_ = stages + (st_) * STAGE + aoff + (j_) * (2 * BM * 16);                                          \
+    const char* Bs_ = stages + (st_) * STAGE + boff + (j_) * (2 * BN * 16);                                          \
+    _Pragma("unroll") for (int h = 0; h < 2; ++h) {                                                                  \
+      _Pragma("unroll") for (int i = 0; i < TA; ++i) fa[b_][h][i] = *reinterpret_cast<const h8*>(As_ + h * (4 * BM * 16) + i * 512); \
+      _Pragma("unroll") for (int j = 0; j < TB; ++j) fb[b_][h][j] = *reinterpret_cast<const h8*>(Bs_ + h * (4 * BN * 16) + j * 512); \
+    }                                                                                                                \
+  } while (0)
+
+  // ---- prologue: stages 0 and 1 requested, stage 0 awaited ------------------------------------------------------------------
+#define QH_ISSUE_ALL(st_)                                                                                            \
+  do {                                                                                                               \
+    QH_PIECE(0, st_); QH_PIECE(1, st_); QH_PIECE(2, st_); QH_PIECE(3, st_);                                          \
+    if (NP > 4) { QH_PIECE(4, st_); QH_PIECE(5, st_); }                                                              \
+    if (NP > 6) { QH_PIECE(6, st_); QH_PIECE(7, st_); }                                                              \
+    if (NP > 8) { QH_PIECE(8, st_); QH_PIECE(9, st_); }                                                              \
+    if (NP > 10) { QH_PIECE(10, st_); QH_PIECE(11, st_); }                                                           \
+    if (NP > 12) { QH_PIECE(12, st_); QH_PIECE(13, st_); }                                                           \
+    if (NP > 14) { QH_PIECE(14, st_); QH_PIECE(15, st_); }                                                           \
+  } while (0)
+  QH_ISSUE_ALL(0);
+  baseA += stepA;     // (the launcher guarantees >= 2 stages)
+  baseB += stepB;
+  QH_ISSUE_ALL(1);
+  baseA += (2 < ntiles) ? stepA : 0;
+  baseB += (2 < ntiles) ? stepB : 0;
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NP) : "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  QH_FRAGS(0, 0, 0);
+
+  // one 16-k step on buffer b_: the first MFMA, then the reads of the NEXT step's fragments (RD_), then the rest; in the
+  // stage's last step (SYNC_) the barrier first and the request for stage t + 2 one piece behind each MFMA
+#define QH_MFMA(i_, j_, ha_, hb_, b_) \
+  acc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[b_][ha_][i_], fb[b_][hb_][j_], acc[i_][j_], 0, 0, 0)
+#define QH_STEP(b_, SYNC_, RD_)                                                                                      \
+  do {                                                                                                               \
+    if (SYNC_) {                                                                                                     \
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                                    \
+      __builtin_amdgcn_s_barrier();                                                                                  \
+      asm volatile("" ::: "memory");                                                                                 \
+    }                                                                                                                \
+    __builtin_amdgcn_sched_barrier(0);                                                                               \
+    QH_MFMA(0, 0, 0, 1, b_);                                                                                         \
+    __builtin_amdgcn_sched_barrier(0);                                                                               \
+    RD_;                                                                                                             \
+    __builtin_amdgcn_sched_barrier(0);                                                                               \
+    _Pragma("unroll") for (int pr = 0; pr < 3; ++pr)                                                                 \
+      _Pragma("unroll") for (int i = 0; i < TA; ++i) _Pragma("unroll") for (int j = 0; j < TB; ++j) {                \
+        const int n_ = (pr * TA + i) * TB + j;                                                                       \
+        if (n_ > 0) {                                                                                                \
+          if (pr == 0) QH_MFMA(i, j, 0, 1, b_);                                                                      \
+          else if (pr == 1) QH_MFMA(i, j, 1, 0, b_);                                                                 \
+          else QH_MFMA(i, j, 0, 0, b_);                                                                              \
+          if (SYNC_ && n_ - 1 < NP) {                                                                                \
+            __builtin_amdgcn_sched_barrier(0);                                                                       \
+            switch (n_ - 1) {                                                                                        \
+              case 0: QH_PIECE(0, st); break;   case 1: QH_PIECE(1, st); break;                                      \
+              case 2: QH_PIECE(2, st); break;   case 3: QH_PIECE(3, st); break;                                      \
+              case 4: QH_PIECE(4, st); break;   case 5: QH_PIECE(5, st); break;                                      \
+              case 6: QH_PIECE(6, st); break;   case 7: QH_PIECE(7, st); break;                                      \
+              case 8: QH_PIECE(8, st); break;   case 9: QH_PIECE(9, st); break;                                      \
+              case 10: QH_PIECE(10, st); break; case 11: QH_PIECE(11, st); break;                                    \
+              case 12: QH_PIECE(12, st); break; case 13: QH_PIECE(13, st); break;                                    \
+              case 14: QH_PIECE(14, st); break; default: QH_PIECE(15, st); break;                                    \
+            }                                                                                                        \
+            __builtin_amdgcn_sched_barrier(0);                                                                       \
+          }                                                                                                          \
+        }                                                                                                            \
+      }                                                                                                              \
+    __builtin_amdgcn_sched_barrier(0);                                                                               \
+  } while (0)
+
+  int st = 0;
+  for (int t = 0; t < ntiles; ++t) {
+    const int stn = st ^ 1;
+    QH_STEP(0, false, QH_FRAGS(1, st, 1));
+    QH_STEP(1, true, QH_FRAGS(0, stn, 0));
+    // the base never leaves the last stage: past it the request re-reads those rows (a stage nobody reads again)
+    baseA += (t + 3 < ntiles) ? stepA : 0;
+    baseB += (t + 3 < ntiles) ? stepB : 0;
+    st = stn;
+  }
+#undef QH_STEP
+#undef QH_MFMA
+#undef QH_FRAGS
+#undef QH_ISSUE_ALL
+#undef QH_PIECE
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+  // ---- epilogue: acc[i][j][r] = C[wm 32 TA + 32 i + (r & 3) + 8 (r >> 2) + 4 kh][wn 32 TB + 32 j + l31] -----------------------
+  const float unscale = hdrA[1] * hdrB[1];
+  if constexpr (DOT) {
+    __shared__ double dred[4];
+    float dsum = 0.0f;
+#pragma unroll
+    for (int i = 0; i < TA; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int ml = wm * (32 * TA) + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * kh;
+        if (m0 + ml >= p.M) continue;
+        const int64_t orow = offCm[ml];
+#pragma unroll
+        for (int j = 0; j < TB; ++j) {
+          const int nl = wn * (32 * TB) + 32 * j + l31;
+          if (n0 + nl < p.N) dsum += acc[i][j][r] * C[orow + offCn[nl]];
+        }
+      }
+    }
+    double ds = (double)dsum;
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) ds += __shfl_down(ds, d, 64);
+    if (lane == 0) dred[wave] = ds;
+    __syncthreads();
+    if (tid == 0) reinterpret_cast<double*>(absmax_out)[blockIdx.x] = ((dred[0] + dred[1]) + (dred[2] + dred[3])) * (double)unscale;
+    return;
+  }
+  const float alpha = unscale / (hread_scale(scale_a, lane) * hread_scale(scale_b, lane));
+  float vmax = 0.0f;
+#pragma unroll
+  for (int i = 0; i < TA; ++i) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int ml = wm * (32 * TA) + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * kh;
+      if (m0 + ml >= p.M) continue;
+      const int64_t orow = offCm[ml];
+#pragma unroll
+      for (int j = 0; j < TB; ++j) {
+        const int nl = wn * (32 * TB) + 32 * j + l31;
+        if (n0 + nl < p.N) {
+          const float v = acc[i][j][r] * alpha;
+          C[orow + offCn[nl]] = v;
+          vmax = fmaxf(vmax, fabsf(v));
+        }
+      }
+    }
+  }
+  if (absmax_out) {
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) vmax = fmaxf(vmax, __shfl_down(vmax, d, 64));
+    if (lane == 0) atomicMax(reinterpret_cast<unsigned int*>(absmax_out + ((blockIdx.x * 4 + wave) % QAMD_SLOTS)), __float_as_uint(vmax));
+  }
+}
+
+template <int TA, int TB, bool DOT>
+static int launch_one(const GettArgs& a, const void* PA, const void* PB, void* C, const void* sa, const void* sb, const void* hdrA,
+                      const void* hdrB, void* amax, hipStream_t st) {
+  constexpr int BM = 64 * TA, BN = 64 * TB;
+  const size_t lds = (size_t)2 * 128 * (BM + BN) + (size_t)(BM + BN) * sizeof(int64_t);
+  (void)hipFuncSetAttribute((const void*)gemmh_kernel<TA, TB, DOT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  const unsigned grid = a.tiles_m * a.tiles_n;
+  QAMD_LAUNCH((gemmh_kernel<TA, TB, DOT>), dim3(grid), dim3(256), lds, st, a, (const char*)PA, (const char*)PB, (float*)C,
+              (const float*)sa, (const float*)sb, (const float*)hdrA, (const float*)hdrB, (float*)amax);
+  return hipGetLastError() == hipSuccess ? 0 : -4;
+}
+
+}  // namespace qamdh
+
+using namespace qamdh;
+
+#define QAMD_GEMMH_CASES QH_CASE(4, 4) QH_CASE(3, 4) QH_CASE(4, 3) QH_CASE(3, 3) QH_CASE(2, 4) QH_CASE(4, 2)
+
+// bytes of one operand's split images for free extent padded to ``xpad`` and K padded to ``kpad`` (a multiple of 32)
+extern "C" int64_t qamd_gemmh_image_bytes(int64_t xpad, int64_t kpad) { return 2 * (kpad / 8) * xpad * 16; }
+
+// absmax of a strided operand into 64 zeroed slots (callers without exponent slots)
+extern "C" int qamd_gemmh_absmax_launch(const SplitArgs* a, const void* X, void* slots, void* stream) {
+  if (!a || !X || !slots) return -2;
+  if (hipMemsetAsync(slots, 0, QAMD_SLOTS * sizeof(float), (hipStream_t)stream) != hipSuccess) return -4;
+  const unsigned gy = a->K < 64 ? a->K : 64;
+  QAMD_LAUNCH(habsmax_kernel, dim3((a->X + 255) / 256, gy), dim3(256), 0, (hipStream_t)stream, *a, (const float*)X, (float*)slots);
+  return hipGetLastError() == hipSuccess ? 0 : -4;
+}
+
+// X (fp32, free bundle a->dim / a->stride, k stride a->sk) -> P[2][a->KG][a->Xpad][8] f16, hdr[0 .. 1] = scale, 1 / scale
+extern "C" int qamd_gemmh_split_launch(const SplitArgs* a, const void* X, const void* slots, void* hdr, void* P, void* stream) {
+  if (!a || !X || !hdr || !P || a->KG == 0 || a->KG % 4 || a->Xpad < a->X || ((uintptr_t)P & 15)) return -2;
+  const unsigned gx = (a->Xpad + 255) / 256;
+  unsigned gy = (8192 + gx - 1) / gx;                 // ~8 K workgroups, at least two k-groups each
+  if (gy > a->KG / 2) gy = a->KG / 2;
+  if (gy < 1) gy = 1;
+  QAMD_LAUNCH(split_kernel, dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, *a, (const float*)X, (const float*)slots, (float*)hdr,
+              (h8*)P);
+  return hipGetLastError() == hipSuccess ? 0 : -4;
+}
+
+// a->tiles_m / tiles_n = ceil(M / 64 ta), ceil(N / 64 tb); a->Kloop = K rounded up to 32 (>= 64); the images padded to both
+extern "C" int qamd_gemmh_launch(int ta, int tb, const GettArgs* a, const void* PA, const void* PB, void* C, const void* scale_a,
+                                 const void* scale_b, const void* hdrA, const void* hdrB, void* absmax_out, void* stream) {
+  if (!a || a->Kloop < 64 || a->Kloop % 32 || a->B != 1 || !hdrA || !hdrB) return -2;
+#define QH_CASE(TA_, TB_) \
+  if (ta == TA_ && tb == TB_) return launch_one<TA_, TB_, false>(*a, PA, PB, C, scale_a, scale_b, hdrA, hdrB, absmax_out, (hipStream_t)stream);
+  QAMD_GEMMH_CASES
+#undef QH_CASE
+  return -2;
+}
+
+// the product consumed by one inner product with T (C's layout): partial[0 .. tiles) one double per workgroup, finished by
+// qamd_gemmk_dot_finish (gemmk.hip)
+extern "C" int qamd_gemmh_dot_launch(int ta, int tb, const GettArgs* a, const void* PA, const void* PB, const void* T,
+                                     const void* hdrA, const void* hdrB, void* partial, void* stream) {
+  if (!a || a->Kloop < 64 || a->Kloop % 32 || a->B != 1 || !hdrA || !hdrB) return -2;
+#define QH_CASE(TA_, TB_)     \
+  if (ta == TA_ && tb == TB_) \
+    return launch_one<TA_, TB_, true>(*a, PA, PB, const_cast<void*>(T), nullptr, nullptr, hdrA, hdrB, partial, (hipStream_t)stream);
+  QAMD_GEMMH_CASES
+#undef QH_CASE
+  return -2;
+}

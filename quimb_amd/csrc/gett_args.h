@@ -83,6 +83,16 @@ struct RowArgs {
   uint32_t ed[5], eh;      // rowq.hip: extents (<= 6) of the new down legs d1..d5 and of the open leg h
 };
 
+// one operand of a split-product join (gemmh.hip): the fp32 source's free bundle and k stride, the image's padded extents
+struct SplitArgs {
+  int32_t ng, pad_;
+  uint32_t dim[QAMD_G];
+  int64_t stride[QAMD_G];
+  int64_t sk;            // element stride of k in the source
+  uint32_t X, Xpad;      // free extent, and padded to whole workgroup tiles
+  uint32_t K, KG;        // contraction extent, and k-groups of 8 in the image (K rounded up to 32, / 8)
+};
+
 struct KtabArgs {
   int32_t nk;
   uint32_t K, Kpad;
@@ -100,6 +110,13 @@ int qamd_gettf_launch(int dtype, int bn, const GettArgs* a, int swap, const void
                       const void* ktab, const void* scale_a, const void* scale_b, void* absmax_out, void* stream);
 int qamd_gemmk_launch(int ta, int tb, const GettArgs* a, const void* A, const void* B, void* C,
                       const void* scale_a, const void* scale_b, void* absmax_out, void* stream);
+int64_t qamd_gemmh_image_bytes(int64_t xpad, int64_t kpad);
+int qamd_gemmh_absmax_launch(const SplitArgs* a, const void* X, void* slots, void* stream);
+int qamd_gemmh_split_launch(const SplitArgs* a, const void* X, const void* slots, void* hdr, void* P, void* stream);
+int qamd_gemmh_launch(int ta, int tb, const GettArgs* a, const void* PA, const void* PB, void* C, const void* scale_a,
+                      const void* scale_b, const void* hdrA, const void* hdrB, void* absmax_out, void* stream);
+int qamd_gemmh_dot_launch(int ta, int tb, const GettArgs* a, const void* PA, const void* PB, const void* T,
+                          const void* hdrA, const void* hdrB, void* partial, void* stream);
 int qamd_dotm_launch(int dtype, const DotArgs* a, const void* R, const void* v, void* slab, void* C,
                      const void* scale_a, const void* scale_b, void* absmax_out, void* stream);
 int qamd_stream_launch(int dtype, int V, const StreamArgs* a, const void* A, const void* B, void* C,

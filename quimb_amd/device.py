@@ -129,7 +129,12 @@ class HipDevice:
         """(pair_kernel, tile_cfg, split_k, micro_arena) in force for THIS call (see ``__init__``)."""
         o = getattr(self._rec_tls, "pins", None) or get_options()
         pick = lambda dev_value, opt_value: opt_value if dev_value is None else dev_value
-        return (int(pick(self.force_kernel, o.pair_kernel)), int(pick(self.force_tile_cfg, o.tile_cfg)),
+        kernel = int(pick(self.force_kernel, o.pair_kernel))
+        if kernel == 0 and o.join_arith == "f16x3":
+            kernel = -7      # (opt-in: the planner puts the joins large enough for it on gemmh.hip, everything else as usual)
+        elif o.join_arith not in ("f32", "f16x3"):
+            raise ValueError(f"join_arith must be 'f32' or 'f16x3', got {o.join_arith!r}")
+        return (kernel, int(pick(self.force_tile_cfg, o.tile_cfg)),
                 int(pick(self.force_split_k, o.split_k)), pick(self.micro_arena, o.micro_arena))
 
     @contextlib.contextmanager
@@ -316,7 +321,7 @@ class HipDevice:
             return False
         pa, pb, pt = a.data_ptr(), b.data_ptr(), t.data_ptr()
         cp = self.compile_pair(spec, dtype, min(pa & -pa, 16), min(pb & -pb, 16), min(pt & -pt, 16))
-        if cp.struct.kernel != 5:
+        if cp.struct.kernel not in (5, 7):
             return False
         nws = int(self.lib.qamd_pair_dot_workspace_bytes(C.byref(cp.struct)))
         if nws <= 0:

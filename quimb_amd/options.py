@@ -38,6 +38,7 @@ class Options:
     pair_kernel: int = 0            #: qamd_pair_plan.kernel on input: 0 auto, -1 tiled GETT, -2 no MFMA GEMM kernels   [QAMD_KERNEL]
     tile_cfg: int = -1              #: qamd_pair_plan.tile_cfg on input                                 [QAMD_TILE_CFG]
     split_k: int = 0                #: qamd_pair_plan.split_k on input                                  [QAMD_SPLIT_K]
+    join_arith: str = "f32"         #: arithmetic of the large fp32 GEMM-shaped joins: "f32" (fp32 MFMA, gemmk.hip) | "f16x3" (OPT-IN: split products on the f16 matrix pipe, fp32 accumulate, gemmh.hip: qamd_pair_plan.kernel = -7)  [QAMD_JOIN_ARITH]
     # ---- execution ----------------------------------------------------------------------------------------------------
     lanes: bool = True              #: independent chains on their own HIP streams                      [QAMD_LANES]
     slice_graph: bool = True        #: slices replay one recorded hipGraph                              [QAMD_SLICE_GRAPH]
@@ -66,7 +67,7 @@ class Options:
             join_order=on("QAMD_JOIN_ORDER", True), lane_priority=on("QAMD_LANE_PRIORITY", False),
             hold_late=env.get("QAMD_HOLD_LATE", "auto"), program_join_order=on("QAMD_PROGRAM_JOIN_ORDER", False),
             pair_kernel=int(env.get("QAMD_KERNEL", "0")), tile_cfg=int(env.get("QAMD_TILE_CFG", "-1")),
-            split_k=int(env.get("QAMD_SPLIT_K", "0")),
+            split_k=int(env.get("QAMD_SPLIT_K", "0")), join_arith=env.get("QAMD_JOIN_ARITH", "f32"),
             lanes=on("QAMD_LANES", True), slice_graph=on("QAMD_SLICE_GRAPH", True), lane_trace=bool(env.get("QAMD_LANE_TRACE")),
             program_own_lane0=on("QAMD_PROGRAM_OWN_LANE0", False),
             fold_constants=on("QAMD_FOLD_CONSTANTS", True), microtree=on("QAMD_MICROTREE", True),

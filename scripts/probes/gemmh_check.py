@@ -1,0 +1,43 @@
+"""The split-product joins (quimb_amd.Options.join_arith = "f16x3", csrc/gemmh.hip) through the Python boundary: GEMM-shaped
+pairs of ragged sizes and several index orders against fp64 numpy, beside the same pair on the default fp32 MFMA path."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import numpy as np
+import quimb_amd as qa
+
+rng = np.random.default_rng(5)
+dev = qa.default_device()
+bad = 0
+cases = [
+    # (a inds, a shape, b inds, b shape, out inds)
+    ("km", (512, 700), "kn", (512, 300), "mn"),
+    ("km", (777, 1300), "kn", (777, 516), "nm"),
+    ("kab", (1296, 36, 36), "kcd", (1296, 6, 216), "abcd"),
+    ("kab", (1000, 20, 30), "kcd", (1000, 40, 10), "cadb"),     # not both bundles contiguous in C: whatever the planner picks
+    ("km", (7776, 1944), "kn", (7776, 972), "mn"),
+]
+for fill in ("uniform", "signed", "wide"):
+    for ai, ash, bi, bsh, oi in cases:
+        if fill == "uniform":
+            a, b = rng.uniform(-0.1, 1, ash), rng.uniform(-0.1, 1, bsh)
+        elif fill == "signed":
+            a, b = rng.normal(size=ash), rng.normal(size=bsh) * 1e-4
+        else:
+            a, b = rng.lognormal(0, 3, ash) * rng.choice([-1, 1], ash), rng.lognormal(0, 3, bsh)
+        a, b = a.astype(np.float32), b.astype(np.float32)
+        want = np.einsum(f"{ai},{bi}->{oi}", a.astype(np.float64), b.astype(np.float64), optimize=True)
+        scale = np.abs(want).max()
+        res = {}
+        for mode in ("f32", "f16x3"):
+            with qa.exec_options(join_arith=mode):
+                got = qa.einsum(f"{ai},{bi}->{oi}", qa.asarray(a), qa.asarray(b))
+                res[mode] = np.abs(qa.to_numpy(got).astype(np.float64) - want).max() / scale
+        with qa.exec_options(join_arith="f16x3"):
+            from quimb_amd.pairwise import plan_pair
+            step = plan_pair(tuple(ai), ash, tuple(bi), bsh, tuple(oi), True)
+            name = dev.describe_pair(dev.compile_pair(step.spec, np.dtype("float32")))
+        ok = res["f16x3"] < max(2e-6, 2 * res["f32"])
+        bad += not ok
+        print(f"{fill:8s} {ai}{ash} x {bi}{bsh} -> {oi}: {name:34s} max-norm err vs fp64: f16x3 {res['f16x3']:.2e}, fp32 MFMA path {res['f32']:.2e}  {'ok' if ok else '** FAILED **'}")
+print("FAILED" if bad else "all ok")
+sys.exit(1 if bad else 0)

@@ -614,6 +614,102 @@ def check_gemmk(seed=21, tiles=(None,)):
                 dev._pairs.clear()
 
 
+GEMMH_CASES = [
+    # the fp32 GEMM-shaped joins as split products on the f16 matrix pipe (gemmh.hip, opt-in: Options.join_arith = "f16x3")
+    ("km,kn->mn", dict(k=264, m=300, n=520)),            # ragged edge tiles on both sides, K % 32 == 8 (zero-padded k)
+    ("km,kn->nm", dict(k=300, m=516, n=260)),            # C m-contiguous: operand roles swap; K % 8 != 0
+    ("kab,kcd->acbd", dict(k=288, a=20, b=16, c=12, d=24)),    # two groups per bundle, C interleaves them
+    ("xkm,kn->xmn", dict(x=2, k=256, m=160, n=384)),     # M = (x, m): an outer M group with its own stride
+    ("km,kn->mn", dict(k=1296, m=1296, n=1296)),         # powers of 6: several tiles per CU on the small tiles
+    ("km,kn->mn", dict(k=2048, m=256, n=256)),           # one tile, a long k loop
+]
+
+
+def check_gemmh(seed=41, tiles=(None,)):
+    """``join_arith = "f16x3"``: every fp32 operand of a large GEMM-shaped join is scaled by a power of two and split into two
+    fp16 halves (2^-24 relative), the products a1 b1 + a1 b2 + a2 b1 are exact and accumulate in fp32 on the f16 MFMA.  Bar:
+    the fp32 k-ordered chain's own (check_gemmk), times 1.5 for the f16 instruction's accumulate (measured: it truncates the
+    aligned addends ~10 bits below the result's last place -- a bias of ~2^-30 per accumulation towards zero, 2e-7 of an
+    all-positive sum at K = 7776).  ``tiles``: 10 ta + tb pinned through the plan inputs (kernel = -7, tile_cfg), None = the
+    planner's.  Fills: the benchmark's mostly-positive one, a sign-mixed one with operands of very different scales, and a
+    heavy-tailed one (entries down to 1e-8 of the largest)."""
+    rng = np.random.default_rng(seed)
+    dev = qa.default_device()
+    names = []
+    for tile in tiles:
+        old_pin = (getattr(dev, "force_kernel", None), getattr(dev, "force_tile_cfg", None))
+        dev.force_kernel = -7
+        dev.force_tile_cfg = None if tile is None else 16 * (int(tile) // 10) + int(tile) % 10
+        if hasattr(dev, "_pairs"):
+            dev._pairs.clear()
+        try:
+            for fill in ("mostly positive", "signed", "heavy tail"):
+                for eq, dims in GEMMH_CASES:
+                    lhs, out = eq.split("->")
+                    ai, bi = lhs.split(",")
+                    sa, sb = [dims[c] for c in ai], [dims[c] for c in bi]
+                    if fill == "mostly positive":
+                        a, b = rng.uniform(-0.1, 1.0, sa), rng.uniform(-0.1, 1.0, sb) * 3.7e4
+                    elif fill == "signed":
+                        a, b = rng.normal(size=sa), rng.normal(size=sb) * 1e-5
+                    else:
+                        a, b = rng.lognormal(0, 3, sa) * rng.choice([-1.0, 1.0], sa), rng.lognormal(0, 3, sb)
+                    a, b = a.astype(np.float32), b.astype(np.float32)
+                    want = np.einsum(eq, a.astype(np.float64), b.astype(np.float64))
+                    got = qa.einsum(eq, qa.asarray(a), qa.asarray(b))
+                    kk = int(np.prod([dims[c] for c in set(ai) & set(bi) - set(out)]))
+                    bound = 1.5 * 2 * np.sqrt(kk) * 2.0**-24 * np.max(np.einsum(eq, np.abs(a).astype(np.float64), np.abs(b).astype(np.float64)))
+                    err = np.max(np.abs(got.to_numpy().astype(np.float64) - want))
+                    assert got.shape == want.shape and err <= bound, (eq, tile, fill, err, bound)
+                    if hasattr(dev, "describe_pair") and hasattr(dev, "compile_pair"):
+                        from quimb_amd.pairwise import plan_pair
+
+                        step = plan_pair(tuple(ai), tuple(sa), tuple(bi), tuple(sb), tuple(out), True)
+                        names.append(dev.describe_pair(dev.compile_pair(step.spec, np.dtype("float32"))))
+            if tile is not None:
+                # short k loops on a pinned tile (the floors K, M, N >= 256 are waived): two, three, four 32-k stages, padded k
+                for kk in (40, 64, 72, 96, 100, 128, 136):
+                    a = rand(rng, (kk, 200), "float32")
+                    b = rand(rng, (kk, 264), "float32")
+                    want = a.astype(np.float64).T @ b.astype(np.float64)
+                    got = qa.einsum("km,kn->mn", qa.asarray(a), qa.asarray(b)).to_numpy().astype(np.float64)
+                    bound = 3 * np.sqrt(kk) * 2.0**-24 * np.max(np.abs(a).astype(np.float64).T @ np.abs(b).astype(np.float64))
+                    assert np.max(np.abs(got - want)) <= bound, (tile, kk, np.max(np.abs(got - want)), bound)
+        finally:
+            dev.force_kernel, dev.force_tile_cfg = old_pin
+            if hasattr(dev, "_pairs"):
+                dev._pairs.clear()
+    return names
+
+
+def check_gemmh_tree(seed=43):
+    """The split products inside an executor: a four-operand two-sided tree whose joins carry exponent slots (the split pass
+    scales by the slots' maximum instead of taking its own), the second join fused with the closing inner product, plain and
+    with strip_exponent, against fp64 numpy and against the same tree on the fp32 MFMA path."""
+    rng = np.random.default_rng(seed)
+    out = []
+    for (L, R, H) in ((1100, 1180, 264), (2048, 1536, 300), (1300, 2100, 512)):     # (L R >= 2^20: the executor fuses the closing inner product)
+        tl, tr = rand(rng, (H, L), "float32"), rand(rng, (H, R), "float32")
+        bl, br = rand(rng, (H, L), "float32") * 3e4, rand(rng, (H, R), "float32") * 1e-3
+        want = float(np.sum((tl.astype(np.float64).T @ tr.astype(np.float64)) * (bl.astype(np.float64).T @ br.astype(np.float64))))
+        inputs = [("h", "l"), ("h", "r"), ("g", "l"), ("g", "r")]
+        size = dict(h=H, g=H, l=L, r=R)
+        tree = qa.ContractionTree(inputs, (), size, path=[(0, 1), (0, 1), (0, 1)])
+        xs = [qa.asarray(x) for x in (tl, tr, bl, br)]
+        vals = {}
+        for mode in ("f32", "f16x3"):
+            ex = qa.TreeExecutor(tree, "float32", options=qa.get_options().replace(join_arith=mode))
+            assert ex.plan[-1][0] == "pairdot", ex.plan[-1][0]
+            got = ex(xs).to_numpy().item()
+            m, e = ex(xs, strip_exponent=True)
+            got_s = m.to_numpy().item() * 10.0 ** e
+            for val in (got, got_s):
+                assert abs(val - want) <= 2e-6 * abs(want), ((L, R, H), mode, val, want)
+            vals[mode] = abs(got_s - want) / abs(want)
+        out.append(((L, R, H), vals))
+    return out
+
+
 GEMMD_CASES = [
     # GEMM-shaped fp64 contractions -> gemmd_kernel (gemmd.hip); every operand-layout combination, K % 16 == 0
     ("mk,kn->mn", dict(m=260, k=64, n=132)),            # A k-contiguous, B free-contiguous, ragged edges on both sides

@@ -268,6 +268,24 @@ def test_krylov_step(hip, dtype):
     checks.check_krylov_step(dtype)
 
 
+def test_gemmh_split_products(hip):
+    """OPT-IN join arithmetic (Options.join_arith = "f16x3", gemmh.hip): fp32 joins as three exact fp16 products with fp32
+    accumulation -- ragged edges, padded k, swapped roles, tensor addressing, three fills, the planner's tile and every tile
+    pinned; then inside an executor (exponent slots, the fused closing inner product)."""
+    names = checks.check_gemmh(tiles=(None, 44, 34, 43, 33, 24, 42))
+    assert names and all(n.startswith("gemmh_kernel") for n in names), sorted(set(names))
+    assert {n for n in names} >= {f"gemmh_kernel<{a}, {b}> f16x3" for (a, b) in ((4, 4), (3, 4), (4, 3), (3, 3), (2, 4), (4, 2))}
+    hip.profile, hip.profile_min_mults = [], 0
+    try:
+        res = checks.check_gemmh_tree()
+        names = [r[2] for r in hip.profile]
+    finally:
+        hip.profile = None
+    assert any(n.startswith("gemmh_kernel") and n.endswith("+ dot") for n in names), names
+    assert any(n.startswith("gemmk_kernel") and n.endswith("+ dot") for n in names), names
+    print("split products vs fp32 MFMA, rel. err of the closing scalar:", res)
+
+
 @pytest.mark.parametrize("dtype", ["float32", "float64", "complex64"])
 def test_expression_switches_to_a_launch_program(hip, dtype):
     checks.check_auto_program(dtype)

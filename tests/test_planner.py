@@ -120,3 +120,46 @@ def test_join_dot_workspace_follows_the_gemmk_tiles():
     # without a device nothing can be launched, but the refusal of an unsupported plan is host logic
     one = (C.c_float * 4)()
     assert lib.qamd_contract_pair_dot(C.byref(p), one, one, one, one, None, 0, None, None, None) == -2      # QAMD_EUNSUPPORTED
+
+
+def test_split_product_joins_are_opt_in():
+    """Kernel 7 (gemmh.hip: fp32 joins as three exact fp16 products on the f16 matrix pipe) is never the planner's own choice:
+    only plan.kernel = -7 on input selects it, for the shapes that pay for the split pass; everything else falls through to
+    the automatic choice.  The workspace holds the operands' split images."""
+    from quimb_amd import _lib
+
+    lib = _lib.load()
+    name, p = _describe("km", (7776, 7776), "kn", (7776, 7776), "mn")
+    assert p.kernel == 5                                                                  # default: the fp32 MFMA kernel
+    name, p = _describe("km", (7776, 7776), "kn", (7776, 7776), "mn", pin=(-7, -1))
+    assert p.kernel == 7 and name == "gemmh_kernel<3, 4> f16x3", name                     # 1271 tiles of 192 x 256: 4.96 rounds
+    mpad, npad, kpad = 41 * 192, 31 * 256, 7776
+    img = lambda x: 2 * (kpad // 8) * x * 16
+    assert lib.qamd_pair_workspace_bytes(C.byref(p)) == 1024 + img(mpad) + img(npad)
+    assert lib.qamd_pair_dot_workspace_bytes(C.byref(p)) == (8 * 41 * 31 + 255) // 256 * 256 + 1024 + img(mpad) + img(npad)
+    name, p = _describe("km", (7776, 3888), "kn", (7776, 1944), "mn", pin=(-7, -1))       # one rank of eight: one round of 128 x 256
+    assert name in ("gemmh_kernel<4, 2> f16x3", "gemmh_kernel<2, 4> f16x3"), name
+    name, p = _describe("km", (8192, 8192), "kn", (8192, 8192), "mn", pin=(-7, 16 * 4 + 4))
+    assert name == "gemmh_kernel<4, 4> f16x3"
+    name, p = _describe("km", (300, 7000), "kn", (300, 5000), "mn", pin=(-7, -1))         # K % 32 != 0: zero-padded images
+    assert p.kernel == 7 and lib.qamd_pair_workspace_bytes(C.byref(p)) > 0
+    # not covered -> the automatic choice, as if the pin were 0
+    for args, kw in ((("km", (128, 4096), "kn", (128, 4096), "mn"), {}),                  # K < 256: not worth the split pass
+                     (("km", (512, 2048), "kn", (512, 200), "mn"), {}),                   # N < 256
+                     (("mk", (2048, 512), "kn", (512, 2048), "mn"), {}),                  # A contiguous along k
+                     (("bkm", (3, 512, 512), "bkn", (3, 512, 512), "bmn"), {}),           # batch bundle
+                     (("km", (512, 2048), "kn", (512, 2048), "mn"), dict(dtype="float64"))):
+        name7, p7 = _describe(*args, pin=(-7, -1), **kw)
+        name0, p0 = _describe(*args, **kw)
+        assert p7.kernel != 7 and (p7.kernel, p7.tile_cfg, p7.split_k, name7) == (p0.kernel, p0.tile_cfg, p0.split_k, name0), (args, name7, name0)
+
+
+def test_join_arith_option_pins_kernel_minus_seven():
+    import quimb_amd as qa
+    from quimb_amd.options import Options
+
+    assert Options().join_arith == "f32"
+    assert Options.from_env({"QAMD_JOIN_ARITH": "f16x3"}).join_arith == "f16x3"
+    with qa.exec_options(join_arith="f16x3") as o:
+        assert o.join_arith == "f16x3" and qa.get_options().join_arith == "f16x3"
+    assert qa.get_options().join_arith == "f32"
