@@ -293,20 +293,34 @@ __global__ __launch_bounds__(256, 1) void gemmh_kernel(const GettArgs p, const c
   // ---- epilogue: acc[i][j][r] = C[wm 32 TA + 32 i + (r & 3) + 8 (r >> 2) + 4 kh][wn 32 TB + 32 j + l31] -----------------------
   const float unscale = hdrA[1] * hdrB[1];
   if constexpr (DOT) {
+    // (a tile's epilogue has the CU to itself -- one workgroup per CU --, so T's values are requested a whole sub-tile row
+    // block ahead of their use, with clamped addresses and 0 / 1 masks instead of branches: 64 loads in flight per lane)
     __shared__ double dred[4];
     float dsum = 0.0f;
+    int64_t ocol[TB];
+    float cmask[TB];
+#pragma unroll
+    for (int j = 0; j < TB; ++j) {
+      const int nl = wn * (32 * TB) + 32 * j + l31;
+      ocol[j] = offCn[nl];                               // (columns past N: the table holds column N - 1)
+      cmask[j] = (n0 + nl < p.N) ? 1.0f : 0.0f;
+    }
 #pragma unroll
     for (int i = 0; i < TA; ++i) {
+      float tv[16][TB];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int ml = wm * (32 * TA) + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * kh;
-        if (m0 + ml >= p.M) continue;
-        const int64_t orow = offCm[ml];
+        const int64_t orow = offCm[ml];                  // (rows past M: row M - 1)
 #pragma unroll
-        for (int j = 0; j < TB; ++j) {
-          const int nl = wn * (32 * TB) + 32 * j + l31;
-          if (n0 + nl < p.N) dsum += acc[i][j][r] * C[orow + offCn[nl]];
-        }
+        for (int j = 0; j < TB; ++j) tv[r][j] = C[orow + ocol[j]];
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int ml = wm * (32 * TA) + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * kh;
+        const float rmask = (m0 + ml < p.M) ? 1.0f : 0.0f;
+#pragma unroll
+        for (int j = 0; j < TB; ++j) dsum = __builtin_fmaf(acc[i][j][r] * (rmask * cmask[j]), tv[r][j], dsum);
       }
     }
     double ds = (double)dsum;
