@@ -680,7 +680,8 @@ static int launch_gemmk(const qamd_pair_plan* p, const PairDims& d, const void* 
 
 // ---- kernel 7 (gemmh.hip): the same joins as split products on the f16 matrix pipe (opt-in: plan.kernel = -7 on input) --------
 // workspace: [0, 16) the two operands' (scale, 1 / scale) pairs, [256, 512) / [512, 768) absmax slots for operands that
-// bring none, [1024, ..) the kernel-role "m" operand's images, then the "n" operand's (each a multiple of 256 bytes)
+// bring none, [1024, ..) the kernel-role "m" operand's column means + their partial sums (doubles), the "n" operand's, then
+// the "m" operand's split images and the "n" operand's (every block a multiple of 256 bytes)
 static const int kGemmhTiles[6][2] = {{4, 4}, {3, 4}, {4, 3}, {3, 3}, {2, 4}, {4, 2}};
 static int64_t gemmh_kpad(int64_t K) { return (K + 31) / 32 * 32; }
 
@@ -711,7 +712,8 @@ static int64_t gemmh_workspace_bytes(const qamd_pair_plan* p, const PairDims& d)
   const bool swap = !p->c_ncontig;
   const int64_t M = swap ? d.N : d.M, N = swap ? d.M : d.N;
   const int64_t mpad = (M + 64 * ta - 1) / (64 * ta) * (64 * ta), npad = (N + 64 * tb - 1) / (64 * tb) * (64 * tb);
-  return 1024 + qamd_gemmh_image_bytes(mpad, gemmh_kpad(d.K)) + qamd_gemmh_image_bytes(npad, gemmh_kpad(d.K));
+  return 1024 + qamd_gemmh_mean_bytes(mpad) + qamd_gemmh_mean_bytes(npad) + qamd_gemmh_image_bytes(mpad, gemmh_kpad(d.K)) +
+         qamd_gemmh_image_bytes(npad, gemmh_kpad(d.K));
 }
 
 static int launch_gemmh(const qamd_pair_plan* p, const PairDims& d, const void* A, const void* B, void* C, void* ws,
@@ -738,7 +740,9 @@ static int launch_gemmh(const qamd_pair_plan* p, const PairDims& d, const void* 
   char* w = (char*)ws;
   float* hdr_m = (float*)w;
   float* hdr_n = hdr_m + 2;
-  char* img_m = w + 1024;
+  char* mean_m = w + 1024;
+  char* mean_n = mean_m + qamd_gemmh_mean_bytes(sm.Xpad);
+  char* img_m = mean_n + qamd_gemmh_mean_bytes(sn.Xpad);
   char* img_n = img_m + qamd_gemmh_image_bytes(sm.Xpad, a.Kloop);
   const void* Am = swap ? B : A;
   const void* Bn = swap ? A : B;
@@ -750,10 +754,13 @@ static int launch_gemmh(const qamd_pair_plan* p, const PairDims& d, const void* 
   const void* split_n = slots_n;
   if (!split_m) { if ((rc = qamd_gemmh_absmax_launch(&sm, Am, w + 256, stream))) return rc; split_m = w + 256; }
   if (!split_n) { if ((rc = qamd_gemmh_absmax_launch(&sn, Bn, w + 512, stream))) return rc; split_n = w + 512; }
-  if ((rc = qamd_gemmh_split_launch(&sm, Am, split_m, hdr_m, img_m, stream))) return rc;
-  if ((rc = qamd_gemmh_split_launch(&sn, Bn, split_n, hdr_n, img_n, stream))) return rc;
-  if (dot_T) return dot_partial ? qamd_gemmh_dot_launch(ta, tb, &a, img_m, img_n, dot_T, hdr_m, hdr_n, dot_partial, stream) : 0;
-  return qamd_gemmh_launch(ta, tb, &a, img_m, img_n, C, slots_m, slots_n, hdr_m, hdr_n, ep ? ep->absmax_out : nullptr, stream);
+  // (both operands centred: the part of the product carried by the columns' means is added exactly in the epilogue)
+  if ((rc = qamd_gemmh_split_launch(&sm, Am, split_m, hdr_m, img_m, mean_m, stream))) return rc;
+  if ((rc = qamd_gemmh_split_launch(&sn, Bn, split_n, hdr_n, img_n, mean_n, stream))) return rc;
+  if (dot_T)
+    return dot_partial ? qamd_gemmh_dot_launch(ta, tb, &a, img_m, img_n, dot_T, hdr_m, hdr_n, mean_m, mean_n, dot_partial, stream) : 0;
+  return qamd_gemmh_launch(ta, tb, &a, img_m, img_n, C, slots_m, slots_n, hdr_m, hdr_n, mean_m, mean_n,
+                           ep ? ep->absmax_out : nullptr, stream);
 }
 
 extern "C" int qamd_gemmd_launch(int ta, int tb, const GettArgs* a, int swap, const void* A, const void* B, void* C,

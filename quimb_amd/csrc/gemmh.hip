@@ -74,15 +74,40 @@ __global__ __launch_bounds__(256) void habsmax_kernel(const SplitArgs p, const f
     atomicMax(reinterpret_cast<unsigned int*>(slots) + ((blockIdx.x * 4 + (threadIdx.x >> 6) + blockIdx.y) % QAMD_SLOTS), __float_as_uint(m));
 }
 
+// ---- column sums over k, in NY partial rows of doubles: part[y][x] = sum of X[k, x] over the y-th k range (no atomics: the
+// split pass adds the NY partials of a column in a fixed order) ------------------------------------------------------------------
+__global__ __launch_bounds__(256) void hmean_kernel(const SplitArgs p, const float* __restrict__ X, double* __restrict__ part) {
+  const uint32_t x = blockIdx.x * 256 + threadIdx.x;
+  if (x >= p.Xpad) return;
+  double s = 0.0;
+  if (x < p.X) {
+    const float* src = X + hdecomp(x, p.ng, p.dim, p.stride);
+    const uint32_t per = (p.K + gridDim.y - 1) / gridDim.y;
+    const uint32_t k0 = blockIdx.y * per, k1 = (k0 + per < p.K) ? k0 + per : p.K;
+    uint32_t k = k0;
+    for (; k + 4 <= k1; k += 4) {
+      const float v0 = src[(int64_t)k * p.sk], v1 = src[(int64_t)(k + 1) * p.sk], v2 = src[(int64_t)(k + 2) * p.sk],
+                  v3 = src[(int64_t)(k + 3) * p.sk];
+      s += ((double)v0 + (double)v1) + ((double)v2 + (double)v3);
+    }
+    for (; k < k1; ++k) s += (double)src[(int64_t)k * p.sk];
+  }
+  part[(int64_t)blockIdx.y * p.Xpad + x] = s;
+}
+
 // ---- the split pass ---------------------------------------------------------------------------------------------------------
 // hdr[0] = the power of two the operand was multiplied by, hdr[1] = its inverse.  Grid (ceil(Xpad / 256), k-group chunks).
+// part != NULL (ny partial rows): the operand is CENTRED first -- every column's mean over k (rounded to fp32) is subtracted
+// before the split and written to mean[x] as a double; the product kernel adds the rank-1 term back in its epilogue.
 __global__ __launch_bounds__(256) void split_kernel(const SplitArgs p, const float* __restrict__ X, const float* __restrict__ slots,
-                                                    float* __restrict__ hdr, h8* __restrict__ P) {
+                                                    float* __restrict__ hdr, h8* __restrict__ P, const double* __restrict__ part,
+                                                    int ny, double* __restrict__ mean) {
   const int lane = threadIdx.x & 63;
   const float m = hread_scale(slots, lane);
   int q = 0;
   (void)frexpf(m, &q);                                 // m = f 2^q, f in [0.5, 1)  ->  m 2^(15 - q) in [2^14, 2^15)
-  const bool fin = m > 0.f && m < 3.0e38f;
+  if (part) q += 1;                                    // (|x - mean| <= 2 max|x|)
+  const bool fin = m > 0.f && m < 1.5e38f;
   const float scale = fin ? ldexpf(1.f, 15 - q) : 1.f;
   if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
     hdr[0] = scale;
@@ -91,6 +116,14 @@ __global__ __launch_bounds__(256) void split_kernel(const SplitArgs p, const flo
   const uint32_t x = blockIdx.x * 256 + threadIdx.x;
   if (x >= p.Xpad) return;
   const bool valid = x < p.X;
+  float ahat = 0.f;
+  if (part) {
+    double sum = 0.0;
+    for (int y = 0; y < ny; ++y) sum += part[(int64_t)y * p.Xpad + x];      // (fixed order; zeros for the padding columns)
+    const double abar = sum / (double)p.K;
+    ahat = (float)abar;
+    if (blockIdx.y == 0) mean[x] = abar;
+  }
   const float* src = X + (valid ? hdecomp(x, p.ng, p.dim, p.stride) : 0);
   const uint32_t per = (p.KG + gridDim.y - 1) / gridDim.y;
   const uint32_t kg0 = blockIdx.y * per, kg1 = (kg0 + per < p.KG) ? kg0 + per : p.KG;
@@ -102,7 +135,7 @@ __global__ __launch_bounds__(256) void split_kernel(const SplitArgs p, const flo
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const uint32_t k = 8 * kg + j;
-      v[j] = (valid && k < p.K) ? src[(int64_t)k * p.sk] * scale : 0.f;
+      v[j] = (valid && k < p.K) ? (src[(int64_t)k * p.sk] - ahat) * scale : 0.f;
     }
     h8 a, b;
 #pragma unroll
@@ -123,7 +156,8 @@ template <int TA, int TB, bool DOT>
 __global__ __launch_bounds__(256, 1) void gemmh_kernel(const GettArgs p, const char* __restrict__ PA, const char* __restrict__ PB,
                                                        float* __restrict__ C, const float* __restrict__ scale_a,
                                                        const float* __restrict__ scale_b, const float* __restrict__ hdrA,
-                                                       const float* __restrict__ hdrB, float* __restrict__ absmax_out) {
+                                                       const float* __restrict__ hdrB, const double* __restrict__ meanA,
+                                                       const double* __restrict__ meanB, float* __restrict__ absmax_out) {
   constexpr int BM = 64 * TA, BN = 64 * TB;
   constexpr int SA = 2 * 4 * BM * 16, SB = 2 * 4 * BN * 16, STAGE = SA + SB;   // bytes: [half][4 k-groups][x][16]
   constexpr int NP = 2 * TA + 2 * TB;                                           // LDS-DMA pieces per wave and stage
@@ -291,12 +325,25 @@ __global__ __launch_bounds__(256, 1) void gemmh_kernel(const GettArgs p, const c
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
   // ---- epilogue: acc[i][j][r] = C[wm 32 TA + 32 i + (r & 3) + 8 (r >> 2) + 4 kh][wn 32 TB + 32 j + l31] -----------------------
+  // centred operands (meanA / meanB: the columns' means over k as doubles, zeros for the padding): with ah = fp32(abar),
+  //   sum_k a b = sum_k (a - ah)(b - bh) + K (ah bbar + bh (abar - ah))
+  // -- the MFMA sum is over sign-mixed terms of the size of the operands' FLUCTUATIONS, the part carried by the means is
+  // added here in double precision
   const float unscale = hdrA[1] * hdrB[1];
+  const bool centred = meanA != nullptr;
+  double bbar[TB], bh[TB];
+#pragma unroll
+  for (int j = 0; j < TB; ++j) {
+    const double v = centred ? meanB[n0 + wn * (32 * TB) + 32 * j + l31] : 0.0;
+    bbar[j] = v * (double)p.K;
+    bh[j] = (double)(float)v * (double)p.K;
+  }
   if constexpr (DOT) {
     // (a tile's epilogue has the CU to itself -- one workgroup per CU --, so T's values are requested a whole sub-tile row
     // block ahead of their use, with clamped addresses and 0 / 1 masks instead of branches: 64 loads in flight per lane)
     __shared__ double dred[4];
     float dsum = 0.0f;
+    double dcorr = 0.0;
     int64_t ocol[TB];
     float cmask[TB];
 #pragma unroll
@@ -319,19 +366,29 @@ __global__ __launch_bounds__(256, 1) void gemmh_kernel(const GettArgs p, const c
       for (int r = 0; r < 16; ++r) {
         const int ml = wm * (32 * TA) + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * kh;
         const float rmask = (m0 + ml < p.M) ? 1.0f : 0.0f;
+        float trow[TB];
 #pragma unroll
-        for (int j = 0; j < TB; ++j) dsum = __builtin_fmaf(acc[i][j][r] * (rmask * cmask[j]), tv[r][j], dsum);
+        for (int j = 0; j < TB; ++j) {
+          trow[j] = tv[r][j] * (rmask * cmask[j]);
+          dsum = __builtin_fmaf(acc[i][j][r], trow[j], dsum);
+        }
+        if (centred) {
+          const double abar = meanA[m0 + ml], ah = (double)(float)abar, ad = abar - ah;
+#pragma unroll
+          for (int j = 0; j < TB; ++j) dcorr += (ah * bbar[j] + ad * bh[j]) * (double)trow[j];
+        }
       }
     }
-    double ds = (double)dsum;
+    double ds = (double)dsum * (double)unscale + dcorr;
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) ds += __shfl_down(ds, d, 64);
     if (lane == 0) dred[wave] = ds;
     __syncthreads();
-    if (tid == 0) reinterpret_cast<double*>(absmax_out)[blockIdx.x] = ((dred[0] + dred[1]) + (dred[2] + dred[3])) * (double)unscale;
+    if (tid == 0) reinterpret_cast<double*>(absmax_out)[blockIdx.x] = (dred[0] + dred[1]) + (dred[2] + dred[3]);
     return;
   }
-  const float alpha = unscale / (hread_scale(scale_a, lane) * hread_scale(scale_b, lane));
+  const float strip = 1.0f / (hread_scale(scale_a, lane) * hread_scale(scale_b, lane));
+  const float alpha = unscale * strip;
   float vmax = 0.0f;
 #pragma unroll
   for (int i = 0; i < TA; ++i) {
@@ -340,11 +397,18 @@ __global__ __launch_bounds__(256, 1) void gemmh_kernel(const GettArgs p, const c
       const int ml = wm * (32 * TA) + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * kh;
       if (m0 + ml >= p.M) continue;
       const int64_t orow = offCm[ml];
+      double ah = 0.0, ad = 0.0;
+      if (centred) {
+        const double abar = meanA[m0 + ml];
+        ah = (double)(float)abar;
+        ad = abar - ah;
+      }
 #pragma unroll
       for (int j = 0; j < TB; ++j) {
         const int nl = wn * (32 * TB) + 32 * j + l31;
         if (n0 + nl < p.N) {
-          const float v = acc[i][j][r] * alpha;
+          float v = acc[i][j][r] * alpha;
+          if (centred) v = (float)((double)v + (ah * bbar[j] + ad * bh[j]) * (double)strip);
           C[orow + offCn[nl]] = v;
           vmax = fmaxf(vmax, fabsf(v));
         }
@@ -360,13 +424,14 @@ __global__ __launch_bounds__(256, 1) void gemmh_kernel(const GettArgs p, const c
 
 template <int TA, int TB, bool DOT>
 static int launch_one(const GettArgs& a, const void* PA, const void* PB, void* C, const void* sa, const void* sb, const void* hdrA,
-                      const void* hdrB, void* amax, hipStream_t st) {
+                      const void* hdrB, const void* meanA, const void* meanB, void* amax, hipStream_t st) {
   constexpr int BM = 64 * TA, BN = 64 * TB;
   const size_t lds = (size_t)2 * 128 * (BM + BN) + (size_t)(BM + BN) * sizeof(int64_t);
   (void)hipFuncSetAttribute((const void*)gemmh_kernel<TA, TB, DOT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   const unsigned grid = a.tiles_m * a.tiles_n;
   QAMD_LAUNCH((gemmh_kernel<TA, TB, DOT>), dim3(grid), dim3(256), lds, st, a, (const char*)PA, (const char*)PB, (float*)C,
-              (const float*)sa, (const float*)sb, (const float*)hdrA, (const float*)hdrB, (float*)amax);
+              (const float*)sa, (const float*)sb, (const float*)hdrA, (const float*)hdrB, (const double*)meanA,
+              (const double*)meanB, (float*)amax);
   return hipGetLastError() == hipSuccess ? 0 : -4;
 }
 
@@ -375,9 +440,12 @@ static int launch_one(const GettArgs& a, const void* PA, const void* PB, void* C
 using namespace qamdh;
 
 #define QAMD_GEMMH_CASES QH_CASE(4, 4) QH_CASE(3, 4) QH_CASE(4, 3) QH_CASE(3, 3) QH_CASE(2, 4) QH_CASE(4, 2)
+#define QAMD_GEMMH_NY 32     // partial rows of the column sums
 
 // bytes of one operand's split images for free extent padded to ``xpad`` and K padded to ``kpad`` (a multiple of 32)
 extern "C" int64_t qamd_gemmh_image_bytes(int64_t xpad, int64_t kpad) { return 2 * (kpad / 8) * xpad * 16; }
+// bytes of one operand's column means (doubles) + the partial sums they are built from
+extern "C" int64_t qamd_gemmh_mean_bytes(int64_t xpad) { return (QAMD_GEMMH_NY + 1) * xpad * 8; }
 
 // absmax of a strided operand into 64 zeroed slots (callers without exponent slots)
 extern "C" int qamd_gemmh_absmax_launch(const SplitArgs* a, const void* X, void* slots, void* stream) {
@@ -388,24 +456,34 @@ extern "C" int qamd_gemmh_absmax_launch(const SplitArgs* a, const void* X, void*
   return hipGetLastError() == hipSuccess ? 0 : -4;
 }
 
-// X (fp32, free bundle a->dim / a->stride, k stride a->sk) -> P[2][a->KG][a->Xpad][8] f16, hdr[0 .. 1] = scale, 1 / scale
-extern "C" int qamd_gemmh_split_launch(const SplitArgs* a, const void* X, const void* slots, void* hdr, void* P, void* stream) {
-  if (!a || !X || !hdr || !P || a->KG == 0 || a->KG % 4 || a->Xpad < a->X || ((uintptr_t)P & 15)) return -2;
+// X (fp32, free bundle a->dim / a->stride, k stride a->sk) -> P[2][a->KG][a->Xpad][8] f16, hdr[0 .. 1] = scale, 1 / scale.
+// mean != NULL (qamd_gemmh_mean_bytes(a->Xpad) bytes: a->Xpad means, then the partial sums): the operand is centred -- every
+// column's mean over k is subtracted before the split; the product kernel is then handed the same pointer.
+extern "C" int qamd_gemmh_split_launch(const SplitArgs* a, const void* X, const void* slots, void* hdr, void* P, void* mean,
+                                       void* stream) {
+  if (!a || !X || !hdr || !P || a->KG == 0 || a->KG % 4 || a->Xpad < a->X || ((uintptr_t)P & 15) || ((uintptr_t)mean & 7)) return -2;
   const unsigned gx = (a->Xpad + 255) / 256;
+  double* part = mean ? (double*)mean + a->Xpad : nullptr;
+  if (mean) {
+    QAMD_LAUNCH(hmean_kernel, dim3(gx, QAMD_GEMMH_NY), dim3(256), 0, (hipStream_t)stream, *a, (const float*)X, part);
+    if (hipGetLastError() != hipSuccess) return -4;
+  }
   unsigned gy = (8192 + gx - 1) / gx;                 // ~8 K workgroups, at least two k-groups each
   if (gy > a->KG / 2) gy = a->KG / 2;
   if (gy < 1) gy = 1;
   QAMD_LAUNCH(split_kernel, dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, *a, (const float*)X, (const float*)slots, (float*)hdr,
-              (h8*)P);
+              (h8*)P, (const double*)part, QAMD_GEMMH_NY, (double*)mean);
   return hipGetLastError() == hipSuccess ? 0 : -4;
 }
 
-// a->tiles_m / tiles_n = ceil(M / 64 ta), ceil(N / 64 tb); a->Kloop = K rounded up to 32 (>= 64); the images padded to both
+// a->tiles_m / tiles_n = ceil(M / 64 ta), ceil(N / 64 tb); a->Kloop = K rounded up to 32 (>= 64); the images padded to both.
+// meanA / meanB: both NULL (operands split as they are) or both the pointers the split launches were given (centred operands).
 extern "C" int qamd_gemmh_launch(int ta, int tb, const GettArgs* a, const void* PA, const void* PB, void* C, const void* scale_a,
-                                 const void* scale_b, const void* hdrA, const void* hdrB, void* absmax_out, void* stream) {
-  if (!a || a->Kloop < 64 || a->Kloop % 32 || a->B != 1 || !hdrA || !hdrB) return -2;
+                                 const void* scale_b, const void* hdrA, const void* hdrB, const void* meanA, const void* meanB,
+                                 void* absmax_out, void* stream) {
+  if (!a || a->Kloop < 64 || a->Kloop % 32 || a->B != 1 || !hdrA || !hdrB || (!meanA) != (!meanB)) return -2;
 #define QH_CASE(TA_, TB_) \
-  if (ta == TA_ && tb == TB_) return launch_one<TA_, TB_, false>(*a, PA, PB, C, scale_a, scale_b, hdrA, hdrB, absmax_out, (hipStream_t)stream);
+  if (ta == TA_ && tb == TB_) return launch_one<TA_, TB_, false>(*a, PA, PB, C, scale_a, scale_b, hdrA, hdrB, meanA, meanB, absmax_out, (hipStream_t)stream);
   QAMD_GEMMH_CASES
 #undef QH_CASE
   return -2;
@@ -414,11 +492,12 @@ extern "C" int qamd_gemmh_launch(int ta, int tb, const GettArgs* a, const void* 
 // the product consumed by one inner product with T (C's layout): partial[0 .. tiles) one double per workgroup, finished by
 // qamd_gemmk_dot_finish (gemmk.hip)
 extern "C" int qamd_gemmh_dot_launch(int ta, int tb, const GettArgs* a, const void* PA, const void* PB, const void* T,
-                                     const void* hdrA, const void* hdrB, void* partial, void* stream) {
-  if (!a || a->Kloop < 64 || a->Kloop % 32 || a->B != 1 || !hdrA || !hdrB) return -2;
+                                     const void* hdrA, const void* hdrB, const void* meanA, const void* meanB, void* partial,
+                                     void* stream) {
+  if (!a || a->Kloop < 64 || a->Kloop % 32 || a->B != 1 || !hdrA || !hdrB || (!meanA) != (!meanB)) return -2;
 #define QH_CASE(TA_, TB_)     \
   if (ta == TA_ && tb == TB_) \
-    return launch_one<TA_, TB_, true>(*a, PA, PB, const_cast<void*>(T), nullptr, nullptr, hdrA, hdrB, partial, (hipStream_t)stream);
+    return launch_one<TA_, TB_, true>(*a, PA, PB, const_cast<void*>(T), nullptr, nullptr, hdrA, hdrB, meanA, meanB, partial, (hipStream_t)stream);
   QAMD_GEMMH_CASES
 #undef QH_CASE
   return -2;

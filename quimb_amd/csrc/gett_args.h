@@ -111,12 +111,14 @@ int qamd_gettf_launch(int dtype, int bn, const GettArgs* a, int swap, const void
 int qamd_gemmk_launch(int ta, int tb, const GettArgs* a, const void* A, const void* B, void* C,
                       const void* scale_a, const void* scale_b, void* absmax_out, void* stream);
 int64_t qamd_gemmh_image_bytes(int64_t xpad, int64_t kpad);
+int64_t qamd_gemmh_mean_bytes(int64_t xpad);
 int qamd_gemmh_absmax_launch(const SplitArgs* a, const void* X, void* slots, void* stream);
-int qamd_gemmh_split_launch(const SplitArgs* a, const void* X, const void* slots, void* hdr, void* P, void* stream);
+int qamd_gemmh_split_launch(const SplitArgs* a, const void* X, const void* slots, void* hdr, void* P, void* mean, void* stream);
 int qamd_gemmh_launch(int ta, int tb, const GettArgs* a, const void* PA, const void* PB, void* C, const void* scale_a,
-                      const void* scale_b, const void* hdrA, const void* hdrB, void* absmax_out, void* stream);
+                      const void* scale_b, const void* hdrA, const void* hdrB, const void* meanA, const void* meanB,
+                      void* absmax_out, void* stream);
 int qamd_gemmh_dot_launch(int ta, int tb, const GettArgs* a, const void* PA, const void* PB, const void* T,
-                          const void* hdrA, const void* hdrB, void* partial, void* stream);
+                          const void* hdrA, const void* hdrB, const void* meanA, const void* meanB, void* partial, void* stream);
 int qamd_dotm_launch(int dtype, const DotArgs* a, const void* R, const void* v, void* slab, void* C,
                      const void* scale_a, const void* scale_b, void* absmax_out, void* stream);
 int qamd_stream_launch(int dtype, int V, const StreamArgs* a, const void* A, const void* B, void* C,

@@ -15,7 +15,7 @@
 
 struct Dev {
   float *A, *B, *C, *T, *hdr, *slotsA, *slotsB;
-  char *PA, *PB;
+  char *PA, *PB, *meanA, *meanB;
   double* partial;
 };
 
@@ -32,7 +32,7 @@ static void fill_args(GettArgs& g, SplitArgs& sa, SplitArgs& sb, int M, int N, i
   sb.dim[0] = N; sb.sk = N; sb.X = N; sb.Xpad = g.tiles_n * BN;
 }
 
-static double run_case(int M, int N, int K, int ta, int tb, int iters, bool full_check, unsigned seed, int fill) {
+static double run_case(int M, int N, int K, int ta, int tb, int iters, bool full_check, unsigned seed, int fill, bool centre = true) {
   std::mt19937 rng(seed);
   std::uniform_real_distribution<float> U(-0.1f, 1.0f), V(-1.f, 1.f);
   std::lognormal_distribution<float> L(0.f, 2.f);
@@ -46,7 +46,7 @@ static double run_case(int M, int N, int K, int ta, int tb, int iters, bool full
   const size_t pa = (size_t)qamd_gemmh_image_bytes(sa.Xpad, g.Kloop), pb = (size_t)qamd_gemmh_image_bytes(sb.Xpad, g.Kloop);
   CK(hipMalloc(&d.A, hA.size() * 4)); CK(hipMalloc(&d.B, hB.size() * 4)); CK(hipMalloc(&d.C, hT.size() * 4));
   CK(hipMalloc(&d.T, hT.size() * 4)); CK(hipMalloc(&d.hdr, 64)); CK(hipMalloc(&d.slotsA, 256)); CK(hipMalloc(&d.slotsB, 256));
-  CK(hipMalloc(&d.PA, pa)); CK(hipMalloc(&d.PB, pb)); CK(hipMalloc(&d.partial, 8 * g.tiles_m * g.tiles_n));
+  CK(hipMalloc(&d.PA, pa)); CK(hipMalloc(&d.PB, pb)); CK(hipMalloc(&d.meanA, qamd_gemmh_mean_bytes(sa.Xpad))); CK(hipMalloc(&d.meanB, qamd_gemmh_mean_bytes(sb.Xpad))); CK(hipMalloc(&d.partial, 8 * g.tiles_m * g.tiles_n));
   CK(hipMemcpy(d.A, hA.data(), hA.size() * 4, hipMemcpyHostToDevice));
   CK(hipMemcpy(d.B, hB.data(), hB.size() * 4, hipMemcpyHostToDevice));
   CK(hipMemcpy(d.T, hT.data(), hT.size() * 4, hipMemcpyHostToDevice));
@@ -57,11 +57,11 @@ static double run_case(int M, int N, int K, int ta, int tb, int iters, bool full
   for (int it = 0; it < iters + 2; ++it) {
     CK(hipEventRecord(e0));
     if (qamd_gemmh_absmax_launch(&sa, d.A, d.slotsA, nullptr) || qamd_gemmh_absmax_launch(&sb, d.B, d.slotsB, nullptr)) { printf("absmax launch failed\n"); exit(1); }
-    if (qamd_gemmh_split_launch(&sa, d.A, d.slotsA, d.hdr, d.PA, nullptr) || qamd_gemmh_split_launch(&sb, d.B, d.slotsB, d.hdr + 2, d.PB, nullptr)) { printf("split launch failed\n"); exit(1); }
+    if (qamd_gemmh_split_launch(&sa, d.A, d.slotsA, d.hdr, d.PA, centre ? d.meanA : nullptr, nullptr) || qamd_gemmh_split_launch(&sb, d.B, d.slotsB, d.hdr + 2, d.PB, centre ? d.meanB : nullptr, nullptr)) { printf("split launch failed\n"); exit(1); }
     CK(hipEventRecord(e1));
-    if (qamd_gemmh_launch(ta, tb, &g, d.PA, d.PB, d.C, nullptr, nullptr, d.hdr, d.hdr + 2, nullptr, nullptr)) { printf("gemmh launch failed\n"); exit(1); }
+    if (qamd_gemmh_launch(ta, tb, &g, d.PA, d.PB, d.C, nullptr, nullptr, d.hdr, d.hdr + 2, centre ? d.meanA : nullptr, centre ? d.meanB : nullptr, nullptr, nullptr)) { printf("gemmh launch failed\n"); exit(1); }
     CK(hipEventRecord(e2));
-    if (qamd_gemmh_dot_launch(ta, tb, &g, d.PA, d.PB, d.T, d.hdr, d.hdr + 2, d.partial, nullptr)) { printf("dot launch failed\n"); exit(1); }
+    if (qamd_gemmh_dot_launch(ta, tb, &g, d.PA, d.PB, d.T, d.hdr, d.hdr + 2, centre ? d.meanA : nullptr, centre ? d.meanB : nullptr, d.partial, nullptr)) { printf("dot launch failed\n"); exit(1); }
     CK(hipEventRecord(e3));
     CK(hipDeviceSynchronize());
     if (it >= 2) {
@@ -111,11 +111,11 @@ static double run_case(int M, int N, int K, int ta, int tb, int iters, bool full
   for (double x : hp) dsum += x;
   for (size_t i = 0; i < hC.size(); ++i) dref += (double)hC[i] * hT[i];
   const double flop = 2.0 * M * N * K;
-  printf("%5d x %5d x %5d tile %dx%d fill %d: max-norm err vs fp64 %.2e (an fp32 fmaf chain: %.2e) over %zu entries%s; mean signed rel err %+.2e (fmaf chain %+.2e); dot rel diff %.2e; scales 2^%d 2^%d | split %.3f ms, product %.3f ms = %.1f TFLOP/s fp32-equivalent (%.0f on the f16 pipe), product + dot epilogue %.3f ms\n",
-         M, N, K, 64 * ta, 64 * tb, fill, worst, worst32, pts.size(), bad ? "  ** FAILED **" : "", bias, bias32, std::fabs(dsum - dref) / (std::fabs(dref) + 1e-300),
+  printf("%5d x %5d x %5d tile %dx%d fill %d %s: max-norm err vs fp64 %.2e (an fp32 fmaf chain: %.2e) over %zu entries%s; mean signed rel err %+.2e (fmaf chain %+.2e); dot rel diff %.2e; scales 2^%d 2^%d | split %.3f ms, product %.3f ms = %.1f TFLOP/s fp32-equivalent (%.0f on the f16 pipe), product + dot epilogue %.3f ms\n",
+         M, N, K, 64 * ta, 64 * tb, fill, centre ? "centred" : "as is", worst, worst32, pts.size(), bad ? "  ** FAILED **" : "", bias, bias32, std::fabs(dsum - dref) / (std::fabs(dref) + 1e-300),
          (int)std::log2(hdr[0]), (int)std::log2(hdr[2]), ms_split, ms_gemm, flop / ms_gemm * 1e-9, 3 * flop / ms_gemm * 1e-9, ms_dot);
   CK(hipFree(d.A)); CK(hipFree(d.B)); CK(hipFree(d.C)); CK(hipFree(d.T)); CK(hipFree(d.hdr)); CK(hipFree(d.slotsA)); CK(hipFree(d.slotsB));
-  CK(hipFree(d.PA)); CK(hipFree(d.PB)); CK(hipFree(d.partial));
+  CK(hipFree(d.PA)); CK(hipFree(d.PB)); CK(hipFree(d.meanA)); CK(hipFree(d.meanB)); CK(hipFree(d.partial));
   return bad;
 }
 
@@ -127,6 +127,7 @@ int main(int argc, char** argv) {
       bad += run_case(300, 520, 200, t[0], t[1], 1, true, 1, 0);
       bad += run_case(516, 260, 72, t[0], t[1], 1, true, 2, 1);
       bad += run_case(1000, 1000, 1024, t[0], t[1], 1, true, 3, 0);
+      bad += run_case(300, 520, 200, t[0], t[1], 1, true, 4, 0, false);
     }
     printf(bad ? "FAILED\n" : "all small cases OK\n");
     return bad ? 1 : 0;
@@ -134,6 +135,7 @@ int main(int argc, char** argv) {
   const int M = atoi(argv[1]), N = atoi(argv[2]), K = atoi(argv[3]);
   const int ta = argc > 4 ? atoi(argv[4]) : 4, tb = argc > 5 ? atoi(argv[5]) : 4, iters = argc > 6 ? atoi(argv[6]) : 5;
   const int fill = argc > 7 ? atoi(argv[7]) : 0;
-  bad = run_case(M, N, K, ta, tb, iters, false, 7, fill);
+  const bool centre = argc > 8 ? atoi(argv[8]) != 0 : true;
+  bad = run_case(M, N, K, ta, tb, iters, false, 7, fill, centre);
   return bad ? 1 : 0;
 }

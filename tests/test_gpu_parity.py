@@ -528,6 +528,56 @@ def test_quadrant_tree_full_size(hip):
     assert out == pytest.approx(m.to_numpy().item() * 10.0**e, rel=2e-6)
 
 
+def test_quadrant_tree_full_size_split_products(hip):
+    """The same four recorded full-size networks with the OPT-IN join arithmetic (``join_arith = "f16x3"``: both 7776^3 joins
+    as centred, split fp16 products on the f16 matrix pipe, the second one with the closing inner product in its epilogue)
+    against the fp64 oracle at the SAME bars as the fp32 MFMA path (1e-6; 1e-5 on the sign-mixed fill), and a rank-of-8
+    share of seed 7 against the fp32 path's value for the same share."""
+    import json
+    import os
+
+    from oracle import np_oracle as orc
+    import quimb_amd as qa
+    from quimb_amd.quadrants import QuadrantRank, QuadrantSharding
+
+    refs = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "full_size_oracle.json")))
+    arrays, inputs = orc.tn2d_rand(10, 10, 6, seed=7, dtype="float32")
+    size = {ix: 6 for t in inputs for ix in t}
+    tree = qa.ContractionTree(inputs, (), size, path=qa.quadrant_path_2d(10, 10))
+    opt = qa.get_options().replace(join_arith="f16x3")
+    ex = qa.TreeExecutor(tree, "float32", options=opt)
+    assert ex.plan[-1][0] == "pairdot"
+    hip.profile = []
+    try:
+        ex(arrays, strip_exponent=True)
+        names = [n for (_, _, n, _, _, _) in hip.profile]
+    finally:
+        hip.profile = None
+    assert sum(n.startswith("gemmh_kernel") for n in names) == 2 and not any(n.startswith("gemmk_kernel") for n in names), names
+    achieved = {}
+    for key, r in sorted(refs.items()):
+        if (r["Lx"], r["Ly"], r["D"]) != (10, 10, 6):
+            continue
+        seed, low = (key.split("@") + ["-0.1"])[:2]
+        arr_k, _ = orc.tn2d_rand(10, 10, 6, seed=int(seed), low=float(low), dtype="float32")
+        mk, ek = ex(arr_k, strip_exponent=True)
+        mk = mk.to_numpy().item()
+        achieved[key] = abs(10.0 ** (np.log10(abs(mk)) + ek - r["log10_abs"]) - 1.0)
+        assert np.sign(mk) == r["sign"], key
+        assert achieved[key] < (1e-6 if float(low) >= -0.1 else 1e-5), (key, achieved[key])
+    print("quadrant tree, split-product joins (f16x3), relative errors vs the fp64 oracle:", {k: f"{v:.2e}" for k, v in achieved.items()})
+    # one rank's share of eight (joins 1944 x 3888 x 7776): the two arithmetics agree on the block's value
+    sh = QuadrantSharding([tuple(t) for t in inputs], size, 10, 10, 8)
+    r = int(np.argmax(sh.cost_report()["per_rank_mults"]))
+    xs = sh.shard([qa.asarray(a) for a in arrays], r)
+    vals = {}
+    for mode in ("f32", "f16x3"):
+        with qa.exec_options(join_arith=mode):
+            m_, e_ = QuadrantRank(sh, r, "float32")(xs)
+        vals[mode] = m_.to_numpy().item() * 10.0 ** float(e_)
+    assert vals["f16x3"] == pytest.approx(vals["f32"], rel=1e-6), vals
+
+
 def test_found_tree_6x6_D6(hip):
     """A tree FOUND by the finders (recursive bisection / the time objective), not written down, executed on the
     device against the fp64 oracle: 6x6 D=6 fp32, with and without exponent stripping."""
