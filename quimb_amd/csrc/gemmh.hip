@@ -19,10 +19,11 @@
 //    whole workgroup tiles, K to a multiple of 32): a 1 KiB LDS-DMA piece is 64 consecutive x of one k-group, and a
 //    32x32x16 fragment read (lane = x, 8 consecutive k per half wave) is one conflict-free ds_read_b128.
 //  * gemmh_kernel: gemmk.hip's recipe on the f16 instruction: 2 x 2 waves, wave tile (32 TA) x (32 TB), operands
-//    HBM/L2 -> LDS by LDS-DMA only, a two-stage ring of 32-k stages (64 KB each at 256 x 256), ONE barrier per stage at its
-//    last k-step, the next step's fragments read behind the first MFMA of the current one, the request for stage t + 2
-//    one piece behind each MFMA after the barrier.  Per 16-k step a wave reads 2 (TA + TB) fragments and issues
-//    3 TA TB MFMAs (a1 b2, a2 b1, a1 b1 -- small terms first).
+//    HBM/L2 -> LDS by LDS-DMA only, a ring of 4 .. 6 stages of 16 k (32 KB each at 256 x 256: whatever fits 160 KB), ONE
+//    barrier per stage behind the step's first MFMA, the next step's fragments read right after it, the request for stage
+//    t + NS one piece behind each following MFMA, counted vmcnt (never 0 inside the loop): a stage is requested NS - 1
+//    steps before it is waited for.  Per 16-k step a wave reads 2 (TA + TB) fragments and issues 3 TA TB MFMAs
+//    (a1 b2, a2 b1, a1 b1 -- small terms first).
 //  * epilogue as gemmk.hip's: alpha * 2^-(ea + eb), absmax slot, or (DOT) the closing inner product with T.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -149,6 +150,14 @@ __global__ __launch_bounds__(256) void split_kernel(const SplitArgs p, const flo
   }
 }
 
+// ring depth of the product kernel: as many 16-k stages ([2 halves][2 k-groups][BM + BN columns][16 bytes]) as fit 160 KB of
+// LDS beside the tile's C-offset tables, at most 6 (the request counter)
+__host__ __device__ constexpr int hring_stages(int ta, int tb) {
+  const int stage = 64 * 64 * (ta + tb), tables = 8 * 64 * (ta + tb) + 64;
+  const int n = (160 * 1024 - tables) / stage;
+  return n > 6 ? 6 : n;
+}
+
 // ---- the product --------------------------------------------------------------------------------------------------------------
 // p.tiles_m / tiles_n: the tile grid (the images are padded to it), p.Kloop: K rounded up to 32 (the images' k extent),
 // p.M / p.N: the valid extents (epilogue), C addressed through p.dim_m / sc_m / dim_n / sc_n as in gemmk.hip.
@@ -159,11 +168,12 @@ __global__ __launch_bounds__(256, 1) void gemmh_kernel(const GettArgs p, const c
                                                        const float* __restrict__ hdrB, const double* __restrict__ meanA,
                                                        const double* __restrict__ meanB, float* __restrict__ absmax_out) {
   constexpr int BM = 64 * TA, BN = 64 * TB;
-  constexpr int SA = 2 * 4 * BM * 16, SB = 2 * 4 * BN * 16, STAGE = SA + SB;   // bytes: [half][4 k-groups][x][16]
-  constexpr int NP = 2 * TA + 2 * TB;                                           // LDS-DMA pieces per wave and stage
+  constexpr int SA = 2 * 2 * BM * 16, SB = 2 * 2 * BN * 16, STAGE = SA + SB;   // bytes of a 16-k stage: [half][2 k-groups][x][16]
+  constexpr int NS = hring_stages(TA, TB);                                      // ring depth: what fits 160 KB of LDS (4 .. 6)
+  constexpr int NP = TA + TB;                                                   // LDS-DMA pieces per wave and stage
   extern __shared__ __attribute__((aligned(16))) char hsmem[];
   char* stages = hsmem;
-  int64_t* offCm = reinterpret_cast<int64_t*>(hsmem + 2 * STAGE);
+  int64_t* offCm = reinterpret_cast<int64_t*>(hsmem + NS * STAGE);
   int64_t* offCn = offCm + BM;
 
   const int tid = threadIdx.x;
@@ -197,27 +207,28 @@ __global__ __launch_bounds__(256, 1) void gemmh_kernel(const GettArgs p, const c
     }
   }
 
-  // ---- LDS-DMA sources: wave w always fetches k-group w of a stage; piece (c, half): 64 rows x 16 bytes -----------------------
+  // ---- LDS-DMA sources: wave w always fetches (half w & 1, k-group w >> 1) of a stage, every 64-row chunk of it -------------
   const int64_t Mpad = (int64_t)p.tiles_m * BM, Npad = (int64_t)p.tiles_n * BN;
   const int64_t KG = p.Kloop >> 3;
-  const int64_t halfA = KG * Mpad * 16, halfB = KG * Npad * 16;
-  const int64_t stepA = 4 * Mpad * 16, stepB = 4 * Npad * 16;
-  const char* baseA = PA + ((int64_t)wave * Mpad + m0) * 16;
-  const char* baseB = PB + ((int64_t)wave * Npad + n0) * 16;
+  const int wh = wave & 1, wk = wave >> 1;
+  const int64_t stepA = 2 * Mpad * 16, stepB = 2 * Npad * 16;
+  const char* baseA0 = PA + (((int64_t)wh * KG + wk) * Mpad + m0) * 16;
+  const char* baseB0 = PB + (((int64_t)wh * KG + wk) * Npad + n0) * 16;
   const uint32_t lane16 = 16u * lane;
-  const int ntiles = (int)(KG >> 2);
+  const int nsteps = (int)(KG >> 1);          // 16-k steps (even: the images' k extent is a multiple of 32)
+  const int dstA = ((wh * 2 + wk) * BM) * 16, dstB = SA + ((wh * 2 + wk) * BN) * 16;
 
-  // piece q of a wave's NP: q < 2 TA: A piece (c = q / 2, half = q % 2), else B piece likewise
+  // piece q of a wave's NP for the stage whose sources are srcA_ / srcB_ into ring slot st_: q < TA: A chunk q, else B chunk q - TA
 #define QH_PIECE(q_, st_)                                                                                            \
   do {                                                                                                               \
-    if ((q_) < 2 * TA) {                                                                                             \
-      constexpr int c_ = ((q_) < 2 * TA ? (q_) : 0) / 2, h_ = (q_) % 2;                                              \
-      hglds(baseA + (h_ ? halfA : 0) + c_ * 1024 + lane16, stages + (st_) * STAGE + ((h_ * 4 + wave) * BM + 64 * c_) * 16); \
-    } else {                                                                                                         \
-      constexpr int c_ = ((q_) < 2 * TA ? 0 : (q_) - 2 * TA) / 2, h_ = (q_) % 2;                                     \
-      hglds(baseB + (h_ ? halfB : 0) + c_ * 1024 + lane16, stages + (st_) * STAGE + SA + ((h_ * 4 + wave) * BN + 64 * c_) * 16); \
-    }                                                                                                                \
+    if ((q_) < TA) hglds(srcA_ + (q_) * 1024 + lane16, stages + (st_) * STAGE + dstA + (q_) * 1024);                 \
+    else hglds(srcB_ + ((q_) - TA) * 1024 + lane16, stages + (st_) * STAGE + dstB + ((q_) - TA) * 1024);             \
   } while (0)
+  // sources of stage s_ (past the last stage: the last one again -- a slot nobody reads, but the request counts stay exact)
+#define QH_SOURCES(s_)                                                                                               \
+  const int64_t sc_ = (s_) < nsteps ? (s_) : nsteps - 1;                                                             \
+  const char* srcA_ = baseA0 + sc_ * stepA;                                                                          \
+  const char* srcB_ = baseB0 + sc_ * stepB
 
   acc16 acc[TA][TB];
 #pragma unroll
@@ -232,54 +243,51 @@ __global__ __launch_bounds__(256, 1) void gemmh_kernel(const GettArgs p, const c
   const int boff = SA + (kh * BN + wn * (32 * TB) + l31) * 16;
 
   h8 fa[2][2][TA], fb[2][2][TB];     // [buffer][half][sub-tile]
-  // fragments of 16-k step j_ of stage st_ into buffer b_
-#define QH_FRAGS(b_, st_, j_)                                                                                        \
+  // fragments of the stage in ring slot st_ into buffer b_
+#define QH_FRAGS(b_, st_)                                                                                            \
   do {                                                                                                               \
-    const char* As_ = stages + (st_) * STAGE + aoff + (j_) * (2 * BM * 16);                                          \
-    const char* Bs_ = stages + (st_) * STAGE + boff + (j_) * (2 * BN * 16);                                          \
+    const char* As_ = stages + (st_) * STAGE + aoff;                                                                 \
+    const char* Bs_ = stages + (st_) * STAGE + boff;                                                                 \
     _Pragma("unroll") for (int h = 0; h < 2; ++h) {                                                                  \
-      _Pragma("unroll") for (int i = 0; i < TA; ++i) fa[b_][h][i] = *reinterpret_cast<const h8*>(As_ + h * (4 * BM * 16) + i * 512); \
-      _Pragma("unroll") for (int j = 0; j < TB; ++j) fb[b_][h][j] = *reinterpret_cast<const h8*>(Bs_ + h * (4 * BN * 16) + j * 512); \
+      _Pragma("unroll") for (int i = 0; i < TA; ++i) fa[b_][h][i] = *reinterpret_cast<const h8*>(As_ + h * (2 * BM * 16) + i * 512); \
+      _Pragma("unroll") for (int j = 0; j < TB; ++j) fb[b_][h][j] = *reinterpret_cast<const h8*>(Bs_ + h * (2 * BN * 16) + j * 512); \
     }                                                                                                                \
   } while (0)
 
-  // ---- prologue: stages 0 and 1 requested, stage 0 awaited ------------------------------------------------------------------
-#define QH_ISSUE_ALL(st_)                                                                                            \
-  do {                                                                                                               \
-    QH_PIECE(0, st_); QH_PIECE(1, st_); QH_PIECE(2, st_); QH_PIECE(3, st_);                                          \
-    if (NP > 4) { QH_PIECE(4, st_); QH_PIECE(5, st_); }                                                              \
-    if (NP > 6) { QH_PIECE(6, st_); QH_PIECE(7, st_); }                                                              \
-    if (NP > 8) { QH_PIECE(8, st_); QH_PIECE(9, st_); }                                                              \
-    if (NP > 10) { QH_PIECE(10, st_); QH_PIECE(11, st_); }                                                           \
-    if (NP > 12) { QH_PIECE(12, st_); QH_PIECE(13, st_); }                                                           \
-    if (NP > 14) { QH_PIECE(14, st_); QH_PIECE(15, st_); }                                                           \
-  } while (0)
-  QH_ISSUE_ALL(0);
-  baseA += stepA;     // (the launcher guarantees >= 2 stages)
-  baseB += stepB;
-  QH_ISSUE_ALL(1);
-  baseA += (2 < ntiles) ? stepA : 0;
-  baseB += (2 < ntiles) ? stepB : 0;
-  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NP) : "memory");
+  // ---- prologue: the whole ring requested (stages 0 .. NS - 1), stage 0 awaited --------------------------------------------
+#pragma unroll
+  for (int s0 = 0; s0 < NS; ++s0) {
+    QH_SOURCES(s0);
+#pragma unroll
+    for (int q = 0; q < NP; ++q) {
+      if (q < TA) hglds(srcA_ + q * 1024 + lane16, stages + s0 * STAGE + dstA + q * 1024);
+      else hglds(srcB_ + (q - TA) * 1024 + lane16, stages + s0 * STAGE + dstB + (q - TA) * 1024);
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 1) * NP) : "memory");
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
-  QH_FRAGS(0, 0, 0);
+  QH_FRAGS(0, 0);
 
-  // one 16-k step on buffer b_: the first MFMA, then the reads of the NEXT step's fragments (RD_), then the rest; in the
-  // stage's last step (SYNC_) the barrier first and the request for stage t + 2 one piece behind each MFMA
+  // One 16-k step on fragment buffer b_ (stage t in ring slot st): the first MFMA; then the ONE barrier of the step -- behind
+  // it stage t + 1 has landed for every wave (this wave's pieces: all but the NS - 2 younger requests) and every wave holds
+  // stage t in registers, so its slot is free --; then the reads of stage t + 1's fragments and, one piece behind each of the
+  // following MFMAs, the request for stage t + NS into slot st.  A stage is requested NS - 1 steps (>= 3400 MFMA cycles) before
+  // the barrier that waits for it: with the two-stage ring of 32-k stages this kernel started with it was ONE stage, and the
+  // matrix pipes sat idle 40 % of the time waiting for the LDS-DMA (profiles/r06_gemmh_pmc.txt).
 #define QH_MFMA(i_, j_, ha_, hb_, b_) \
   acc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[b_][ha_][i_], fb[b_][hb_][j_], acc[i_][j_], 0, 0, 0)
-#define QH_STEP(b_, SYNC_, RD_)                                                                                      \
+#define QH_STEP(b_)                                                                                                  \
   do {                                                                                                               \
-    if (SYNC_) {                                                                                                     \
-      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                                    \
-      __builtin_amdgcn_s_barrier();                                                                                  \
-      asm volatile("" ::: "memory");                                                                                 \
-    }                                                                                                                \
+    const int stn_ = st + 1 >= NS ? 0 : st + 1;                                                                      \
+    QH_SOURCES(t + NS);                                                                                              \
     __builtin_amdgcn_sched_barrier(0);                                                                               \
     QH_MFMA(0, 0, 0, 1, b_);                                                                                         \
     __builtin_amdgcn_sched_barrier(0);                                                                               \
-    RD_;                                                                                                             \
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((NS - 2) * NP) : "memory");                                  \
+    __builtin_amdgcn_s_barrier();                                                                                    \
+    asm volatile("" ::: "memory");                                                                                   \
+    QH_FRAGS((b_) ^ 1, stn_);                                                                                        \
     __builtin_amdgcn_sched_barrier(0);                                                                               \
     _Pragma("unroll") for (int pr = 0; pr < 3; ++pr)                                                                 \
       _Pragma("unroll") for (int i = 0; i < TA; ++i) _Pragma("unroll") for (int j = 0; j < TB; ++j) {                \
@@ -288,39 +296,32 @@ __global__ __launch_bounds__(256, 1) void gemmh_kernel(const GettArgs p, const c
           if (pr == 0) QH_MFMA(i, j, 0, 1, b_);                                                                      \
           else if (pr == 1) QH_MFMA(i, j, 1, 0, b_);                                                                 \
           else QH_MFMA(i, j, 0, 0, b_);                                                                              \
-          if (SYNC_ && n_ - 1 < NP) {                                                                                \
+          if (n_ - 1 < NP) {                                                                                         \
             __builtin_amdgcn_sched_barrier(0);                                                                       \
             switch (n_ - 1) {                                                                                        \
               case 0: QH_PIECE(0, st); break;   case 1: QH_PIECE(1, st); break;                                      \
               case 2: QH_PIECE(2, st); break;   case 3: QH_PIECE(3, st); break;                                      \
               case 4: QH_PIECE(4, st); break;   case 5: QH_PIECE(5, st); break;                                      \
-              case 6: QH_PIECE(6, st); break;   case 7: QH_PIECE(7, st); break;                                      \
-              case 8: QH_PIECE(8, st); break;   case 9: QH_PIECE(9, st); break;                                      \
-              case 10: QH_PIECE(10, st); break; case 11: QH_PIECE(11, st); break;                                    \
-              case 12: QH_PIECE(12, st); break; case 13: QH_PIECE(13, st); break;                                    \
-              case 14: QH_PIECE(14, st); break; default: QH_PIECE(15, st); break;                                    \
+              case 6: QH_PIECE(6, st); break;   default: QH_PIECE(7, st); break;                                     \
             }                                                                                                        \
             __builtin_amdgcn_sched_barrier(0);                                                                       \
           }                                                                                                          \
         }                                                                                                            \
       }                                                                                                              \
     __builtin_amdgcn_sched_barrier(0);                                                                               \
+    st = stn_;                                                                                                       \
+    ++t;                                                                                                             \
   } while (0)
 
-  int st = 0;
-  for (int t = 0; t < ntiles; ++t) {
-    const int stn = st ^ 1;
-    QH_STEP(0, false, QH_FRAGS(1, st, 1));
-    QH_STEP(1, true, QH_FRAGS(0, stn, 0));
-    // the base never leaves the last stage: past it the request re-reads those rows (a stage nobody reads again)
-    baseA += (t + 3 < ntiles) ? stepA : 0;
-    baseB += (t + 3 < ntiles) ? stepB : 0;
-    st = stn;
+  int st = 0, t = 0;
+  while (t < nsteps) {
+    QH_STEP(0);
+    QH_STEP(1);
   }
 #undef QH_STEP
 #undef QH_MFMA
 #undef QH_FRAGS
-#undef QH_ISSUE_ALL
+#undef QH_SOURCES
 #undef QH_PIECE
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
@@ -426,7 +427,7 @@ template <int TA, int TB, bool DOT>
 static int launch_one(const GettArgs& a, const void* PA, const void* PB, void* C, const void* sa, const void* sb, const void* hdrA,
                       const void* hdrB, const void* meanA, const void* meanB, void* amax, hipStream_t st) {
   constexpr int BM = 64 * TA, BN = 64 * TB;
-  const size_t lds = (size_t)2 * 128 * (BM + BN) + (size_t)(BM + BN) * sizeof(int64_t);
+  const size_t lds = (size_t)hring_stages(TA, TB) * 64 * (BM + BN) + (size_t)(BM + BN) * sizeof(int64_t);
   (void)hipFuncSetAttribute((const void*)gemmh_kernel<TA, TB, DOT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   const unsigned grid = a.tiles_m * a.tiles_n;
   QAMD_LAUNCH((gemmh_kernel<TA, TB, DOT>), dim3(grid), dim3(256), lds, st, a, (const char*)PA, (const char*)PB, (float*)C,
