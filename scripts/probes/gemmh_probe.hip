@@ -128,6 +128,7 @@ int main(int argc, char** argv) {
       bad += run_case(516, 260, 72, t[0], t[1], 1, true, 2, 1);
       bad += run_case(1000, 1000, 1024, t[0], t[1], 1, true, 3, 0);
       bad += run_case(300, 520, 200, t[0], t[1], 1, true, 4, 0, false);
+      bad += run_case(301, 523, 136, t[0], t[1], 1, true, 5, 0);      // extents that are no multiples of 4: one column per thread in the split pass
     }
     printf(bad ? "FAILED\n" : "all small cases OK\n");
     return bad ? 1 : 0;

@@ -622,6 +622,7 @@ GEMMH_CASES = [
     ("xkm,kn->xmn", dict(x=2, k=256, m=160, n=384)),     # M = (x, m): an outer M group with its own stride
     ("km,kn->mn", dict(k=1296, m=1296, n=1296)),         # powers of 6: several tiles per CU on the small tiles
     ("km,kn->mn", dict(k=2048, m=256, n=256)),           # one tile, a long k loop
+    ("km,kn->mn", dict(k=260, m=301, n=523)),            # extents that are no multiples of 4: the split pass one column per thread
 ]
 
 
