@@ -244,7 +244,7 @@ def roofline_classes(prof_all, step_ms):
     return out
 
 
-def split_products_run(qa, dev, tree, xs, dtype, args, sync, ms_f32, flops_step):
+def split_products_run(qa, dev, tree, xs, dtype, args, sync, ms_f32, flops_step, shares=None):
     """The same contraction with the OPT-IN join arithmetic (quimb_amd.Options.join_arith = "f16x3", csrc/gemmh.hip): the two
     7776^3 joins as three exact fp16 products per multiply-add on the f16 matrix pipe, fp32 accumulation; everything else
     unchanged.  Reported BESIDE the headline, never as it: `value` / `roofline` above are the fp32 MFMA path's."""
@@ -281,7 +281,19 @@ def split_products_run(qa, dev, tree, xs, dtype, args, sync, ms_f32, flops_step)
                        "brackets": "the two split passes + the product (one C-ABI call)",
                        "tflops_algorithmic": nf / avg / 1e9, "tflops_executed_on_the_f16_pipe": 3 * nf / avg / 1e9,
                        "frac_of_f16_mfma_peak": 3 * nf / avg / 1e9 / MFMA_F16_PEAK_TF})
+        share_ms = None
+        if shares is not None:
+            # the busiest rank's share of an N-rank job under the same arithmetic (one GPU timing it, as `scaling_projection` does
+            # for the fp32 path): what the replicated corner rows leave of the faster joins
+            share_ms = {}
+            with qa.exec_options(join_arith="f16x3"):
+                for w_ in (2, 4, 8):
+                    try:
+                        share_ms[str(w_)] = shares(w_)
+                    except Exception as err:
+                        share_ms[str(w_)] = {"error": f"{type(err).__name__}: {err}"}
         return {
+            "busiest_rank_share_ms": share_ms,
             "what": "OPT-IN (Options.join_arith = 'f16x3'; default 'f32'): every fp32 operand of the two joins scaled by a power of "
                     "two and split into two fp16 halves (|x - h1 - h2| <= 2^-24 |x|), a b = a1 b1 + a1 b2 + a2 b1 with exact products "
                     "and fp32 accumulation on v_mfma_f32_32x32x16_f16; corner sweeps, exponents, layouts unchanged",
@@ -727,6 +739,27 @@ def main():
                                         "the chip to itself), an HIP event pair around every pairwise launch; the timed region "
                                         "overlaps the branches on parallel streams, so the shares can add up to more than 1")
         # ---- N = 1 extras (after the timed region): other BASELINE configs, what one rank of N = 2 / 4 / 8 costs -------
+        def share_ms_of(w_, with_report=False):
+            """ms per step of the busiest rank's share of a ``w_``-rank job on THIS GPU, under the options in force: what a rank of
+            `--gpus N` runs -- its share as a launch program, and a host read after every step (the collective needs the pair): a
+            SYNCHRONOUS step, not a pipelined one."""
+            sh_ = QuadrantSharding(inputs, size, args.Lx, args.Ly, w_)
+            rep_ = sh_.cost_report()
+            r_ = int(np.argmax(rep_["per_rank_mults"]))
+            qr_ = QuadrantRank(sh_, r_, dtype)
+            loc_ = sh_.shard([qa.asarray(a) for a in arrays], r_)
+            qr_.program(loc_)
+
+            def one_():
+                m_, e_ = qr_(loc_, defer=True)
+                return float(e_.cpu()[0]) if hasattr(e_, "cpu") else float(np.asarray(e_).reshape(-1)[0])
+
+            for _ in range(2):
+                one_()
+            t_, _ = _time_steps(one_, 8, sync)
+            del qr_, loc_
+            return (t_ * 1e3, rep_) if with_report else t_ * 1e3
+
         secondary = projection = None
         if mode == "single" and not args.no_secondary and (args.Lx, args.Ly) == (10, 10):
             sys.path.insert(0, os.path.join(ROOT, "scripts"))
@@ -747,32 +780,17 @@ def main():
                           "one_gpu_ms": ms}
             for w_ in (2, 4, 8):
                 try:
-                    sh_ = QuadrantSharding(inputs, size, args.Lx, args.Ly, w_)
-                    rep_ = sh_.cost_report()
-                    r_ = int(np.argmax(rep_["per_rank_mults"]))
-                    qr_ = QuadrantRank(sh_, r_, dtype)
-                    loc_ = sh_.shard([qa.asarray(a) for a in arrays], r_)
-                    # what a rank of `--gpus N` runs: its share as a launch program, and a host read after every step
-                    # (the collective needs the pair) -- a SYNCHRONOUS step, not a pipelined one
-                    qr_.program(loc_)
-
-                    def one_():
-                        m_, e_ = qr_(loc_, defer=True)
-                        return float(e_.cpu()[0]) if hasattr(e_, "cpu") else float(np.asarray(e_).reshape(-1)[0])
-
-                    for _ in range(2):
-                        one_()
-                    t_, _ = _time_steps(one_, 8, sync)
-                    projection[str(w_)] = {"grid": rep_["grid"], "busiest_rank_ms": t_ * 1e3, "speedup_vs_one_gpu": ms / (t_ * 1e3),
+                    t_ms_, rep_ = share_ms_of(w_, True)
+                    projection[str(w_)] = {"grid": rep_["grid"], "busiest_rank_ms": t_ms_, "speedup_vs_one_gpu": ms / t_ms_,
                                            "busiest_rank_fraction_of_flops": rep_["busiest_rank_fraction"],
                                            "step": "launch program + host read of the (mantissa, exponent) pair per step"}
-                    del qr_, loc_
                 except Exception as err:
                     projection[str(w_)] = {"error": f"{type(err).__name__}: {err}"}
         split16 = None
         if mode == "single" and not args.no_secondary and not dry_run and qa.get_options().join_arith == "f32" \
                 and tree is quad_tree:
-            split16 = split_products_run(qa, dev, tree, xs, dtype, args, sync, ms, flops_step)
+            split16 = split_products_run(qa, dev, tree, xs, dtype, args, sync, ms, flops_step,
+                                         shares=share_ms_of if (args.Lx, args.Ly) == (10, 10) else None)
         cpu = None if (args.no_cpu or world > 1 or emulate) else cpu_baseline(args.D, args.Ly, args.seed, Lx=args.Lx, full=not args.no_cpu_full)   # N=1 only
         nsl = plan.nslices if mode == "two_sided" else tree.nslices
         if mode == "single":

@@ -31,6 +31,8 @@
 
 #define QAMD_LAUNCH(...) do { (void)hipGetLastError(); hipLaunchKernelGGL(__VA_ARGS__); } while (0)
 
+#define QAMD_GEMMH_NY 32     // partial rows of a column's sums over k (the mean pass)
+
 namespace qamdh {
 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
@@ -75,39 +77,84 @@ __global__ __launch_bounds__(256) void habsmax_kernel(const SplitArgs p, const f
     atomicMax(reinterpret_cast<unsigned int*>(slots) + ((blockIdx.x * 4 + (threadIdx.x >> 6) + blockIdx.y) % QAMD_SLOTS), __float_as_uint(m));
 }
 
-// ---- column sums over k, in NY partial rows of doubles: part[y][x] = sum of X[k, x] over the y-th k range (no atomics: the
-// split pass adds the NY partials of a column in a fixed order) ------------------------------------------------------------------
+// ---- column sums over k, in NY partial rows of doubles: part[y][x] = sum of X[k, x] over the y-th k range, behind the NY rows
+// another NY of sum sqrt|X[k, x]| and NY of sum |X[k, x]| (no atomics: the split pass adds a column's partials in a fixed order) --
 __global__ __launch_bounds__(256) void hmean_kernel(const SplitArgs p, const float* __restrict__ X, double* __restrict__ part) {
   const uint32_t x = blockIdx.x * 256 + threadIdx.x;
   if (x >= p.Xpad) return;
-  double s = 0.0;
+  double s = 0.0;            // the column sum itself: exact to double precision (it goes into the result)
+  float r = 0.f, a1 = 0.f;   // the two sums the centring RULE looks at: fp32 is plenty (and deterministic)
   if (x < p.X) {
     const float* src = X + hdecomp(x, p.ng, p.dim, p.stride);
     const uint32_t per = (p.K + gridDim.y - 1) / gridDim.y;
     const uint32_t k0 = blockIdx.y * per, k1 = (k0 + per < p.K) ? k0 + per : p.K;
     uint32_t k = k0;
-    for (; k + 4 <= k1; k += 4) {
-      const float v0 = src[(int64_t)k * p.sk], v1 = src[(int64_t)(k + 1) * p.sk], v2 = src[(int64_t)(k + 2) * p.sk],
-                  v3 = src[(int64_t)(k + 3) * p.sk];
-      s += ((double)v0 + (double)v1) + ((double)v2 + (double)v3);
+    for (; k + 8 <= k1; k += 8) {
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = src[(int64_t)(k + j) * p.sk];
+      s += (((double)v[0] + (double)v[1]) + ((double)v[2] + (double)v[3])) + (((double)v[4] + (double)v[5]) + ((double)v[6] + (double)v[7]));
+      float rr = 0.f, aa = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float av = fabsf(v[j]);
+        aa += av;
+        rr += __builtin_sqrtf(av);
+      }
+      r += rr;
+      a1 += aa;
     }
-    for (; k < k1; ++k) s += (double)src[(int64_t)k * p.sk];
+    for (; k < k1; ++k) {
+      const float v = src[(int64_t)k * p.sk];
+      s += (double)v;
+      r += __builtin_sqrtf(fabsf(v));
+      a1 += fabsf(v);
+    }
   }
   part[(int64_t)blockIdx.y * p.Xpad + x] = s;
+  part[(int64_t)(gridDim.y + blockIdx.y) * p.Xpad + x] = (double)r;
+  part[(int64_t)(2 * gridDim.y + blockIdx.y) * p.Xpad + x] = (double)a1;
+}
+
+// ---- the centring constants: one thread per column adds the partials in a fixed order -------------------------------------------
+// mean[x] = the column's exact mean over k (double), cused[x] = the fp32 constant c the split pass subtracts: with ANY constants
+//   sum_k a b = sum_k (a - c)(b - d) + K (c bbar + d (abar - c)),
+// which the product kernel's epilogue adds back.  c = the mean where the column is COHERENT (|sum x| >= 0.75 sum |x|: only
+// same-sign sums carry the accumulate's bias; the sample mean of a sign-mixed column is noise) and the mean is TYPICAL of it;
+// where it is carried by outliers (heavy tails: |mean| above 1.5 .. 2 x the power mean (sum sqrt|x| / K)^2, which outliers
+// barely move) the constant shrinks to zero -- subtracting such a mean would turn every ordinary entry into a large one of
+// the same sign.
+__global__ __launch_bounds__(256) void hcentre_kernel(const SplitArgs p, const double* __restrict__ part, int ny,
+                                                      double* __restrict__ mean, float* __restrict__ cused) {
+  const uint32_t x = blockIdx.x * 256 + threadIdx.x;
+  if (x >= p.Xpad) return;
+  double sum = 0.0, rsum = 0.0, asum = 0.0;
+  for (int y = 0; y < ny; ++y) {                                            // (zeros for the padding columns)
+    sum += part[(int64_t)y * p.Xpad + x];
+    rsum += part[(int64_t)(ny + y) * p.Xpad + x];
+    asum += part[(int64_t)(2 * ny + y) * p.Xpad + x];
+  }
+  const double abar = sum / (double)p.K, rh = rsum / (double)p.K, mhalf = rh * rh;
+  double lam = 0.0;
+  if (mhalf > 0.0 && asum > 0.0) {
+    const double tails = (2.0 - fabs(abar) / mhalf) * 2.0;                // 1 up to |mean| = 1.5 x the power mean, 0 from 2 x
+    const double coherent = (fabs(sum) / asum - 0.5) * 4.0;                // 1 from |sum x| = 0.75 sum |x|, 0 below 0.5
+    lam = (tails < 0.0 ? 0.0 : (tails > 1.0 ? 1.0 : tails)) * (coherent < 0.0 ? 0.0 : (coherent > 1.0 ? 1.0 : coherent));
+  }
+  mean[x] = abar;
+  cused[x] = (float)(lam * abar);
 }
 
 // ---- the split pass ---------------------------------------------------------------------------------------------------------
 // hdr[0] = the power of two the operand was multiplied by, hdr[1] = its inverse.  Grid (ceil(Xpad / 256), k-group chunks).
-// part != NULL (ny partial rows): the operand is CENTRED first -- every column's mean over k (rounded to fp32) is subtracted
-// before the split and written to mean[x] as a double; the product kernel adds the rank-1 term back in its epilogue.
+// cused != NULL: the operand is CENTRED first -- the constant cused[x] (hcentre_kernel) is subtracted from every column.
 __global__ __launch_bounds__(256) void split_kernel(const SplitArgs p, const float* __restrict__ X, const float* __restrict__ slots,
-                                                    float* __restrict__ hdr, h8* __restrict__ P, const double* __restrict__ part,
-                                                    int ny, double* __restrict__ mean) {
+                                                    float* __restrict__ hdr, h8* __restrict__ P, const float* __restrict__ cused) {
   const int lane = threadIdx.x & 63;
   const float m = hread_scale(slots, lane);
   int q = 0;
   (void)frexpf(m, &q);                                 // m = f 2^q, f in [0.5, 1)  ->  m 2^(15 - q) in [2^14, 2^15)
-  if (part) q += 1;                                    // (|x - mean| <= 2 max|x|)
+  if (cused) q += 1;                                   // (|x - c| <= 2 max|x|)
   const bool fin = m > 0.f && m < 1.5e38f;
   const float scale = fin ? ldexpf(1.f, 15 - q) : 1.f;
   if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
@@ -117,14 +164,7 @@ __global__ __launch_bounds__(256) void split_kernel(const SplitArgs p, const flo
   const uint32_t x = blockIdx.x * 256 + threadIdx.x;
   if (x >= p.Xpad) return;
   const bool valid = x < p.X;
-  float ahat = 0.f;
-  if (part) {
-    double sum = 0.0;
-    for (int y = 0; y < ny; ++y) sum += part[(int64_t)y * p.Xpad + x];      // (fixed order; zeros for the padding columns)
-    const double abar = sum / (double)p.K;
-    ahat = (float)abar;
-    if (blockIdx.y == 0) mean[x] = abar;
-  }
+  const float ahat = cused ? cused[x] : 0.f;
   const float* src = X + (valid ? hdecomp(x, p.ng, p.dim, p.stride) : 0);
   const uint32_t per = (p.KG + gridDim.y - 1) / gridDim.y;
   const uint32_t kg0 = blockIdx.y * per, kg1 = (kg0 + per < p.KG) ? kg0 + per : p.KG;
@@ -167,6 +207,7 @@ __global__ __launch_bounds__(256, 1) void gemmh_kernel(const GettArgs p, const c
                                                        const float* __restrict__ scale_b, const float* __restrict__ hdrA,
                                                        const float* __restrict__ hdrB, const double* __restrict__ meanA,
                                                        const double* __restrict__ meanB, float* __restrict__ absmax_out) {
+  // (behind an operand's Xpad means: the 3 NY partial rows of the mean pass, then the Xpad constants actually subtracted)
   constexpr int BM = 64 * TA, BN = 64 * TB;
   constexpr int SA = 2 * 2 * BM * 16, SB = 2 * 2 * BN * 16, STAGE = SA + SB;   // bytes of a 16-k stage: [half][2 k-groups][x][16]
   constexpr int NS = hring_stages(TA, TB);                                      // ring depth: what fits 160 KB of LDS (4 .. 6)
@@ -326,18 +367,21 @@ __global__ __launch_bounds__(256, 1) void gemmh_kernel(const GettArgs p, const c
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
   // ---- epilogue: acc[i][j][r] = C[wm 32 TA + 32 i + (r & 3) + 8 (r >> 2) + 4 kh][wn 32 TB + 32 j + l31] -----------------------
-  // centred operands (meanA / meanB: the columns' means over k as doubles, zeros for the padding): with ah = fp32(abar),
+  // centred operands (meanA / meanB: the columns' means over k as doubles, zeros for the padding; usedA / usedB: the fp32
+  // constants ah, bh the split pass subtracted):
   //   sum_k a b = sum_k (a - ah)(b - bh) + K (ah bbar + bh (abar - ah))
-  // -- the MFMA sum is over sign-mixed terms of the size of the operands' FLUCTUATIONS, the part carried by the means is
+  // -- the MFMA sum is over sign-mixed terms of the size of the operands' FLUCTUATIONS, the part carried by the constants is
   // added here in double precision
   const float unscale = hdrA[1] * hdrB[1];
   const bool centred = meanA != nullptr;
+  const float* usedA = centred ? reinterpret_cast<const float*>(meanA + (int64_t)(3 * QAMD_GEMMH_NY + 1) * Mpad) : nullptr;
+  const float* usedB = centred ? reinterpret_cast<const float*>(meanB + (int64_t)(3 * QAMD_GEMMH_NY + 1) * Npad) : nullptr;
   double bbar[TB], bh[TB];
 #pragma unroll
   for (int j = 0; j < TB; ++j) {
-    const double v = centred ? meanB[n0 + wn * (32 * TB) + 32 * j + l31] : 0.0;
-    bbar[j] = v * (double)p.K;
-    bh[j] = (double)(float)v * (double)p.K;
+    const int g = n0 + wn * (32 * TB) + 32 * j + l31;
+    bbar[j] = centred ? meanB[g] * (double)p.K : 0.0;
+    bh[j] = centred ? (double)usedB[g] * (double)p.K : 0.0;
   }
   if constexpr (DOT) {
     // (a tile's epilogue has the CU to itself -- one workgroup per CU --, so T's values are requested a whole sub-tile row
@@ -374,7 +418,7 @@ __global__ __launch_bounds__(256, 1) void gemmh_kernel(const GettArgs p, const c
           dsum = __builtin_fmaf(acc[i][j][r], trow[j], dsum);
         }
         if (centred) {
-          const double abar = meanA[m0 + ml], ah = (double)(float)abar, ad = abar - ah;
+          const double abar = meanA[m0 + ml], ah = (double)usedA[m0 + ml], ad = abar - ah;
 #pragma unroll
           for (int j = 0; j < TB; ++j) dcorr += (ah * bbar[j] + ad * bh[j]) * (double)trow[j];
         }
@@ -401,7 +445,7 @@ __global__ __launch_bounds__(256, 1) void gemmh_kernel(const GettArgs p, const c
       double ah = 0.0, ad = 0.0;
       if (centred) {
         const double abar = meanA[m0 + ml];
-        ah = (double)(float)abar;
+        ah = (double)usedA[m0 + ml];
         ad = abar - ah;
       }
 #pragma unroll
@@ -441,12 +485,12 @@ static int launch_one(const GettArgs& a, const void* PA, const void* PB, void* C
 using namespace qamdh;
 
 #define QAMD_GEMMH_CASES QH_CASE(4, 4) QH_CASE(3, 4) QH_CASE(4, 3) QH_CASE(3, 3) QH_CASE(2, 4) QH_CASE(4, 2)
-#define QAMD_GEMMH_NY 32     // partial rows of the column sums
 
 // bytes of one operand's split images for free extent padded to ``xpad`` and K padded to ``kpad`` (a multiple of 32)
 extern "C" int64_t qamd_gemmh_image_bytes(int64_t xpad, int64_t kpad) { return 2 * (kpad / 8) * xpad * 16; }
 // bytes of one operand's column means (doubles) + the partial sums they are built from
-extern "C" int64_t qamd_gemmh_mean_bytes(int64_t xpad) { return (QAMD_GEMMH_NY + 1) * xpad * 8; }
+// (xpad means, 3 NY rows of partial sums, then xpad fp32 constants)
+extern "C" int64_t qamd_gemmh_mean_bytes(int64_t xpad) { return (3 * QAMD_GEMMH_NY + 1) * xpad * 8 + xpad * 4; }
 
 // absmax of a strided operand into 64 zeroed slots (callers without exponent slots)
 extern "C" int qamd_gemmh_absmax_launch(const SplitArgs* a, const void* X, void* slots, void* stream) {
@@ -458,22 +502,25 @@ extern "C" int qamd_gemmh_absmax_launch(const SplitArgs* a, const void* X, void*
 }
 
 // X (fp32, free bundle a->dim / a->stride, k stride a->sk) -> P[2][a->KG][a->Xpad][8] f16, hdr[0 .. 1] = scale, 1 / scale.
-// mean != NULL (qamd_gemmh_mean_bytes(a->Xpad) bytes: a->Xpad means, then the partial sums): the operand is centred -- every
-// column's mean over k is subtracted before the split; the product kernel is then handed the same pointer.
+// mean != NULL (qamd_gemmh_mean_bytes(a->Xpad) bytes: a->Xpad means, the partial sums, the constants subtracted): the operand
+// is centred (split_kernel); the product kernel is then handed the same pointer.
 extern "C" int qamd_gemmh_split_launch(const SplitArgs* a, const void* X, const void* slots, void* hdr, void* P, void* mean,
                                        void* stream) {
   if (!a || !X || !hdr || !P || a->KG == 0 || a->KG % 4 || a->Xpad < a->X || ((uintptr_t)P & 15) || ((uintptr_t)mean & 7)) return -2;
   const unsigned gx = (a->Xpad + 255) / 256;
   double* part = mean ? (double*)mean + a->Xpad : nullptr;
+  float* cused = mean ? reinterpret_cast<float*>((double*)mean + (int64_t)(3 * QAMD_GEMMH_NY + 1) * a->Xpad) : nullptr;
   if (mean) {
     QAMD_LAUNCH(hmean_kernel, dim3(gx, QAMD_GEMMH_NY), dim3(256), 0, (hipStream_t)stream, *a, (const float*)X, part);
+    QAMD_LAUNCH(hcentre_kernel, dim3(gx), dim3(256), 0, (hipStream_t)stream, *a, (const double*)part, QAMD_GEMMH_NY, (double*)mean,
+                cused);
     if (hipGetLastError() != hipSuccess) return -4;
   }
   unsigned gy = (8192 + gx - 1) / gx;                 // ~8 K workgroups, at least two k-groups each
   if (gy > a->KG / 2) gy = a->KG / 2;
   if (gy < 1) gy = 1;
   QAMD_LAUNCH(split_kernel, dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, *a, (const float*)X, (const float*)slots, (float*)hdr,
-              (h8*)P, (const double*)part, QAMD_GEMMH_NY, (double*)mean);
+              (h8*)P, (const float*)cused);
   return hipGetLastError() == hipSuccess ? 0 : -4;
 }
 

@@ -135,7 +135,7 @@ def test_split_product_joins_are_opt_in():
     assert p.kernel == 7 and name == "gemmh_kernel<3, 4> f16x3", name                     # 1271 tiles of 192 x 256: 4.96 rounds
     mpad, npad, kpad = 41 * 192, 31 * 256, 7776
     img = lambda x: 2 * (kpad // 8) * x * 16       # both fp16 halves, 16 bytes per (k-group of 8, column)
-    means = lambda x: (32 + 1) * x * 8            # a column's mean over k + the 32 partial sums it is built from, doubles
+    means = lambda x: (3 * 32 + 1) * x * 8 + 4 * x     # a column's mean (double), 3 x 32 partial sums (doubles), the fp32 constant subtracted
     assert lib.qamd_pair_workspace_bytes(C.byref(p)) == 1024 + means(mpad) + means(npad) + img(mpad) + img(npad)
     assert lib.qamd_pair_dot_workspace_bytes(C.byref(p)) == (8 * 41 * 31 + 255) // 256 * 256 + lib.qamd_pair_workspace_bytes(C.byref(p))
     name, p = _describe("km", (7776, 3888), "kn", (7776, 1944), "mn", pin=(-7, -1))       # one rank of eight: one round of 128 x 256
