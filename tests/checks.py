@@ -629,11 +629,11 @@ GEMMH_CASES = [
 def check_gemmh(seed=41, tiles=(None,)):
     """``join_arith = "f16x3"``: every fp32 operand of a large GEMM-shaped join is scaled by a power of two and split into two
     fp16 halves (2^-24 relative), the products a1 b1 + a1 b2 + a2 b1 are exact and accumulate in fp32 on the f16 MFMA; the
-    operands are CENTRED first (every column's mean over k subtracted, the rank-1 part K abar bbar added back in double
-    precision in the epilogue), so that the MFMA sums sign-mixed terms of the size of the fluctuations -- the f16
-    instruction's accumulate truncates aligned addends ~10 bits below the result's last place, which biased an all-positive
-    K = 7776 sum by -2e-7 before the centring.  Bar: the fp32 k-ordered chain's own (check_gemmk) times 1.5 (a column
-    whose mean is carried by one outlier adds |K abar bbar| <= ||a|| ||b|| to the magnitudes the roundings scale with).
+    operands are CENTRED first (a coherent column's mean over k subtracted -- sign-mixed or outlier-dominated columns keep
+    their values --, the part of the product the constants carry added back in double precision in the epilogue), so that
+    the MFMA sums sign-mixed terms of the size of the fluctuations -- the f16 instruction's accumulate truncates aligned
+    addends ~10 bits below the result's last place, which biased an all-positive K = 7776 sum by -2e-7 before the
+    centring.  Bar: the fp32 k-ordered chain's own (check_gemmk) times 1.5.
     ``tiles``: 10 ta + tb pinned through the plan inputs (kernel = -7, tile_cfg), None = the planner's.  Fills: the
     benchmark's mostly-positive one, a sign-mixed one with operands of very different scales, and a heavy-tailed one
     (entries down to 1e-8 of the largest)."""
