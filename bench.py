@@ -849,6 +849,9 @@ def main():
             out["dry_run"] = True
         if split16 is not None:
             out["split_products_f16x3"] = split16
+            if "value" in split16:      # (beside the headline, never as it: `value` above is the fp32 MFMA path's)
+                out["value_split_f16x3_opt_in"] = split16["value"]
+                out["ms_per_step_split_f16x3_opt_in"] = split16["ms_per_step"]
         if secondary is not None:
             out["secondary"] = secondary
         if projection is not None:
