@@ -665,6 +665,16 @@ def check_gemmh(seed=41, tiles=(None,)):
                     bound = 1.5 * 2 * np.sqrt(kk) * 2.0**-24 * np.max(np.einsum(eq, np.abs(a).astype(np.float64), np.abs(b).astype(np.float64)))
                     err = np.max(np.abs(got.to_numpy().astype(np.float64) - want))
                     assert got.shape == want.shape and err <= bound, (eq, tile, fill, err, bound)
+                    if tile is None and fill == "mostly positive" and kk >= 1024 and hasattr(dev, "describe_pair"):
+                        # the point of the centring: on coherent operands the split products are MORE accurate per entry than
+                        # the fp32 MFMA kernel (an fp32 fma chain of K terms), not merely within the same bar
+                        dev.force_kernel = None
+                        try:
+                            got32 = qa.einsum(eq, qa.asarray(a), qa.asarray(b))
+                        finally:
+                            dev.force_kernel = -7
+                        err32 = np.max(np.abs(got32.to_numpy().astype(np.float64) - want))
+                        assert err <= 0.5 * err32, (eq, fill, err, err32)
                     if hasattr(dev, "describe_pair") and hasattr(dev, "compile_pair"):
                         from quimb_amd.pairwise import plan_pair
 
