@@ -36,6 +36,9 @@
 
 #define QAMD_LAUNCH(...) do { (void)hipGetLastError(); hipLaunchKernelGGL(__VA_ARGS__); } while (0)
 
+#ifndef QAMD_GEMMH_BAND
+#define QAMD_GEMMH_BAND 4    // tile rows per band of the tile walk (an XCD's 32 workgroups share BAND A panels and 32 / BAND B panels)
+#endif
 #define QAMD_GEMMH_NY 32     // partial rows of a column's sums over k (the mean pass)
 
 namespace qamdh {
@@ -235,9 +238,9 @@ __global__ __launch_bounds__(256, 1) void gemmh_kernel(const GettArgs p, const c
     const uint32_t xcd = pid & 7, idx = pid >> 3;
     const uint32_t q = per_batch >> 3, r = per_batch & 7;
     const uint32_t s = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    const uint32_t band = 4 * p.tiles_n;
-    const uint32_t first_m = (s / band) * 4;
-    const uint32_t gsz = (p.tiles_m - first_m) < 4 ? (p.tiles_m - first_m) : 4;
+    const uint32_t band = QAMD_GEMMH_BAND * p.tiles_n;
+    const uint32_t first_m = (s / band) * QAMD_GEMMH_BAND;
+    const uint32_t gsz = (p.tiles_m - first_m) < QAMD_GEMMH_BAND ? (p.tiles_m - first_m) : QAMD_GEMMH_BAND;
     const uint32_t in_band = s % band;
     tm = first_m + in_band % gsz;
     tn = in_band / gsz;
