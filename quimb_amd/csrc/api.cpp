@@ -686,9 +686,9 @@ static const int kGemmhTiles[6][2] = {{4, 4}, {3, 4}, {4, 3}, {3, 3}, {2, 4}, {4
 static int64_t gemmh_kpad(int64_t K) { return (K + 31) / 32 * 32; }
 
 static bool gemmh_config(const qamd_pair_plan* p, const PairDims& d, int pin, int& ta, int& tb) {
-  if (p->dtype != QAMD_F32 || p->nk != 1 || p->nb != 0 || d.B != 1 || p->a_kcontig || p->b_kcontig) return false;
-  if (p->nm < 1 || p->nn < 1 || p->sa_m[p->nm - 1] != 1 || p->sb_n[p->nn - 1] != 1) return false;
-  if (p->sa_k[0] <= 0 || p->sb_k[0] <= 0) return false;
+  // (any operand layout: the split pass gathers with the operands' own strides -- coalesced for the k-outer joins, a slower
+  // pass for k-contiguous operands -- and the product kernel only ever sees the images)
+  if (p->dtype != QAMD_F32 || p->nk < 1 || p->nb != 0 || d.B != 1 || p->nm < 1 || p->nn < 1) return false;
   // (worth two extra passes over the operands only where the product dominates them; a pinned tile waives the floors down
   // to what the kernel needs: two 32-k stages)
   if (d.M >= (1ll << 31) || d.N >= (1ll << 31) || d.K >= (1ll << 31) || d.K < 33) return false;
@@ -721,7 +721,7 @@ static int launch_gemmh(const qamd_pair_plan* p, const PairDims& d, const void* 
                         void* dot_partial = nullptr, int* tiles_out = nullptr) {
   if (dot_T) C = const_cast<void*>(dot_T);
   const int ta = p->tile_cfg / 16, tb = p->tile_cfg % 16;
-  if (ta < 2 || ta > 4 || tb < 2 || tb > 4 || p->dtype != QAMD_F32 || p->nk != 1 || p->nb != 0 || !A || !B || !C) return QAMD_EINVAL;
+  if (ta < 2 || ta > 4 || tb < 2 || tb > 4 || p->dtype != QAMD_F32 || p->nk < 1 || p->nb != 0 || !A || !B || !C) return QAMD_EINVAL;
   if (!ws || ws_bytes < gemmh_workspace_bytes(p, d) || ((uintptr_t)ws & 15)) return QAMD_EWORKSPACE;
   const bool swap = !p->c_ncontig;
   GettArgs a;
@@ -735,6 +735,12 @@ static int launch_gemmh(const qamd_pair_plan* p, const PairDims& d, const void* 
   for (int i = 0; i < a.nm; ++i) { sm.dim[i] = a.dim_m[i]; sm.stride[i] = a.sa_m[i]; }
   for (int i = 0; i < a.nn; ++i) { sn.dim[i] = a.dim_n[i]; sn.stride[i] = a.sb_n[i]; }
   sm.sk = a.sa_k0; sn.sk = a.sb_k0;
+  sm.nk = sn.nk = p->nk;
+  for (int i = 0; i < p->nk; ++i) {
+    sm.dim_k[i] = sn.dim_k[i] = (uint32_t)p->dim_k[i];
+    sm.stride_k[i] = swap ? p->sb_k[i] : p->sa_k[i];
+    sn.stride_k[i] = swap ? p->sa_k[i] : p->sb_k[i];
+  }
   sm.X = a.M; sm.Xpad = a.tiles_m * 64 * ta; sn.X = a.N; sn.Xpad = a.tiles_n * 64 * tb;
   sm.K = sn.K = a.K; sm.KG = sn.KG = a.Kloop / 8;
   char* w = (char*)ws;

@@ -1,7 +1,8 @@
 // gemmh.hip -- the fp32 GEMM-shaped joins on the f16 matrix pipe: split products ("f16x3"), gfx950 only.  OPT-IN
 // (qamd_pair_plan.kernel = -7 on input; quimb_amd.Options.join_arith = "f16x3"): the default stays gemmk.hip on the fp32 MFMA.
 //
-//   C[m, n] = alpha * sum_k A[k, m] * B[k, n]                       (operands fp32, k-outer, as gemmk.hip takes them)
+//   C[m, n] = alpha * sum_k A[k, m] * B[k, n]         (operands fp32 with ANY strides: the split pass re-lays them out; the
+//                                                      k-outer joins gemmk.hip takes are the coalesced case it is tuned for)
 //
 // An fp32 value x, scaled by a power of two so that the operand's largest magnitude sits in [2^14, 2^15), is written as
 //   x = h1 + h2 + e,   h1 = fp16(x), h2 = fp16(x - h1),   |e| <= 2^-24 |x|   (two round-to-nearest steps of 11 bits each,
@@ -57,6 +58,11 @@ __device__ __forceinline__ int64_t hdecomp(uint32_t idx, int n, const uint32_t* 
   return off;
 }
 
+// source offset of contraction index k: one stride, or (several K groups) a decomposition
+__device__ __forceinline__ int64_t hkoff(const SplitArgs& p, uint32_t k) {
+  return p.nk <= 1 ? (int64_t)k * p.sk : hdecomp(k, p.nk, p.dim_k, p.stride_k);
+}
+
 // max over a tensor's 64 absmax slots (one per lane, wave reduction)
 __device__ __forceinline__ float hread_scale(const float* slots, int lane) {
   static_assert(QAMD_SLOTS == 64, "one slot per lane");
@@ -77,7 +83,7 @@ __global__ __launch_bounds__(256) void habsmax_kernel(const SplitArgs p, const f
   float m = 0.f;
   if (x < p.X) {
     const int64_t off = hdecomp(x, p.ng, p.dim, p.stride);
-    for (uint32_t k = blockIdx.y; k < p.K; k += gridDim.y) m = fmaxf(m, fabsf(X[(int64_t)k * p.sk + off]));
+    for (uint32_t k = blockIdx.y; k < p.K; k += gridDim.y) m = fmaxf(m, fabsf(X[hkoff(p, k) + off]));
   }
 #pragma unroll
   for (int d = 32; d > 0; d >>= 1) m = fmaxf(m, __shfl_xor(m, d, 64));
@@ -100,7 +106,7 @@ __global__ __launch_bounds__(256) void hmean_kernel(const SplitArgs p, const flo
     for (; k + 8 <= k1; k += 8) {
       float v[8];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] = src[(int64_t)(k + j) * p.sk];
+      for (int j = 0; j < 8; ++j) v[j] = src[hkoff(p, k + j)];
       s += (((double)v[0] + (double)v[1]) + ((double)v[2] + (double)v[3])) + (((double)v[4] + (double)v[5]) + ((double)v[6] + (double)v[7]));
       float rr = 0.f, aa = 0.f;
 #pragma unroll
@@ -113,7 +119,7 @@ __global__ __launch_bounds__(256) void hmean_kernel(const SplitArgs p, const flo
       a1 += aa;
     }
     for (; k < k1; ++k) {
-      const float v = src[(int64_t)k * p.sk];
+      const float v = src[hkoff(p, k)];
       s += (double)v;
       r += __builtin_sqrtf(fabsf(v));
       a1 += fabsf(v);
@@ -184,7 +190,7 @@ __global__ __launch_bounds__(256) void split_kernel(const SplitArgs p, const flo
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const uint32_t k = 8 * kg + j;
-      v[j] = (valid && k < p.K) ? (src[(int64_t)k * p.sk] - ahat) * scale : 0.f;
+      v[j] = (valid && k < p.K) ? (src[hkoff(p, k)] - ahat) * scale : 0.f;
     }
     h8 a, b;
 #pragma unroll
@@ -509,7 +515,7 @@ extern "C" int qamd_gemmh_absmax_launch(const SplitArgs* a, const void* X, void*
   return hipGetLastError() == hipSuccess ? 0 : -4;
 }
 
-// X (fp32, free bundle a->dim / a->stride, k stride a->sk) -> P[2][a->KG][a->Xpad][8] f16, hdr[0 .. 1] = scale, 1 / scale.
+// X (fp32, free bundle a->dim / a->stride, k stride a->sk or the K groups a->dim_k / a->stride_k) -> P[2][a->KG][a->Xpad][8] f16, hdr[0 .. 1] = scale, 1 / scale.
 // mean != NULL (qamd_gemmh_mean_bytes(a->Xpad) bytes: a->Xpad means, the partial sums, the constants subtracted): the operand
 // is centred (split_kernel); the product kernel is then handed the same pointer.
 extern "C" int qamd_gemmh_split_launch(const SplitArgs* a, const void* X, const void* slots, void* hdr, void* P, void* mean,

@@ -88,9 +88,12 @@ struct SplitArgs {
   int32_t ng, pad_;
   uint32_t dim[QAMD_G];
   int64_t stride[QAMD_G];
-  int64_t sk;            // element stride of k in the source
+  int64_t sk;            // element stride of k in the source (nk <= 1)
   uint32_t X, Xpad;      // free extent, and padded to whole workgroup tiles
   uint32_t K, KG;        // contraction extent, and k-groups of 8 in the image (K rounded up to 32, / 8)
+  int32_t nk, pad2_;     // nk > 1: the contraction bundle in several groups (outermost first), k -> offset by decomposition
+  uint32_t dim_k[QAMD_G];
+  int64_t stride_k[QAMD_G];
 };
 
 struct KtabArgs {

@@ -52,5 +52,30 @@ for (K, M, N) in ((512, 384, 640), (1296, 1296, 216)):
     ok = res["f16x3"] < max(2e-6, 2 * res["f32"])
     bad += not ok
     print(f"complex64 km({K}, {M}) x kn({K}, {N}) -> mn: max-norm err vs complex128: f16x3 {res['f16x3']:.2e}, fp32 MFMA path {res['f32']:.2e}  {'ok' if ok else '** FAILED **'}")
+# timing of whole calls (split passes included) for the four operand layouts of a square product, both arithmetics
+import torch
+for n in (4096, 8192):
+    for ai, bi in (("km", "kn"), ("mk", "kn"), ("km", "nk"), ("mk", "nk")):
+        a = qa.asarray(rng.uniform(-0.1, 1, (n, n)).astype(np.float32))
+        b = qa.asarray(rng.uniform(-0.1, 1, (n, n)).astype(np.float32))
+        line = f"{ai},{bi}->mn {n}^3:"
+        for mode in ("f32", "f16x3"):
+            with qa.exec_options(join_arith=mode):
+                for _ in range(2):
+                    qa.einsum(f"{ai},{bi}->mn", a, b)
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(5):
+                    qa.einsum(f"{ai},{bi}->mn", a, b)
+                e1.record()
+                torch.cuda.synchronize()
+                ms = e0.elapsed_time(e1) / 5
+                from quimb_amd.pairwise import plan_pair
+                step = plan_pair(tuple(ai), (n, n), tuple(bi), (n, n), ("m", "n"), True)
+                name = dev.describe_pair(dev.compile_pair(step.spec, np.dtype("float32")))
+            line += f"  {mode}: {ms:.3f} ms = {2 * n**3 / ms * 1e-9:.0f} TFLOP/s ({name.split('<')[0]})"
+        print(line)
+        del a, b
 print("FAILED" if bad else "all ok")
 sys.exit(1 if bad else 0)

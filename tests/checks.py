@@ -622,7 +622,12 @@ GEMMH_CASES = [
     ("xkm,kn->xmn", dict(x=2, k=256, m=160, n=384)),     # M = (x, m): an outer M group with its own stride
     ("km,kn->mn", dict(k=1296, m=1296, n=1296)),         # powers of 6: several tiles per CU on the small tiles
     ("km,kn->mn", dict(k=2048, m=256, n=256)),           # one tile, a long k loop
-    ("km,kn->mn", dict(k=260, m=301, n=523)),            # extents that are no multiples of 4: the split pass one column per thread
+    ("km,kn->mn", dict(k=260, m=301, n=523)),            # extents that are no multiples of 4
+    ("mk,kn->mn", dict(k=300, m=516, n=260)),            # A contiguous along k (the split pass gathers: any layout is covered)
+    ("km,nk->mn", dict(k=264, m=300, n=520)),            # B contiguous along k
+    ("mk,nk->nm", dict(k=288, m=320, n=264)),            # both, roles swapped
+    ("muk,kun->mn", dict(k=12, u=24, m=300, n=264)),     # K in two groups whose order differs between the operands
+    ("amk,kbn->abmn", dict(k=256, a=3, m=100, b=2, n=140)),    # free bundles in two groups around k
 ]
 
 

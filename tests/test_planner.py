@@ -145,9 +145,14 @@ def test_split_product_joins_are_opt_in():
     name, p = _describe("km", (300, 7000), "kn", (300, 5000), "mn", pin=(-7, -1))         # K % 32 != 0: zero-padded images
     assert p.kernel == 7 and lib.qamd_pair_workspace_bytes(C.byref(p)) > 0
     # not covered -> the automatic choice, as if the pin were 0
+    # any operand layout is covered (the split pass gathers with the operands' own strides): k-contiguous operands, K in groups
+    for args in (("mk", (2048, 512), "kn", (512, 2048), "mn"), ("km", (512, 2048), "nk", (2048, 512), "mn"),
+                 ("mk", (2048, 512), "nk", (2048, 512), "nm"), ("muk", (2048, 24, 32), "kun", (32, 24, 2048), "mn")):
+        name7, p7 = _describe(*args, pin=(-7, -1))
+        assert p7.kernel == 7 and name7.startswith("gemmh_kernel<"), (args, name7)
     for args, kw in ((("km", (128, 4096), "kn", (128, 4096), "mn"), {}),                  # K < 256: not worth the split pass
                      (("km", (512, 2048), "kn", (512, 200), "mn"), {}),                   # N < 256
-                     (("mk", (2048, 512), "kn", (512, 2048), "mn"), {}),                  # A contiguous along k
+                     (("hvm", (6, 6, 46656), "hxvy", (6, 6, 6, 6), "mxy"), {}),           # big x small: the streaming kernels
                      (("bkm", (3, 512, 512), "bkn", (3, 512, 512), "bmn"), {}),           # batch bundle
                      (("km", (512, 2048), "kn", (512, 2048), "mn"), dict(dtype="float64"))):
         name7, p7 = _describe(*args, pin=(-7, -1), **kw)
