@@ -204,6 +204,101 @@ __global__ __launch_bounds__(256) void split_kernel(const SplitArgs p, const flo
   }
 }
 
+// ---- the same two passes for K-CONTIGUOUS sources (the innermost K group stride-1 in multiples of 8, everything 16-byte aligned:
+// row-major A[m, k]): a thread reads the 32 contiguous bytes of one (column, k-group), 16 lanes a 512-byte run of a column --
+// and the split pass transposes through LDS, so that its stores are the same 1 KiB runs of consecutive columns --------------
+typedef float hf4 __attribute__((ext_vector_type(4)));
+
+// 16 columns per workgroup, 16 lanes along k per column; grid (Xpad / 16, NY)
+__global__ __launch_bounds__(256) void hmean_kc_kernel(const SplitArgs p, const float* __restrict__ X, double* __restrict__ part) {
+  const uint32_t x = blockIdx.x * 16 + (threadIdx.x >> 4);
+  const uint32_t kq = threadIdx.x & 15;
+  double s = 0.0;
+  float r = 0.f, a1 = 0.f;
+  const uint32_t KGv = p.K >> 3;                                  // whole k-groups of the source (K % 8 == 0 here)
+  const uint32_t per = (KGv + gridDim.y - 1) / gridDim.y;
+  const uint32_t g0 = blockIdx.y * per, g1 = (g0 + per < KGv) ? g0 + per : KGv;
+  if (x < p.X) {
+    const float* src = X + hdecomp(x, p.ng, p.dim, p.stride);
+    for (uint32_t g = g0 + kq; g < g1; g += 16) {
+      const hf4* q = reinterpret_cast<const hf4*>(src + hkoff(p, 8 * g));
+      const hf4 v0 = q[0], v1 = q[1];
+      s += (((double)v0[0] + (double)v0[1]) + ((double)v0[2] + (double)v0[3])) + (((double)v1[0] + (double)v1[1]) + ((double)v1[2] + (double)v1[3]));
+      float rr = 0.f, aa = 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float b0 = fabsf(v0[j]), b1 = fabsf(v1[j]);
+        aa += b0 + b1;
+        rr += __builtin_sqrtf(b0) + __builtin_sqrtf(b1);
+      }
+      r += rr;
+      a1 += aa;
+    }
+  }
+#pragma unroll
+  for (int d = 8; d > 0; d >>= 1) {                                // the 16 lanes of a column, fixed order
+    s += __shfl_xor(s, d, 64);
+    r += __shfl_xor(r, d, 64);
+    a1 += __shfl_xor(a1, d, 64);
+  }
+  if (kq == 0 && x < p.Xpad) {
+    part[(int64_t)blockIdx.y * p.Xpad + x] = s;
+    part[(int64_t)(gridDim.y + blockIdx.y) * p.Xpad + x] = (double)r;
+    part[(int64_t)(2 * gridDim.y + blockIdx.y) * p.Xpad + x] = (double)a1;
+  }
+}
+
+// a workgroup: 64 columns x 16 k-groups; grid (Xpad / 64, ceil(KG / 16))
+__global__ __launch_bounds__(256) void split_kc_kernel(const SplitArgs p, const float* __restrict__ X, const float* __restrict__ slots,
+                                                       float* __restrict__ hdr, h8* __restrict__ P, const float* __restrict__ cused) {
+  __shared__ h8 tile[2][16][65];                                   // [half][k-group][column (+1: the transposing accesses)]
+  const int lane = threadIdx.x & 63;
+  const float m = hread_scale(slots, lane);
+  int q = 0;
+  (void)frexpf(m, &q);
+  if (cused) q += 1;
+  const bool fin = m > 0.f && m < 1.5e38f;
+  const float scale = fin ? ldexpf(1.f, 15 - q) : 1.f;
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+    hdr[0] = scale;
+    hdr[1] = fin ? ldexpf(1.f, q - 15) : 1.f;
+  }
+  const uint32_t x0 = blockIdx.x * 64, g0 = blockIdx.y * 16;
+  const uint32_t kq = threadIdx.x & 15, r0 = threadIdx.x >> 4;
+  const uint32_t g = g0 + kq;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const uint32_t row = r0 + 16 * i, x = x0 + row;
+    h8 a, b;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { a[j] = (_Float16)0.f; b[j] = (_Float16)0.f; }
+    if (x < p.X && 8 * g < p.K) {
+      const hf4* src = reinterpret_cast<const hf4*>(X + hdecomp(x, p.ng, p.dim, p.stride) + hkoff(p, 8 * g));
+      const hf4 v0 = src[0], v1 = src[1];
+      const float c = cused ? cused[x] : 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float xv = ((j < 4 ? v0[j & 3] : v1[j & 3]) - c) * scale;
+        const _Float16 h = (_Float16)xv;
+        a[j] = h;
+        b[j] = (_Float16)(xv - (float)h);
+      }
+    }
+    tile[0][kq][row] = a;
+    tile[1][kq][row] = b;
+  }
+  __syncthreads();
+  const uint32_t xc = threadIdx.x & 63, gq = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const uint32_t gg = gq + 4 * i;
+    if (g0 + gg < p.KG && x0 + xc < p.Xpad) {
+      P[(int64_t)(g0 + gg) * p.Xpad + x0 + xc] = tile[0][gg][xc];
+      P[((int64_t)p.KG + g0 + gg) * p.Xpad + x0 + xc] = tile[1][gg][xc];
+    }
+  }
+}
+
 // ring depth of the product kernel: as many 16-k stages ([2 halves][2 k-groups][BM + BN columns][16 bytes]) as fit 160 KB of
 // LDS beside the tile's C-offset tables, at most 6 (the request counter)
 __host__ __device__ constexpr int hring_stages(int ta, int tb) {
@@ -524,11 +619,27 @@ extern "C" int qamd_gemmh_split_launch(const SplitArgs* a, const void* X, const 
   const unsigned gx = (a->Xpad + 255) / 256;
   double* part = mean ? (double*)mean + a->Xpad : nullptr;
   float* cused = mean ? reinterpret_cast<float*>((double*)mean + (int64_t)(3 * QAMD_GEMMH_NY + 1) * a->Xpad) : nullptr;
+  // k-contiguous sources (16-byte loads along k, LDS-transposed stores): the innermost K group stride-1 in multiples of 8,
+  // every other stride and the base pointer 16-byte aligned
+  bool kc = ((uintptr_t)X & 15) == 0 && a->K % 8 == 0;
+  if (a->nk >= 1) {
+    kc = kc && a->stride_k[a->nk - 1] == 1 && a->dim_k[a->nk - 1] % 8 == 0;
+    for (int g = 0; g + 1 < a->nk; ++g) kc = kc && a->stride_k[g] % 4 == 0;
+  } else {
+    kc = kc && a->sk == 1;
+  }
+  for (int g = 0; g < a->ng; ++g) kc = kc && a->stride[g] % 4 == 0;
   if (mean) {
-    QAMD_LAUNCH(hmean_kernel, dim3(gx, QAMD_GEMMH_NY), dim3(256), 0, (hipStream_t)stream, *a, (const float*)X, part);
+    if (kc) QAMD_LAUNCH(hmean_kc_kernel, dim3((a->Xpad + 15) / 16, QAMD_GEMMH_NY), dim3(256), 0, (hipStream_t)stream, *a, (const float*)X, part);
+    else QAMD_LAUNCH(hmean_kernel, dim3(gx, QAMD_GEMMH_NY), dim3(256), 0, (hipStream_t)stream, *a, (const float*)X, part);
     QAMD_LAUNCH(hcentre_kernel, dim3(gx), dim3(256), 0, (hipStream_t)stream, *a, (const double*)part, QAMD_GEMMH_NY, (double*)mean,
                 cused);
     if (hipGetLastError() != hipSuccess) return -4;
+  }
+  if (kc) {
+    QAMD_LAUNCH(split_kc_kernel, dim3((a->Xpad + 63) / 64, (a->KG + 15) / 16), dim3(256), 0, (hipStream_t)stream, *a, (const float*)X,
+                (const float*)slots, (float*)hdr, (h8*)P, (const float*)cused);
+    return hipGetLastError() == hipSuccess ? 0 : -4;
   }
   unsigned gy = (8192 + gx - 1) / gx;                 // ~8 K workgroups, at least two k-groups each
   if (gy > a->KG / 2) gy = a->KG / 2;

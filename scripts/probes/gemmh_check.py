@@ -39,7 +39,8 @@ for fill in ("uniform", "signed", "wide"):
         ok = res["f16x3"] < max(2e-6, 2 * res["f32"])
         bad += not ok
         print(f"{fill:8s} {ai}{ash} x {bi}{bsh} -> {oi}: {name:34s} max-norm err vs fp64: f16x3 {res['f16x3']:.2e}, fp32 MFMA path {res['f32']:.2e}  {'ok' if ok else '** FAILED **'}")
-# complex operands: 2 x 2 real blocks on the real kernels (ops.complex_expand) -- the expanded pair is an fp32 join like any other
+# complex operands: 2 x 2 real blocks on the real kernels (ops.complex_expand) -- kept OFF the split products on purpose (columns of
+# alternating sign that no per-column constant centres: ops._complex_gett): both modes must give the same numbers
 for (K, M, N) in ((512, 384, 640), (1296, 1296, 216)):
     a = (rng.uniform(-0.1, 1, (K, M)) + 1j * rng.uniform(-0.1, 1, (K, M))).astype(np.complex64)
     b = (rng.uniform(-0.1, 1, (K, N)) + 1j * rng.uniform(-1, 0.1, (K, N))).astype(np.complex64)

@@ -628,6 +628,8 @@ GEMMH_CASES = [
     ("mk,nk->nm", dict(k=288, m=320, n=264)),            # both, roles swapped
     ("muk,kun->mn", dict(k=12, u=24, m=300, n=264)),     # K in two groups whose order differs between the operands
     ("amk,kbn->abmn", dict(k=256, a=3, m=100, b=2, n=140)),    # free bundles in two groups around k
+    ("mk,kn->mn", dict(k=1024, m=520, n=300)),           # ... and the k-contiguous passes proper (K % 8 == 0: 16-byte loads along k,
+    ("muk,nuk->mn", dict(k=16, u=20, m=300, n=264)),     #     LDS-transposed stores), K in two groups with the inner one a multiple of 8
 ]
 
 
