@@ -138,6 +138,10 @@ def test_split_product_joins_are_opt_in():
     means = lambda x: (3 * 32 + 1) * x * 8 + 4 * x     # a column's mean (double), 3 x 32 partial sums (doubles), the fp32 constant subtracted
     assert lib.qamd_pair_workspace_bytes(C.byref(p)) == 1024 + means(mpad) + means(npad) + img(mpad) + img(npad)
     assert lib.qamd_pair_dot_workspace_bytes(C.byref(p)) == (8 * 41 * 31 + 255) // 256 * 256 + lib.qamd_pair_workspace_bytes(C.byref(p))
+    # without its workspace the call is refused before anything is launched (host logic: no device needed)
+    one = (C.c_float * 4)()
+    assert lib.qamd_contract_pair_ex(C.byref(p), one, one, one, None, None, 0, None, None) == -3          # QAMD_EWORKSPACE
+    assert lib.qamd_contract_pair_dot(C.byref(p), one, one, one, one, None, 0, None, None, None) == -3
     name, p = _describe("km", (7776, 3888), "kn", (7776, 1944), "mn", pin=(-7, -1))       # one rank of eight: one round of 128 x 256
     assert name in ("gemmh_kernel<4, 2> f16x3", "gemmh_kernel<2, 4> f16x3"), name
     name, p = _describe("km", (8192, 8192), "kn", (8192, 8192), "mn", pin=(-7, 16 * 4 + 4))
