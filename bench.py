@@ -275,9 +275,17 @@ def split_products_run(qa, dev, tree, xs, dtype, args, sync, ms_f32, flops_step,
             j[0] += e0.elapsed_time(e1)
             j[1] += 1
         jl = []
+        traffic = None
+        try:      # HBM bytes of the product launch from the committed PMC passes (profiles/r06_gemmh_traffic.json)
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r06_gemmh_traffic.json")))
+            traffic = {"hbm_bytes_per_product_launch": tj["hbm_bytes_per_launch"], "algorithmic_bytes": tj["algorithmic_bytes_per_launch"],
+                       "shape": tj["shape"], "source": "profiles/r06_gemmh_traffic.json"}
+        except Exception:
+            pass
         for name, (tsum, cnt, (shape, _nb, nf)) in sorted(joins.items()):
             avg = tsum / cnt
             jl.append({"kernel": name, "shape": shape, "launches_timed": cnt, "avg_launch_ms": avg,
+                       "traffic": traffic if (traffic and traffic["shape"] == shape) else None,
                        "brackets": "the two split passes + the product (one C-ABI call)",
                        "tflops_algorithmic": nf / avg / 1e9, "tflops_executed_on_the_f16_pipe": 3 * nf / avg / 1e9,
                        "frac_of_f16_mfma_peak": 3 * nf / avg / 1e9 / MFMA_F16_PEAK_TF})
