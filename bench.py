@@ -269,7 +269,7 @@ def split_products_run(qa, dev, tree, xs, dtype, args, sync, ms_f32, flops_step,
         res16 = (r16[0].item(), r16[1] if isinstance(r16[1], float) else dev.read_exponent(r16[1]))
         joins = {}
         for spec, _, name, _, e0, e1 in prof16:
-            if not name.startswith("gemmh_kernel"):
+            if not name.startswith("gemmh"):
                 continue
             j = joins.setdefault(name, [0.0, 0, _launch_work(spec)])
             j[0] += e0.elapsed_time(e1)
@@ -705,7 +705,7 @@ def main():
             # the roof that bounds this launch: min(MFMA peak, AI x HBM peak)
             if ai < MFMA_F32_PEAK_TF * 1e12 / (HBM_PEAK_GBS * 1e9):
                 roof = {"bound": "hbm", "achieved": bytes_launch / avg / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s"}
-            elif cfg.startswith("gemmh_kernel"):
+            elif cfg.startswith("gemmh"):
                 # split products (opt-in): three f16 MFMA products per algorithmic multiply-add; the event pair brackets the
                 # two split passes + the product
                 roof = {"bound": "mfma", "achieved": 3 * flops_launch / avg / 1e12, "peak": MFMA_F16_PEAK_TF, "unit": "TFLOP/s",

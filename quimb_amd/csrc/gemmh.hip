@@ -30,6 +30,9 @@
 //    t + NS one piece behind each following MFMA, counted vmcnt (never 0 inside the loop): a stage is requested NS - 1
 //    steps before it is waited for.  Per 16-k step a wave reads 2 (TA + TB) fragments and issues 3 TA TB MFMAs
 //    (a1 b2, a2 b1, a1 b1 -- small terms first).
+//  * gemmh8_kernel (even tiles: 256 x 256, 128 x 256, 256 x 128): the same ring with EIGHT waves in two groups that run half a step
+//    apart -- while one group issues its step's MFMAs at raised priority, the other reads its fragments and requests a later
+//    stage: 7776^3 2.43 -> 2.30 ms, zero operands 1718 -> 1890 TFLOP/s (75 % of the f16 peak).
 //  * epilogue as gemmk.hip's: alpha * 2^-(ea + eb), absmax slot, or (DOT) the closing inner product with T.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -39,6 +42,9 @@
 
 #ifndef QAMD_GEMMH_BAND
 #define QAMD_GEMMH_BAND 4    // tile rows per band of the tile walk (an XCD's 32 workgroups share BAND A panels and 32 / BAND B panels)
+#endif
+#ifndef QAMD_GEMMH_W8
+#define QAMD_GEMMH_W8 1       // even tiles run the eight-wave, two-group kernel (gemmh8_kernel): +6 % at 7776^3; 0 = gemmh_kernel for every tile
 #endif
 #define QAMD_GEMMH_NY 32     // partial rows of a column's sums over k (the mean pass)
 
@@ -576,6 +582,269 @@ __global__ __launch_bounds__(256, 1) void gemmh_kernel(const GettArgs p, const c
   }
 }
 
+// ---- the same product with EIGHT waves in two staggered groups (TA, TB even) ---------------------------------------------------------
+// 2 x 4 waves, wave tile (32 TA) x (16 TB), two waves per SIMD (<= 256 registers): group 0 = the upper tile half (waves 0..3),
+// group 1 = the lower one, running HALF A STEP behind (one extra barrier at its start, one at group 0's end).  A step is two
+// phases with a barrier after each: L -- read the step's fragments, request a stage NS - 1 steps ahead -- and C -- the step's
+// 3 TA TB / 2 MFMAs at raised priority.  While one group's waves are in C the SIMDs' other waves are in L: the matrix pipe
+// always has a wave issuing, and no fragment is double-buffered (its reads have a whole phase to land).
+template <int TA, int TB, bool DOT>
+__global__ __launch_bounds__(512, 1) void gemmh8_kernel(const GettArgs p, const char* __restrict__ PA, const char* __restrict__ PB,
+                                                       float* __restrict__ C, const float* __restrict__ scale_a,
+                                                       const float* __restrict__ scale_b, const float* __restrict__ hdrA,
+                                                       const float* __restrict__ hdrB, const double* __restrict__ meanA,
+                                                       const double* __restrict__ meanB, float* __restrict__ absmax_out) {
+  // (behind an operand's Xpad means: the 3 NY partial rows of the mean pass, then the Xpad constants actually subtracted)
+  constexpr int BM = 64 * TA, BN = 64 * TB;
+  constexpr int SA = 2 * 2 * BM * 16, SB = 2 * 2 * BN * 16, STAGE = SA + SB;   // bytes of a 16-k stage: [half][2 k-groups][x][16]
+  constexpr int NS = hring_stages(TA, TB);                                      // ring depth: what fits 160 KB of LDS (4 .. 6)
+  constexpr int TBW = TB / 2, NT = 512;                                         // a wave's sub-tile columns (2 x 4 waves), threads
+  constexpr int NPA = TA / 2, NPB = TB / 2, NP = NPA + NPB;                     // LDS-DMA pieces per wave and stage
+  static_assert(TA % 2 == 0 && TB % 2 == 0, "even tile shapes only");
+  extern __shared__ __attribute__((aligned(16))) char hsmem[];
+  char* stages = hsmem;
+  int64_t* offCm = reinterpret_cast<int64_t*>(hsmem + NS * STAGE);
+  int64_t* offCn = offCm + BM;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;           // wm = the wave's GROUP (0: leads, 1: half a step behind)
+
+  // ---- tile coordinates: each XCD a contiguous run of the tile sequence, bands of 4 tile rows (as gemmk.hip) ----------------
+  const uint32_t per_batch = p.tiles_m * p.tiles_n;
+  const uint32_t pid = blockIdx.x;
+  uint32_t tm, tn;
+  {
+    const uint32_t xcd = pid & 7, idx = pid >> 3;
+    const uint32_t q = per_batch >> 3, r = per_batch & 7;
+    const uint32_t s = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    const uint32_t band = QAMD_GEMMH_BAND * p.tiles_n;
+    const uint32_t first_m = (s / band) * QAMD_GEMMH_BAND;
+    const uint32_t gsz = (p.tiles_m - first_m) < QAMD_GEMMH_BAND ? (p.tiles_m - first_m) : QAMD_GEMMH_BAND;
+    const uint32_t in_band = s % band;
+    tm = first_m + in_band % gsz;
+    tn = in_band / gsz;
+  }
+  const uint32_t m0 = tm * BM, n0 = tn * BN;
+  for (int i = tid; i < BM + BN; i += NT) {
+    if (i < BM) {
+      uint32_t g = m0 + i;
+      offCm[i] = hdecomp(g < p.M ? g : p.M - 1, p.nm, p.dim_m, p.sc_m);
+    } else {
+      uint32_t g = n0 + (i - BM);
+      offCn[i - BM] = hdecomp(g < p.N ? g : p.N - 1, p.nn, p.dim_n, p.sc_n);
+    }
+  }
+
+  // ---- LDS-DMA sources: wave w always fetches (half w & 1, k-group w >> 1) of a stage, every 64-row chunk of it -------------
+  const int64_t Mpad = (int64_t)p.tiles_m * BM, Npad = (int64_t)p.tiles_n * BN;
+  const int64_t KG = p.Kloop >> 3;
+  const int wh = wave & 1, wk = (wave >> 1) & 1, ws = wave >> 2;   // ws: chunks ws, ws + 2, .. of the (wh, wk) images
+  const int64_t stepA = 2 * Mpad * 16, stepB = 2 * Npad * 16;
+  const char* baseA0 = PA + (((int64_t)wh * KG + wk) * Mpad + m0) * 16;
+  const char* baseB0 = PB + (((int64_t)wh * KG + wk) * Npad + n0) * 16;
+  const uint32_t lane16 = 16u * lane;
+  const int nsteps = (int)(KG >> 1);          // 16-k steps (even: the images' k extent is a multiple of 32)
+  const int dstA = ((wh * 2 + wk) * BM) * 16, dstB = SA + ((wh * 2 + wk) * BN) * 16;
+
+  // piece q of a wave's NP for the stage whose sources are srcA_ / srcB_ into ring slot st_: q < TA: A chunk q, else B chunk q - TA
+#define QH_PIECE(q_, st_)                                                                                            \
+  do {                                                                                                               \
+    if ((q_) < NPA) {                                                                                                \
+      const int c_ = ws + 2 * (q_);                                                                                  \
+      hglds(srcA_ + c_ * 1024 + lane16, stages + (st_) * STAGE + dstA + c_ * 1024);                                  \
+    } else {                                                                                                         \
+      const int c_ = ws + 2 * ((q_) - NPA);                                                                          \
+      hglds(srcB_ + c_ * 1024 + lane16, stages + (st_) * STAGE + dstB + c_ * 1024);                                  \
+    }                                                                                                                \
+  } while (0)
+  // sources of stage s_ (past the last stage: the last one again -- a slot nobody reads, but the request counts stay exact)
+#define QH_SOURCES(s_)                                                                                               \
+  const int64_t sc_ = (s_) < nsteps ? (s_) : nsteps - 1;                                                             \
+  const char* srcA_ = baseA0 + sc_ * stepA;                                                                          \
+  const char* srcB_ = baseB0 + sc_ * stepB
+
+  acc16 acc[TA][TBW];
+#pragma unroll
+  for (int i = 0; i < TA; ++i)
+#pragma unroll
+    for (int j = 0; j < TBW; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+  const int l31 = lane & 31, kh = lane >> 5;
+  const int aoff = (kh * BM + wm * (32 * TA) + l31) * 16;
+  const int boff = SA + (kh * BN + wn * (32 * TBW) + l31) * 16;
+
+  h8 fa[2][TA], fb[2][TBW];     // [half][sub-tile]: single-buffered
+  // ---- prologue: stages 0 .. NS - 2 requested, stage 0 awaited; group 1 then waits half a step ------------------------------
+#pragma unroll
+  for (int s0 = 0; s0 < NS - 1; ++s0) {
+    QH_SOURCES(s0);
+#pragma unroll
+    for (int q = 0; q < NP; ++q) QH_PIECE(q, s0);
+  }
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * NP) : "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  if (wm == 1) {
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  }
+  int st = 0, sp = NS - 1;      // ring slots of stage t and of the stage requested in step t (stage t + NS - 1)
+  for (int t = 0; t < nsteps; ++t) {
+    // ---- L(t): the step's fragments, the request NS - 1 steps ahead (its slot: stage t - 1's, read by both groups by now)
+    {
+      const char* As_ = stages + st * STAGE + aoff;
+      const char* Bs_ = stages + st * STAGE + boff;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+#pragma unroll
+        for (int i = 0; i < TA; ++i) fa[h][i] = *reinterpret_cast<const h8*>(As_ + h * (2 * BM * 16) + i * 512);
+#pragma unroll
+        for (int j = 0; j < TBW; ++j) fb[h][j] = *reinterpret_cast<const h8*>(Bs_ + h * (2 * BN * 16) + j * 512);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      QH_SOURCES(t + NS - 1);
+#pragma unroll
+      for (int q = 0; q < NP; ++q) QH_PIECE(q, sp);
+      __builtin_amdgcn_sched_barrier(0);
+      // group 1 ends its L at the barrier that precedes group 0's L(t + 1): its pieces of stage t + 1 must have landed
+      if (wm == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * NP) : "memory");
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    // ---- C(t)
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int pr = 0; pr < 3; ++pr)
+#pragma unroll
+      for (int i = 0; i < TA; ++i)
+#pragma unroll
+        for (int j = 0; j < TBW; ++j) {
+          const int ha = pr == 1 ? 1 : 0, hb = pr == 0 ? 1 : 0;       // a1 b2, a2 b1, a1 b1
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[ha][i], fb[hb][j], acc[i][j], 0, 0, 0);
+        }
+    __builtin_amdgcn_s_setprio(0);
+    // group 0 ends its C at the same barrier: its pieces of stage t + 1 landed before anybody reads them
+    if (wm == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * NP) : "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    st = st + 1 >= NS ? 0 : st + 1;
+    sp = sp + 1 >= NS ? 0 : sp + 1;
+  }
+  if (wm == 0) {
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  }
+#undef QH_SOURCES
+#undef QH_PIECE
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+  // ---- epilogue: acc[i][j][r] = C[wm 32 TA + 32 i + (r & 3) + 8 (r >> 2) + 4 kh][wn 32 TBW + 32 j + l31] -----------------------
+  // centred operands (meanA / meanB: the columns' means over k as doubles, zeros for the padding; usedA / usedB: the fp32
+  // constants ah, bh the split pass subtracted):
+  //   sum_k a b = sum_k (a - ah)(b - bh) + K (ah bbar + bh (abar - ah))
+  // -- the MFMA sum is over sign-mixed terms of the size of the operands' FLUCTUATIONS, the part carried by the constants is
+  // added here in double precision
+  const float unscale = hdrA[1] * hdrB[1];
+  const bool centred = meanA != nullptr;
+  const float* usedA = centred ? reinterpret_cast<const float*>(meanA + (int64_t)(3 * QAMD_GEMMH_NY + 1) * Mpad) : nullptr;
+  const float* usedB = centred ? reinterpret_cast<const float*>(meanB + (int64_t)(3 * QAMD_GEMMH_NY + 1) * Npad) : nullptr;
+  double bbar[TBW], bh[TBW];
+#pragma unroll
+  for (int j = 0; j < TBW; ++j) {
+    const int g = n0 + wn * (32 * TBW) + 32 * j + l31;
+    bbar[j] = centred ? meanB[g] * (double)p.K : 0.0;
+    bh[j] = centred ? (double)usedB[g] * (double)p.K : 0.0;
+  }
+  if constexpr (DOT) {
+    // (a tile's epilogue has the CU to itself -- one workgroup per CU --, so T's values are requested a whole sub-tile row
+    // block ahead of their use, with clamped addresses and 0 / 1 masks instead of branches: 64 loads in flight per lane)
+    __shared__ double dred[8];
+    float dsum = 0.0f;
+    double dcorr = 0.0;
+    int64_t ocol[TBW];
+    float cmask[TBW];
+#pragma unroll
+    for (int j = 0; j < TBW; ++j) {
+      const int nl = wn * (32 * TBW) + 32 * j + l31;
+      ocol[j] = offCn[nl];                               // (columns past N: the table holds column N - 1)
+      cmask[j] = (n0 + nl < p.N) ? 1.0f : 0.0f;
+    }
+#pragma unroll
+    for (int i = 0; i < TA; ++i) {
+      float tv[16][TBW];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int ml = wm * (32 * TA) + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * kh;
+        const int64_t orow = offCm[ml];                  // (rows past M: row M - 1)
+#pragma unroll
+        for (int j = 0; j < TBW; ++j) tv[r][j] = C[orow + ocol[j]];
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int ml = wm * (32 * TA) + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * kh;
+        const float rmask = (m0 + ml < p.M) ? 1.0f : 0.0f;
+        float trow[TBW];
+#pragma unroll
+        for (int j = 0; j < TBW; ++j) {
+          trow[j] = tv[r][j] * (rmask * cmask[j]);
+          dsum = __builtin_fmaf(acc[i][j][r], trow[j], dsum);
+        }
+        if (centred) {
+          const double abar = meanA[m0 + ml], ah = (double)usedA[m0 + ml], ad = abar - ah;
+#pragma unroll
+          for (int j = 0; j < TBW; ++j) dcorr += (ah * bbar[j] + ad * bh[j]) * (double)trow[j];
+        }
+      }
+    }
+    double ds = (double)dsum * (double)unscale + dcorr;
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) ds += __shfl_down(ds, d, 64);
+    if (lane == 0) dred[wave] = ds;
+    __syncthreads();
+    if (tid == 0)
+      reinterpret_cast<double*>(absmax_out)[blockIdx.x] = ((dred[0] + dred[1]) + (dred[2] + dred[3])) + ((dred[4] + dred[5]) + (dred[6] + dred[7]));
+    return;
+  }
+  const float strip = 1.0f / (hread_scale(scale_a, lane) * hread_scale(scale_b, lane));
+  const float alpha = unscale * strip;
+  float vmax = 0.0f;
+#pragma unroll
+  for (int i = 0; i < TA; ++i) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int ml = wm * (32 * TA) + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * kh;
+      if (m0 + ml >= p.M) continue;
+      const int64_t orow = offCm[ml];
+      double ah = 0.0, ad = 0.0;
+      if (centred) {
+        const double abar = meanA[m0 + ml];
+        ah = (double)usedA[m0 + ml];
+        ad = abar - ah;
+      }
+#pragma unroll
+      for (int j = 0; j < TBW; ++j) {
+        const int nl = wn * (32 * TBW) + 32 * j + l31;
+        if (n0 + nl < p.N) {
+          float v = acc[i][j][r] * alpha;
+          if (centred) v = (float)((double)v + (ah * bbar[j] + ad * bh[j]) * (double)strip);
+          C[orow + offCn[nl]] = v;
+          vmax = fmaxf(vmax, fabsf(v));
+        }
+      }
+    }
+  }
+  if (absmax_out) {
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) vmax = fmaxf(vmax, __shfl_down(vmax, d, 64));
+    if (lane == 0) atomicMax(reinterpret_cast<unsigned int*>(absmax_out + ((blockIdx.x * 8 + wave) % QAMD_SLOTS)), __float_as_uint(vmax));
+  }
+}
+
 template <int TA, int TB, bool DOT>
 static int launch_one(const GettArgs& a, const void* PA, const void* PB, void* C, const void* sa, const void* sb, const void* hdrA,
                       const void* hdrB, const void* meanA, const void* meanB, void* amax, hipStream_t st) {
@@ -584,6 +853,19 @@ static int launch_one(const GettArgs& a, const void* PA, const void* PB, void* C
   (void)hipFuncSetAttribute((const void*)gemmh_kernel<TA, TB, DOT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   const unsigned grid = a.tiles_m * a.tiles_n;
   QAMD_LAUNCH((gemmh_kernel<TA, TB, DOT>), dim3(grid), dim3(256), lds, st, a, (const char*)PA, (const char*)PB, (float*)C,
+              (const float*)sa, (const float*)sb, (const float*)hdrA, (const float*)hdrB, (const double*)meanA,
+              (const double*)meanB, (float*)amax);
+  return hipGetLastError() == hipSuccess ? 0 : -4;
+}
+
+template <int TA, int TB, bool DOT>
+static int launch_one8(const GettArgs& a, const void* PA, const void* PB, void* C, const void* sa, const void* sb, const void* hdrA,
+                       const void* hdrB, const void* meanA, const void* meanB, void* amax, hipStream_t st) {
+  constexpr int BM = 64 * TA, BN = 64 * TB;
+  const size_t lds = (size_t)hring_stages(TA, TB) * 64 * (BM + BN) + (size_t)(BM + BN) * sizeof(int64_t);
+  (void)hipFuncSetAttribute((const void*)gemmh8_kernel<TA, TB, DOT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  const unsigned grid = a.tiles_m * a.tiles_n;
+  QAMD_LAUNCH((gemmh8_kernel<TA, TB, DOT>), dim3(grid), dim3(512), lds, st, a, (const char*)PA, (const char*)PB, (float*)C,
               (const float*)sa, (const float*)sb, (const float*)hdrA, (const float*)hdrB, (const double*)meanA,
               (const double*)meanB, (float*)amax);
   return hipGetLastError() == hipSuccess ? 0 : -4;
@@ -656,6 +938,7 @@ extern "C" int qamd_gemmh_launch(int ta, int tb, const GettArgs* a, const void* 
                                  void* absmax_out, void* stream) {
   if (!a || a->Kloop < 64 || a->Kloop % 32 || a->B != 1 || !hdrA || !hdrB || (!meanA) != (!meanB)) return -2;
 #define QH_CASE(TA_, TB_) \
+  if (QAMD_GEMMH_W8 && ta == TA_ && tb == TB_ && TA_ % 2 == 0 && TB_ % 2 == 0) return launch_one8<(TA_ % 2 ? 4 : TA_), (TB_ % 2 ? 4 : TB_), false>(*a, PA, PB, C, scale_a, scale_b, hdrA, hdrB, meanA, meanB, absmax_out, (hipStream_t)stream); \
   if (ta == TA_ && tb == TB_) return launch_one<TA_, TB_, false>(*a, PA, PB, C, scale_a, scale_b, hdrA, hdrB, meanA, meanB, absmax_out, (hipStream_t)stream);
   QAMD_GEMMH_CASES
 #undef QH_CASE
@@ -669,6 +952,7 @@ extern "C" int qamd_gemmh_dot_launch(int ta, int tb, const GettArgs* a, const vo
                                      void* stream) {
   if (!a || a->Kloop < 64 || a->Kloop % 32 || a->B != 1 || !hdrA || !hdrB || (!meanA) != (!meanB)) return -2;
 #define QH_CASE(TA_, TB_)     \
+  if (QAMD_GEMMH_W8 && ta == TA_ && tb == TB_ && TA_ % 2 == 0 && TB_ % 2 == 0) return launch_one8<(TA_ % 2 ? 4 : TA_), (TB_ % 2 ? 4 : TB_), true>(*a, PA, PB, const_cast<void*>(T), nullptr, nullptr, hdrA, hdrB, meanA, meanB, partial, (hipStream_t)stream); \
   if (ta == TA_ && tb == TB_) \
     return launch_one<TA_, TB_, true>(*a, PA, PB, const_cast<void*>(T), nullptr, nullptr, hdrA, hdrB, meanA, meanB, partial, (hipStream_t)stream);
   QAMD_GEMMH_CASES

@@ -273,15 +273,17 @@ def test_gemmh_split_products(hip):
     accumulation -- ragged edges, padded k, swapped roles, tensor addressing, three fills, the planner's tile and every tile
     pinned; then inside an executor (exponent slots, the fused closing inner product)."""
     names = checks.check_gemmh(tiles=(None, 44, 34, 43, 33, 24, 42))
-    assert names and all(n.startswith("gemmh_kernel") for n in names), sorted(set(names))
-    assert {n for n in names} >= {f"gemmh_kernel<{a}, {b}> f16x3" for (a, b) in ((4, 4), (3, 4), (4, 3), (3, 3), (2, 4), (4, 2))}
+    assert names and all(n.startswith("gemmh") for n in names), sorted(set(names))
+    # (even tiles: the eight-wave two-group kernel; tiles with an odd side: the four-wave one)
+    assert {n for n in names} >= {"gemmh8_kernel<4, 4> f16x3", "gemmh_kernel<3, 4> f16x3", "gemmh_kernel<4, 3> f16x3",
+                                  "gemmh_kernel<3, 3> f16x3", "gemmh8_kernel<2, 4> f16x3", "gemmh8_kernel<4, 2> f16x3"}
     hip.profile, hip.profile_min_mults = [], 0
     try:
         res = checks.check_gemmh_tree()
         names = [r[2] for r in hip.profile]
     finally:
         hip.profile = None
-    assert any(n.startswith("gemmh_kernel") and n.endswith("+ dot") for n in names), names
+    assert any(n.startswith("gemmh") and n.endswith("+ dot") for n in names), names
     assert any(n.startswith("gemmk_kernel") and n.endswith("+ dot") for n in names), names
     print("split products vs fp32 MFMA, rel. err of the closing scalar:", res)
 
@@ -553,7 +555,7 @@ def test_quadrant_tree_full_size_split_products(hip):
         names = [n for (_, _, n, _, _, _) in hip.profile]
     finally:
         hip.profile = None
-    assert sum(n.startswith("gemmh_kernel") for n in names) == 2 and not any(n.startswith("gemmk_kernel") for n in names), names
+    assert sum(n.startswith("gemmh") for n in names) == 2 and not any(n.startswith("gemmk_kernel") for n in names), names
     achieved = {}
     for key, r in sorted(refs.items()):
         if (r["Lx"], r["Ly"], r["D"]) != (10, 10, 6):

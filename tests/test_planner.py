@@ -132,20 +132,20 @@ def test_split_product_joins_are_opt_in():
     name, p = _describe("km", (7776, 7776), "kn", (7776, 7776), "mn")
     assert p.kernel == 5                                                                  # default: the fp32 MFMA kernel
     name, p = _describe("km", (7776, 7776), "kn", (7776, 7776), "mn", pin=(-7, -1))
-    assert p.kernel == 7 and name == "gemmh_kernel<3, 4> f16x3", name                     # 1271 tiles of 192 x 256: 4.96 rounds
-    mpad, npad, kpad = 41 * 192, 31 * 256, 7776
+    assert p.kernel == 7 and name == "gemmh8_kernel<4, 4> f16x3", name                    # 961 tiles of 256 x 256 on the eight-wave kernel
+    mpad, npad, kpad = 31 * 256, 31 * 256, 7776
     img = lambda x: 2 * (kpad // 8) * x * 16       # both fp16 halves, 16 bytes per (k-group of 8, column)
     means = lambda x: (3 * 32 + 1) * x * 8 + 4 * x     # a column's mean (double), 3 x 32 partial sums (doubles), the fp32 constant subtracted
     assert lib.qamd_pair_workspace_bytes(C.byref(p)) == 1024 + means(mpad) + means(npad) + img(mpad) + img(npad)
-    assert lib.qamd_pair_dot_workspace_bytes(C.byref(p)) == (8 * 41 * 31 + 255) // 256 * 256 + lib.qamd_pair_workspace_bytes(C.byref(p))
+    assert lib.qamd_pair_dot_workspace_bytes(C.byref(p)) == (8 * 31 * 31 + 255) // 256 * 256 + lib.qamd_pair_workspace_bytes(C.byref(p))
     # without its workspace the call is refused before anything is launched (host logic: no device needed)
     one = (C.c_float * 4)()
     assert lib.qamd_contract_pair_ex(C.byref(p), one, one, one, None, None, 0, None, None) == -3          # QAMD_EWORKSPACE
     assert lib.qamd_contract_pair_dot(C.byref(p), one, one, one, one, None, 0, None, None, None) == -3
     name, p = _describe("km", (7776, 3888), "kn", (7776, 1944), "mn", pin=(-7, -1))       # one rank of eight: one round of 128 x 256
-    assert name in ("gemmh_kernel<4, 2> f16x3", "gemmh_kernel<2, 4> f16x3"), name
+    assert name in ("gemmh8_kernel<4, 2> f16x3", "gemmh8_kernel<2, 4> f16x3"), name
     name, p = _describe("km", (8192, 8192), "kn", (8192, 8192), "mn", pin=(-7, 16 * 4 + 4))
-    assert name == "gemmh_kernel<4, 4> f16x3"
+    assert name == "gemmh8_kernel<4, 4> f16x3"
     name, p = _describe("km", (300, 7000), "kn", (300, 5000), "mn", pin=(-7, -1))         # K % 32 != 0: zero-padded images
     assert p.kernel == 7 and lib.qamd_pair_workspace_bytes(C.byref(p)) > 0
     # not covered -> the automatic choice, as if the pin were 0
@@ -153,7 +153,7 @@ def test_split_product_joins_are_opt_in():
     for args in (("mk", (2048, 512), "kn", (512, 2048), "mn"), ("km", (512, 2048), "nk", (2048, 512), "mn"),
                  ("mk", (2048, 512), "nk", (2048, 512), "nm"), ("muk", (2048, 24, 32), "kun", (32, 24, 2048), "mn")):
         name7, p7 = _describe(*args, pin=(-7, -1))
-        assert p7.kernel == 7 and name7.startswith("gemmh_kernel<"), (args, name7)
+        assert p7.kernel == 7 and name7.startswith("gemmh"), (args, name7)
     for args, kw in ((("km", (128, 4096), "kn", (128, 4096), "mn"), {}),                  # K < 256: not worth the split pass
                      (("km", (512, 2048), "kn", (512, 200), "mn"), {}),                   # N < 256
                      (("hvm", (6, 6, 46656), "hxvy", (6, 6, 6, 6), "mxy"), {}),           # big x small: the streaming kernels
