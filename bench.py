@@ -15,8 +15,12 @@ amplitude (single-layer 10x10 D=6 tensor network, fp32), MI355X.
   round 1's 216 single-value slices of the sweep, ``--two-sided`` round 2's branch decomposition.)
 * N == 1 also reports: ``secondary`` (BASELINE configs #2, #3 as worded -- the compressed boundary-MPS sweep at a stated
   chi, on the headline's tensors -- and #5: circuit amplitude, DMRG2 matvec / local update / sweeps),
-  ``scaling_projection`` (the busiest rank's share of the N = 2 / 4 / 8 jobs timed on this one GPU) and
-  ``cpu_baseline``.
+  ``scaling_projection`` (the busiest rank's share of the N = 2 / 4 / 8 jobs timed on this one GPU), ``cpu_baseline``, and
+  ``split_products_f16x3``: the same contraction re-run with the OPT-IN join arithmetic (Options.join_arith = "f16x3":
+  the two joins as three exact fp16 products per multiply-add on the f16 matrix pipe, csrc/gemmh.hip) -- its own ms per
+  step, value, error against the fp64 oracle and join timings, BESIDE the headline: ``value`` / ``roofline`` / ``dtype``
+  are always the fp32 MFMA path's unless QAMD_JOIN_ARITH=f16x3 makes the split products the process default (``dtype``
+  then says so).
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with the extra ``roofline`` (dominant kernel, HIP
 events on the launch stream) and ``cpu_baseline`` (numpy/OpenBLAS port of the sweep: a bounded sample to pick the thread
