@@ -54,6 +54,10 @@ class Options:
     auto_program_total_bytes: int = 16 << 30   #: [QAMD_AUTO_PROGRAM_TOTAL_BYTES]
     debug: bool = False             #: say on stderr why a recording was refused                        [QAMD_DEBUG]
 
+    def __post_init__(self):
+        if self.join_arith not in ("f32", "f16x3"):
+            raise ValueError(f"join_arith must be 'f32' or 'f16x3', got {self.join_arith!r}")
+
     def replace(self, **kw):
         return dataclasses.replace(self, **kw)
 

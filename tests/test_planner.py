@@ -173,3 +173,7 @@ def test_join_arith_option_pins_kernel_minus_seven():
     with qa.exec_options(join_arith="f16x3") as o:
         assert o.join_arith == "f16x3" and qa.get_options().join_arith == "f16x3"
     assert qa.get_options().join_arith == "f32"
+    with pytest.raises(ValueError):
+        Options(join_arith="bf16")
+    with pytest.raises(ValueError):
+        qa.get_options().replace(join_arith="fast")
