@@ -313,6 +313,120 @@ __host__ __device__ constexpr int hring_stages(int ta, int tb) {
   return n > 6 ? 6 : n;
 }
 
+// ---- the epilogue both product kernels share: acc[i][j][r] = C[row0 + 32 i + (r & 3) + 8 (r >> 2) + 4 kh][col0 + 32 j + l31] of the
+// workgroup's tile (row0 / col0: the wave's corner in it; NW: waves per workgroup) ---------------------------------------------------
+template <int TA, int TBW, bool DOT, int NW>
+__device__ __forceinline__ void hepilogue(const GettArgs& p, acc16 (&acc)[TA][TBW], float* __restrict__ C,
+                                          const float* __restrict__ scale_a, const float* __restrict__ scale_b,
+                                          const float* __restrict__ hdrA, const float* __restrict__ hdrB,
+                                          const double* __restrict__ meanA, const double* __restrict__ meanB,
+                                          float* __restrict__ absmax_out, const int64_t* offCm, const int64_t* offCn, uint32_t m0,
+                                          uint32_t n0, int row0, int col0, int64_t Mpad, int64_t Npad, int tid, int lane, int wave) {
+  const int l31 = lane & 31, kh = lane >> 5;
+  // centred operands (meanA / meanB: the columns' means over k as doubles, zeros for the padding; usedA / usedB: the fp32
+  // constants ah, bh the split pass subtracted):
+  //   sum_k a b = sum_k (a - ah)(b - bh) + K (ah bbar + bh (abar - ah))
+  // -- the MFMA sum is over sign-mixed terms of the size of the operands' FLUCTUATIONS, the part carried by the constants is
+  // added here in double precision
+  const float unscale = hdrA[1] * hdrB[1];
+  const bool centred = meanA != nullptr;
+  const float* usedA = centred ? reinterpret_cast<const float*>(meanA + (int64_t)(3 * QAMD_GEMMH_NY + 1) * Mpad) : nullptr;
+  const float* usedB = centred ? reinterpret_cast<const float*>(meanB + (int64_t)(3 * QAMD_GEMMH_NY + 1) * Npad) : nullptr;
+  double bbar[TBW], bh[TBW];
+#pragma unroll
+  for (int j = 0; j < TBW; ++j) {
+    const int g = n0 + col0 + 32 * j + l31;
+    bbar[j] = centred ? meanB[g] * (double)p.K : 0.0;
+    bh[j] = centred ? (double)usedB[g] * (double)p.K : 0.0;
+  }
+  if constexpr (DOT) {
+    // (a tile's epilogue has the CU to itself -- one workgroup per CU --, so T's values are requested a whole sub-tile row
+    // block ahead of their use, with clamped addresses and 0 / 1 masks instead of branches: 64 loads in flight per lane)
+    __shared__ double dred[NW];
+    float dsum = 0.0f;
+    double dcorr = 0.0;
+    int64_t ocol[TBW];
+    float cmask[TBW];
+#pragma unroll
+    for (int j = 0; j < TBW; ++j) {
+      const int nl = col0 + 32 * j + l31;
+      ocol[j] = offCn[nl];                               // (columns past N: the table holds column N - 1)
+      cmask[j] = (n0 + nl < p.N) ? 1.0f : 0.0f;
+    }
+#pragma unroll
+    for (int i = 0; i < TA; ++i) {
+      float tv[16][TBW];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int ml = row0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * kh;
+        const int64_t orow = offCm[ml];                  // (rows past M: row M - 1)
+#pragma unroll
+        for (int j = 0; j < TBW; ++j) tv[r][j] = C[orow + ocol[j]];
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int ml = row0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * kh;
+        const float rmask = (m0 + ml < p.M) ? 1.0f : 0.0f;
+        float trow[TBW];
+#pragma unroll
+        for (int j = 0; j < TBW; ++j) {
+          trow[j] = tv[r][j] * (rmask * cmask[j]);
+          dsum = __builtin_fmaf(acc[i][j][r], trow[j], dsum);
+        }
+        if (centred) {
+          const double abar = meanA[m0 + ml], ah = (double)usedA[m0 + ml], ad = abar - ah;
+#pragma unroll
+          for (int j = 0; j < TBW; ++j) dcorr += (ah * bbar[j] + ad * bh[j]) * (double)trow[j];
+        }
+      }
+    }
+    double ds = (double)dsum * (double)unscale + dcorr;
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) ds += __shfl_down(ds, d, 64);
+    if (lane == 0) dred[wave] = ds;
+    __syncthreads();
+    if (tid == 0) {
+      double tot = (dred[0] + dred[1]) + (dred[2] + dred[3]);
+      if constexpr (NW == 8) tot += (dred[4] + dred[5]) + (dred[6] + dred[7]);
+      reinterpret_cast<double*>(absmax_out)[blockIdx.x] = tot;
+    }
+    return;
+  }
+  const float strip = 1.0f / (hread_scale(scale_a, lane) * hread_scale(scale_b, lane));
+  const float alpha = unscale * strip;
+  float vmax = 0.0f;
+#pragma unroll
+  for (int i = 0; i < TA; ++i) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int ml = row0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * kh;
+      if (m0 + ml >= p.M) continue;
+      const int64_t orow = offCm[ml];
+      double ah = 0.0, ad = 0.0;
+      if (centred) {
+        const double abar = meanA[m0 + ml];
+        ah = (double)usedA[m0 + ml];
+        ad = abar - ah;
+      }
+#pragma unroll
+      for (int j = 0; j < TBW; ++j) {
+        const int nl = col0 + 32 * j + l31;
+        if (n0 + nl < p.N) {
+          float v = acc[i][j][r] * alpha;
+          if (centred) v = (float)((double)v + (ah * bbar[j] + ad * bh[j]) * (double)strip);
+          C[orow + offCn[nl]] = v;
+          vmax = fmaxf(vmax, fabsf(v));
+        }
+      }
+    }
+  }
+  if (absmax_out) {
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) vmax = fmaxf(vmax, __shfl_down(vmax, d, 64));
+    if (lane == 0) atomicMax(reinterpret_cast<unsigned int*>(absmax_out + ((blockIdx.x * NW + wave) % QAMD_SLOTS)), __float_as_uint(vmax));
+  }
+}
+
 // ---- the product --------------------------------------------------------------------------------------------------------------
 // p.tiles_m / tiles_n: the tile grid (the images are padded to it), p.Kloop: K rounded up to 32 (the images' k extent),
 // p.M / p.N: the valid extents (epilogue), C addressed through p.dim_m / sc_m / dim_n / sc_n as in gemmk.hip.
@@ -481,105 +595,8 @@ __global__ __launch_bounds__(256, 1) void gemmh_kernel(const GettArgs p, const c
 #undef QH_PIECE
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
-  // ---- epilogue: acc[i][j][r] = C[wm 32 TA + 32 i + (r & 3) + 8 (r >> 2) + 4 kh][wn 32 TB + 32 j + l31] -----------------------
-  // centred operands (meanA / meanB: the columns' means over k as doubles, zeros for the padding; usedA / usedB: the fp32
-  // constants ah, bh the split pass subtracted):
-  //   sum_k a b = sum_k (a - ah)(b - bh) + K (ah bbar + bh (abar - ah))
-  // -- the MFMA sum is over sign-mixed terms of the size of the operands' FLUCTUATIONS, the part carried by the constants is
-  // added here in double precision
-  const float unscale = hdrA[1] * hdrB[1];
-  const bool centred = meanA != nullptr;
-  const float* usedA = centred ? reinterpret_cast<const float*>(meanA + (int64_t)(3 * QAMD_GEMMH_NY + 1) * Mpad) : nullptr;
-  const float* usedB = centred ? reinterpret_cast<const float*>(meanB + (int64_t)(3 * QAMD_GEMMH_NY + 1) * Npad) : nullptr;
-  double bbar[TB], bh[TB];
-#pragma unroll
-  for (int j = 0; j < TB; ++j) {
-    const int g = n0 + wn * (32 * TB) + 32 * j + l31;
-    bbar[j] = centred ? meanB[g] * (double)p.K : 0.0;
-    bh[j] = centred ? (double)usedB[g] * (double)p.K : 0.0;
-  }
-  if constexpr (DOT) {
-    // (a tile's epilogue has the CU to itself -- one workgroup per CU --, so T's values are requested a whole sub-tile row
-    // block ahead of their use, with clamped addresses and 0 / 1 masks instead of branches: 64 loads in flight per lane)
-    __shared__ double dred[4];
-    float dsum = 0.0f;
-    double dcorr = 0.0;
-    int64_t ocol[TB];
-    float cmask[TB];
-#pragma unroll
-    for (int j = 0; j < TB; ++j) {
-      const int nl = wn * (32 * TB) + 32 * j + l31;
-      ocol[j] = offCn[nl];                               // (columns past N: the table holds column N - 1)
-      cmask[j] = (n0 + nl < p.N) ? 1.0f : 0.0f;
-    }
-#pragma unroll
-    for (int i = 0; i < TA; ++i) {
-      float tv[16][TB];
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int ml = wm * (32 * TA) + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * kh;
-        const int64_t orow = offCm[ml];                  // (rows past M: row M - 1)
-#pragma unroll
-        for (int j = 0; j < TB; ++j) tv[r][j] = C[orow + ocol[j]];
-      }
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int ml = wm * (32 * TA) + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * kh;
-        const float rmask = (m0 + ml < p.M) ? 1.0f : 0.0f;
-        float trow[TB];
-#pragma unroll
-        for (int j = 0; j < TB; ++j) {
-          trow[j] = tv[r][j] * (rmask * cmask[j]);
-          dsum = __builtin_fmaf(acc[i][j][r], trow[j], dsum);
-        }
-        if (centred) {
-          const double abar = meanA[m0 + ml], ah = (double)usedA[m0 + ml], ad = abar - ah;
-#pragma unroll
-          for (int j = 0; j < TB; ++j) dcorr += (ah * bbar[j] + ad * bh[j]) * (double)trow[j];
-        }
-      }
-    }
-    double ds = (double)dsum * (double)unscale + dcorr;
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) ds += __shfl_down(ds, d, 64);
-    if (lane == 0) dred[wave] = ds;
-    __syncthreads();
-    if (tid == 0) reinterpret_cast<double*>(absmax_out)[blockIdx.x] = (dred[0] + dred[1]) + (dred[2] + dred[3]);
-    return;
-  }
-  const float strip = 1.0f / (hread_scale(scale_a, lane) * hread_scale(scale_b, lane));
-  const float alpha = unscale * strip;
-  float vmax = 0.0f;
-#pragma unroll
-  for (int i = 0; i < TA; ++i) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int ml = wm * (32 * TA) + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * kh;
-      if (m0 + ml >= p.M) continue;
-      const int64_t orow = offCm[ml];
-      double ah = 0.0, ad = 0.0;
-      if (centred) {
-        const double abar = meanA[m0 + ml];
-        ah = (double)usedA[m0 + ml];
-        ad = abar - ah;
-      }
-#pragma unroll
-      for (int j = 0; j < TB; ++j) {
-        const int nl = wn * (32 * TB) + 32 * j + l31;
-        if (n0 + nl < p.N) {
-          float v = acc[i][j][r] * alpha;
-          if (centred) v = (float)((double)v + (ah * bbar[j] + ad * bh[j]) * (double)strip);
-          C[orow + offCn[nl]] = v;
-          vmax = fmaxf(vmax, fabsf(v));
-        }
-      }
-    }
-  }
-  if (absmax_out) {
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) vmax = fmaxf(vmax, __shfl_down(vmax, d, 64));
-    if (lane == 0) atomicMax(reinterpret_cast<unsigned int*>(absmax_out + ((blockIdx.x * 4 + wave) % QAMD_SLOTS)), __float_as_uint(vmax));
-  }
+  hepilogue<TA, TB, DOT, 4>(p, acc, C, scale_a, scale_b, hdrA, hdrB, meanA, meanB, absmax_out, offCm, offCn, m0, n0, wm * (32 * TA),
+                            wn * (32 * TB), Mpad, Npad, tid, lane, wave);
 }
 
 // ---- the same product with EIGHT waves in two staggered groups (TA, TB even) ---------------------------------------------------------
@@ -743,106 +760,8 @@ __global__ __launch_bounds__(512, 1) void gemmh8_kernel(const GettArgs p, const 
 #undef QH_PIECE
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
-  // ---- epilogue: acc[i][j][r] = C[wm 32 TA + 32 i + (r & 3) + 8 (r >> 2) + 4 kh][wn 32 TBW + 32 j + l31] -----------------------
-  // centred operands (meanA / meanB: the columns' means over k as doubles, zeros for the padding; usedA / usedB: the fp32
-  // constants ah, bh the split pass subtracted):
-  //   sum_k a b = sum_k (a - ah)(b - bh) + K (ah bbar + bh (abar - ah))
-  // -- the MFMA sum is over sign-mixed terms of the size of the operands' FLUCTUATIONS, the part carried by the constants is
-  // added here in double precision
-  const float unscale = hdrA[1] * hdrB[1];
-  const bool centred = meanA != nullptr;
-  const float* usedA = centred ? reinterpret_cast<const float*>(meanA + (int64_t)(3 * QAMD_GEMMH_NY + 1) * Mpad) : nullptr;
-  const float* usedB = centred ? reinterpret_cast<const float*>(meanB + (int64_t)(3 * QAMD_GEMMH_NY + 1) * Npad) : nullptr;
-  double bbar[TBW], bh[TBW];
-#pragma unroll
-  for (int j = 0; j < TBW; ++j) {
-    const int g = n0 + wn * (32 * TBW) + 32 * j + l31;
-    bbar[j] = centred ? meanB[g] * (double)p.K : 0.0;
-    bh[j] = centred ? (double)usedB[g] * (double)p.K : 0.0;
-  }
-  if constexpr (DOT) {
-    // (a tile's epilogue has the CU to itself -- one workgroup per CU --, so T's values are requested a whole sub-tile row
-    // block ahead of their use, with clamped addresses and 0 / 1 masks instead of branches: 64 loads in flight per lane)
-    __shared__ double dred[8];
-    float dsum = 0.0f;
-    double dcorr = 0.0;
-    int64_t ocol[TBW];
-    float cmask[TBW];
-#pragma unroll
-    for (int j = 0; j < TBW; ++j) {
-      const int nl = wn * (32 * TBW) + 32 * j + l31;
-      ocol[j] = offCn[nl];                               // (columns past N: the table holds column N - 1)
-      cmask[j] = (n0 + nl < p.N) ? 1.0f : 0.0f;
-    }
-#pragma unroll
-    for (int i = 0; i < TA; ++i) {
-      float tv[16][TBW];
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int ml = wm * (32 * TA) + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * kh;
-        const int64_t orow = offCm[ml];                  // (rows past M: row M - 1)
-#pragma unroll
-        for (int j = 0; j < TBW; ++j) tv[r][j] = C[orow + ocol[j]];
-      }
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int ml = wm * (32 * TA) + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * kh;
-        const float rmask = (m0 + ml < p.M) ? 1.0f : 0.0f;
-        float trow[TBW];
-#pragma unroll
-        for (int j = 0; j < TBW; ++j) {
-          trow[j] = tv[r][j] * (rmask * cmask[j]);
-          dsum = __builtin_fmaf(acc[i][j][r], trow[j], dsum);
-        }
-        if (centred) {
-          const double abar = meanA[m0 + ml], ah = (double)usedA[m0 + ml], ad = abar - ah;
-#pragma unroll
-          for (int j = 0; j < TBW; ++j) dcorr += (ah * bbar[j] + ad * bh[j]) * (double)trow[j];
-        }
-      }
-    }
-    double ds = (double)dsum * (double)unscale + dcorr;
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) ds += __shfl_down(ds, d, 64);
-    if (lane == 0) dred[wave] = ds;
-    __syncthreads();
-    if (tid == 0)
-      reinterpret_cast<double*>(absmax_out)[blockIdx.x] = ((dred[0] + dred[1]) + (dred[2] + dred[3])) + ((dred[4] + dred[5]) + (dred[6] + dred[7]));
-    return;
-  }
-  const float strip = 1.0f / (hread_scale(scale_a, lane) * hread_scale(scale_b, lane));
-  const float alpha = unscale * strip;
-  float vmax = 0.0f;
-#pragma unroll
-  for (int i = 0; i < TA; ++i) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int ml = wm * (32 * TA) + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * kh;
-      if (m0 + ml >= p.M) continue;
-      const int64_t orow = offCm[ml];
-      double ah = 0.0, ad = 0.0;
-      if (centred) {
-        const double abar = meanA[m0 + ml];
-        ah = (double)usedA[m0 + ml];
-        ad = abar - ah;
-      }
-#pragma unroll
-      for (int j = 0; j < TBW; ++j) {
-        const int nl = wn * (32 * TBW) + 32 * j + l31;
-        if (n0 + nl < p.N) {
-          float v = acc[i][j][r] * alpha;
-          if (centred) v = (float)((double)v + (ah * bbar[j] + ad * bh[j]) * (double)strip);
-          C[orow + offCn[nl]] = v;
-          vmax = fmaxf(vmax, fabsf(v));
-        }
-      }
-    }
-  }
-  if (absmax_out) {
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) vmax = fmaxf(vmax, __shfl_down(vmax, d, 64));
-    if (lane == 0) atomicMax(reinterpret_cast<unsigned int*>(absmax_out + ((blockIdx.x * 8 + wave) % QAMD_SLOTS)), __float_as_uint(vmax));
-  }
+  hepilogue<TA, TBW, DOT, 8>(p, acc, C, scale_a, scale_b, hdrA, hdrB, meanA, meanB, absmax_out, offCm, offCn, m0, n0, wm * (32 * TA),
+                             wn * (32 * TBW), Mpad, Npad, tid, lane, wave);
 }
 
 template <int TA, int TB, bool DOT>
