@@ -172,7 +172,7 @@ static bool gemmk_config(const qamd_pair_plan* p, const PairDims& d, int64_t ali
 }
 
 // kernel 7 (gemmh.hip, defined beside its launcher below)
-static bool gemmh_config(const qamd_pair_plan* p, const PairDims& d, int pin, int& ta, int& tb);
+static bool gemmh_config(const qamd_pair_plan* p, const PairDims& d, int pin, bool all_layouts, int& ta, int& tb);
 static int64_t gemmh_workspace_bytes(const qamd_pair_plan* p, const PairDims& d);
 
 // ---- gemmd.hip eligibility and tile choice (fp64, LDS-DMA ring, either operand layout) -----------------------------
@@ -303,10 +303,11 @@ extern "C" int qamd_pair_plan_finalize(qamd_pair_plan* p, int64_t align_a, int64
   // the caller's explicit pins (the ONLY way to steer the choice: nothing below reads the environment):
   //   kernel  0 auto | -1 tiled GETT | -2 auto without the MFMA GEMM kernels | -5 / -6 gemmk / gemmd with the tile named by
   //   tile_cfg = 16 ta + tb (where the kernel can run the shape at all; otherwise the automatic choice) | -7 split products on
-  //   the f16 matrix pipe (gemmh.hip) for the fp32 GEMM-shaped joins large enough to pay for the split pass, auto elsewhere
+  //   the f16 matrix pipe (gemmh.hip) for the fp32 k-outer joins large enough to pay for the split pass, auto elsewhere | -8 the
+  //   same for every fp32 GEMM-shaped pair without a batch bundle, whatever its operand layout
   const int pin_kernel = p->kernel;
   int pin_gemm = 0;
-  if (pin_kernel == -5 || pin_kernel == -6 || pin_kernel == -7) {
+  if (pin_kernel == -5 || pin_kernel == -6 || pin_kernel == -7 || pin_kernel == -8) {
     if (p->tile_cfg > 0) pin_gemm = 10 * (p->tile_cfg / 16) + p->tile_cfg % 16;
     p->tile_cfg = -1;
     p->kernel = 0;
@@ -409,7 +410,7 @@ extern "C" int qamd_pair_plan_finalize(qamd_pair_plan* p, int64_t align_a, int64
     if (p->kernel == 0 && kern == 0 && p->tile_cfg < 0 && pin_kernel != -2) {
       int ta = 0, tb = 0;
       // kernel 7 (gemmh.hip): opt-in, the same shapes as kernel 5 with B == 1
-      if (pin_kernel == -7 && gemmh_config(p, d, pin_gemm, ta, tb)) {
+      if ((pin_kernel == -7 || pin_kernel == -8) && gemmh_config(p, d, pin_gemm, pin_kernel == -8, ta, tb)) {
         p->kernel = 7;
         p->tile_cfg = 16 * ta + tb;
         p->split_k = 1;
@@ -685,10 +686,17 @@ static int launch_gemmk(const qamd_pair_plan* p, const PairDims& d, const void* 
 static const int kGemmhTiles[6][2] = {{4, 4}, {3, 4}, {4, 3}, {3, 3}, {2, 4}, {4, 2}};
 static int64_t gemmh_kpad(int64_t K) { return (K + 31) / 32 * 32; }
 
-static bool gemmh_config(const qamd_pair_plan* p, const PairDims& d, int pin, int& ta, int& tb) {
-  // (any operand layout: the split pass gathers with the operands' own strides -- coalesced for the k-outer joins, a slower
-  // pass for k-contiguous operands -- and the product kernel only ever sees the images)
+static bool gemmh_config(const qamd_pair_plan* p, const PairDims& d, int pin, bool all_layouts, int& ta, int& tb) {
   if (p->dtype != QAMD_F32 || p->nk < 1 || p->nb != 0 || d.B != 1 || p->nm < 1 || p->nn < 1) return false;
+  // kernel = -7: the k-outer joins only -- the pairs whose DEFAULT kernel (gemmk.hip) accumulates as one fp32 chain over k, which
+  // the split products never round worse than.  kernel = -8: any operand layout (the split pass gathers with the operands' own
+  // strides and the product kernel only ever sees the images): k-contiguous operands, K in several groups, complex pairs'
+  // real expansions -- pairs whose default kernels (gettf.hip: k-tiles, split-K) accumulate in BLOCKS, which on incoherent
+  // operands (random signs / phases) is more accurate than any single chain, this one included.
+  if (!all_layouts) {
+    if (p->nk != 1 || p->a_kcontig || p->b_kcontig || p->sa_m[p->nm - 1] != 1 || p->sb_n[p->nn - 1] != 1) return false;
+    if (p->sa_k[0] <= 0 || p->sb_k[0] <= 0) return false;
+  }
   // (worth two extra passes over the operands only where the product dominates them; a pinned tile waives the floors down
   // to what the kernel needs: two 32-k stages)
   if (d.M >= (1ll << 31) || d.N >= (1ll << 31) || d.K >= (1ll << 31) || d.K < 33) return false;
@@ -737,6 +745,11 @@ static int launch_gemmh(const qamd_pair_plan* p, const PairDims& d, const void* 
   for (int i = 0; i < a.nm; ++i) { sm.dim[i] = a.dim_m[i]; sm.stride[i] = a.sa_m[i]; }
   for (int i = 0; i < a.nn; ++i) { sn.dim[i] = a.dim_n[i]; sn.stride[i] = a.sb_n[i]; }
   sm.sk = a.sa_k0; sn.sk = a.sb_k0;
+  // an innermost K group of TWO (the re / im component of a complex pair's real expansion: ops._complex_spec): columns that
+  // alternate between two populations with k -- one centring constant per parity of k
+  const int period = (p->nk >= 2 && p->dim_k[p->nk - 1] == 2) ? 2 : 1;
+  sm.period = sn.period = period;
+  a.pad_ = period;
   sm.nk = sn.nk = p->nk;
   for (int i = 0; i < p->nk; ++i) {
     sm.dim_k[i] = sn.dim_k[i] = (uint32_t)p->dim_k[i];

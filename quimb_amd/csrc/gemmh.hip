@@ -1,5 +1,6 @@
 // gemmh.hip -- the fp32 GEMM-shaped joins on the f16 matrix pipe: split products ("f16x3"), gfx950 only.  OPT-IN
-// (qamd_pair_plan.kernel = -7 on input; quimb_amd.Options.join_arith = "f16x3"): the default stays gemmk.hip on the fp32 MFMA.
+// (qamd_pair_plan.kernel = -7 on input: the k-outer joins, -8: any operand layout; quimb_amd.Options.join_arith = "f16x3" /
+// "f16x3-all"): the default stays gemmk.hip on the fp32 MFMA.
 //
 //   C[m, n] = alpha * sum_k A[k, m] * B[k, n]         (operands fp32 with ANY strides: the split pass re-lays them out; the
 //                                                      k-outer joins gemmk.hip takes are the coalesced case it is tuned for)
@@ -47,6 +48,10 @@
 #define QAMD_GEMMH_W8 1       // even tiles run the eight-wave, two-group kernel (gemmh8_kernel): +6 % at 7776^3; 0 = gemmh_kernel for every tile
 #endif
 #define QAMD_GEMMH_NY 32     // partial rows of a column's sums over k (the mean pass)
+// An operand's centring block (doubles unless said otherwise), always laid out for two parities of k (period 1 uses parity 0):
+//   mean[2][Xpad] | part[3 kinds][NY][2][Xpad] | cused[2][Xpad] (floats)
+#define QAMD_GEMMH_PART0(xpad) (2 * (int64_t)(xpad))
+#define QAMD_GEMMH_USED0(xpad) ((2 + 6 * QAMD_GEMMH_NY) * (int64_t)(xpad))
 
 namespace qamdh {
 
@@ -102,42 +107,49 @@ __global__ __launch_bounds__(256) void habsmax_kernel(const SplitArgs p, const f
 __global__ __launch_bounds__(256) void hmean_kernel(const SplitArgs p, const float* __restrict__ X, double* __restrict__ part) {
   const uint32_t x = blockIdx.x * 256 + threadIdx.x;
   if (x >= p.Xpad) return;
-  double s = 0.0;            // the column sum itself: exact to double precision (it goes into the result)
-  float r = 0.f, a1 = 0.f;   // the two sums the centring RULE looks at: fp32 is plenty (and deterministic)
+  const uint32_t pm = p.period == 2 ? 1u : 0u;      // parity mask of k
+  double s[2] = {0.0, 0.0};    // the column sums themselves: exact to double precision (they go into the result)
+  float r[2] = {0.f, 0.f}, a1[2] = {0.f, 0.f};   // the sums the centring RULE looks at: fp32 is plenty (and deterministic)
   if (x < p.X) {
     const float* src = X + hdecomp(x, p.ng, p.dim, p.stride);
-    const uint32_t per = (p.K + gridDim.y - 1) / gridDim.y;
+    uint32_t per = (p.K + gridDim.y - 1) / gridDim.y;
+    per += per & 1;                                   // (even ranges: the parity of k is then the parity of its place in the range)
     const uint32_t k0 = blockIdx.y * per, k1 = (k0 + per < p.K) ? k0 + per : p.K;
-    uint32_t k = k0;
+    uint32_t k = k0 < p.K ? k0 : p.K;
     for (; k + 8 <= k1; k += 8) {
       float v[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) v[j] = src[hkoff(p, k + j)];
-      s += (((double)v[0] + (double)v[1]) + ((double)v[2] + (double)v[3])) + (((double)v[4] + (double)v[5]) + ((double)v[6] + (double)v[7]));
-      float rr = 0.f, aa = 0.f;
+      const double se = ((double)v[0] + (double)v[2]) + ((double)v[4] + (double)v[6]), so = ((double)v[1] + (double)v[3]) + ((double)v[5] + (double)v[7]);
+      float re = 0.f, ro = 0.f, ae = 0.f, ao = 0.f;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const float av = fabsf(v[j]);
-        aa += av;
-        rr += __builtin_sqrtf(av);
+      for (int j = 0; j < 8; j += 2) {
+        const float b0 = fabsf(v[j]), b1 = fabsf(v[j + 1]);
+        ae += b0; ao += b1;
+        re += __builtin_sqrtf(b0); ro += __builtin_sqrtf(b1);
       }
-      r += rr;
-      a1 += aa;
+      if (pm) { s[0] += se; s[1] += so; r[0] += re; r[1] += ro; a1[0] += ae; a1[1] += ao; }
+      else { s[0] += se + so; r[0] += re + ro; a1[0] += ae + ao; }
     }
     for (; k < k1; ++k) {
       const float v = src[hkoff(p, k)];
-      s += (double)v;
-      r += __builtin_sqrtf(fabsf(v));
-      a1 += fabsf(v);
+      const uint32_t q = k & pm;
+      s[q] += (double)v;
+      r[q] += __builtin_sqrtf(fabsf(v));
+      a1[q] += fabsf(v);
     }
   }
-  part[(int64_t)blockIdx.y * p.Xpad + x] = s;
-  part[(int64_t)(gridDim.y + blockIdx.y) * p.Xpad + x] = (double)r;
-  part[(int64_t)(2 * gridDim.y + blockIdx.y) * p.Xpad + x] = (double)a1;
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    part[((int64_t)(0 * gridDim.y + blockIdx.y) * 2 + q) * p.Xpad + x] = s[q];
+    part[((int64_t)(1 * gridDim.y + blockIdx.y) * 2 + q) * p.Xpad + x] = (double)r[q];
+    part[((int64_t)(2 * gridDim.y + blockIdx.y) * 2 + q) * p.Xpad + x] = (double)a1[q];
+  }
 }
 
 // ---- the centring constants: one thread per column adds the partials in a fixed order -------------------------------------------
-// mean[x] = the column's exact mean over k (double), cused[x] = the fp32 constant c the split pass subtracts: with ANY constants
+// mean[q][x] = the column's exact mean over the k of parity q (double; period 1: all k, q = 0), cused[q][x] = the fp32
+// constant c the split pass subtracts from them: with ANY constants (per parity: one such term each)
 //   sum_k a b = sum_k (a - c)(b - d) + K (c bbar + d (abar - c)),
 // which the product kernel's epilogue adds back.  c = the mean where the column is COHERENT (|sum x| >= 0.75 sum |x|: only
 // same-sign sums carry the accumulate's bias; the sample mean of a sign-mixed column is noise) and the mean is TYPICAL of it;
@@ -148,21 +160,28 @@ __global__ __launch_bounds__(256) void hcentre_kernel(const SplitArgs p, const d
                                                       double* __restrict__ mean, float* __restrict__ cused) {
   const uint32_t x = blockIdx.x * 256 + threadIdx.x;
   if (x >= p.Xpad) return;
-  double sum = 0.0, rsum = 0.0, asum = 0.0;
-  for (int y = 0; y < ny; ++y) {                                            // (zeros for the padding columns)
-    sum += part[(int64_t)y * p.Xpad + x];
-    rsum += part[(int64_t)(ny + y) * p.Xpad + x];
-    asum += part[(int64_t)(2 * ny + y) * p.Xpad + x];
+  const int np = p.period == 2 ? 2 : 1;
+  const double Kp = (double)p.K / np;                                     // k values of one parity (K is even when period = 2)
+  for (int q = 0; q < 2; ++q) {
+    double abar = 0.0, lam = 0.0;
+    if (q < np) {
+      double sum = 0.0, rsum = 0.0, asum = 0.0;
+      for (int y = 0; y < ny; ++y) {                                      // (fixed order; zeros for the padding columns)
+        sum += part[((int64_t)(0 * ny + y) * 2 + q) * p.Xpad + x];
+        rsum += part[((int64_t)(1 * ny + y) * 2 + q) * p.Xpad + x];
+        asum += part[((int64_t)(2 * ny + y) * 2 + q) * p.Xpad + x];
+      }
+      abar = sum / Kp;
+      const double rh = rsum / Kp, mhalf = rh * rh;
+      if (mhalf > 0.0 && asum > 0.0) {
+        const double tails = (2.0 - fabs(abar) / mhalf) * 2.0;            // 1 up to |mean| = 1.5 x the power mean, 0 from 2 x
+        const double coherent = (fabs(sum) / asum - 0.5) * 4.0;            // 1 from |sum x| = 0.75 sum |x|, 0 below 0.5
+        lam = (tails < 0.0 ? 0.0 : (tails > 1.0 ? 1.0 : tails)) * (coherent < 0.0 ? 0.0 : (coherent > 1.0 ? 1.0 : coherent));
+      }
+    }
+    mean[(int64_t)q * p.Xpad + x] = abar;
+    cused[(int64_t)q * p.Xpad + x] = (float)(lam * abar);
   }
-  const double abar = sum / (double)p.K, rh = rsum / (double)p.K, mhalf = rh * rh;
-  double lam = 0.0;
-  if (mhalf > 0.0 && asum > 0.0) {
-    const double tails = (2.0 - fabs(abar) / mhalf) * 2.0;                // 1 up to |mean| = 1.5 x the power mean, 0 from 2 x
-    const double coherent = (fabs(sum) / asum - 0.5) * 4.0;                // 1 from |sum x| = 0.75 sum |x|, 0 below 0.5
-    lam = (tails < 0.0 ? 0.0 : (tails > 1.0 ? 1.0 : tails)) * (coherent < 0.0 ? 0.0 : (coherent > 1.0 ? 1.0 : coherent));
-  }
-  mean[x] = abar;
-  cused[x] = (float)(lam * abar);
 }
 
 // ---- the split pass ---------------------------------------------------------------------------------------------------------
@@ -184,7 +203,7 @@ __global__ __launch_bounds__(256) void split_kernel(const SplitArgs p, const flo
   const uint32_t x = blockIdx.x * 256 + threadIdx.x;
   if (x >= p.Xpad) return;
   const bool valid = x < p.X;
-  const float ahat = cused ? cused[x] : 0.f;
+  const float ahat0 = cused ? cused[x] : 0.f, ahat1 = (cused && p.period == 2) ? cused[(int64_t)p.Xpad + x] : ahat0;   // (k even / odd)
   const float* src = X + (valid ? hdecomp(x, p.ng, p.dim, p.stride) : 0);
   const uint32_t per = (p.KG + gridDim.y - 1) / gridDim.y;
   const uint32_t kg0 = blockIdx.y * per, kg1 = (kg0 + per < p.KG) ? kg0 + per : p.KG;
@@ -196,7 +215,7 @@ __global__ __launch_bounds__(256) void split_kernel(const SplitArgs p, const flo
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const uint32_t k = 8 * kg + j;
-      v[j] = (valid && k < p.K) ? (src[hkoff(p, k)] - ahat) * scale : 0.f;
+      v[j] = (valid && k < p.K) ? (src[hkoff(p, k)] - ((j & 1) ? ahat1 : ahat0)) * scale : 0.f;
     }
     h8 a, b;
 #pragma unroll
@@ -219,8 +238,9 @@ typedef float hf4 __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(256) void hmean_kc_kernel(const SplitArgs p, const float* __restrict__ X, double* __restrict__ part) {
   const uint32_t x = blockIdx.x * 16 + (threadIdx.x >> 4);
   const uint32_t kq = threadIdx.x & 15;
-  double s = 0.0;
-  float r = 0.f, a1 = 0.f;
+  const bool two = p.period == 2;
+  double s[2] = {0.0, 0.0};
+  float r[2] = {0.f, 0.f}, a1[2] = {0.f, 0.f};
   const uint32_t KGv = p.K >> 3;                                  // whole k-groups of the source (K % 8 == 0 here)
   const uint32_t per = (KGv + gridDim.y - 1) / gridDim.y;
   const uint32_t g0 = blockIdx.y * per, g1 = (g0 + per < KGv) ? g0 + per : KGv;
@@ -229,28 +249,31 @@ __global__ __launch_bounds__(256) void hmean_kc_kernel(const SplitArgs p, const 
     for (uint32_t g = g0 + kq; g < g1; g += 16) {
       const hf4* q = reinterpret_cast<const hf4*>(src + hkoff(p, 8 * g));
       const hf4 v0 = q[0], v1 = q[1];
-      s += (((double)v0[0] + (double)v0[1]) + ((double)v0[2] + (double)v0[3])) + (((double)v1[0] + (double)v1[1]) + ((double)v1[2] + (double)v1[3]));
-      float rr = 0.f, aa = 0.f;
+      const double se = ((double)v0[0] + (double)v0[2]) + ((double)v1[0] + (double)v1[2]), so = ((double)v0[1] + (double)v0[3]) + ((double)v1[1] + (double)v1[3]);
+      float re = 0.f, ro = 0.f, ae = 0.f, ao = 0.f;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float b0 = fabsf(v0[j]), b1 = fabsf(v1[j]);
-        aa += b0 + b1;
-        rr += __builtin_sqrtf(b0) + __builtin_sqrtf(b1);
+      for (int j = 0; j < 4; j += 2) {
+        const float b0 = fabsf(v0[j]), b1 = fabsf(v0[j + 1]), b2 = fabsf(v1[j]), b3 = fabsf(v1[j + 1]);
+        ae += b0 + b2; ao += b1 + b3;
+        re += __builtin_sqrtf(b0) + __builtin_sqrtf(b2); ro += __builtin_sqrtf(b1) + __builtin_sqrtf(b3);
       }
-      r += rr;
-      a1 += aa;
+      if (two) { s[0] += se; s[1] += so; r[0] += re; r[1] += ro; a1[0] += ae; a1[1] += ao; }
+      else { s[0] += se + so; r[0] += re + ro; a1[0] += ae + ao; }
     }
   }
 #pragma unroll
-  for (int d = 8; d > 0; d >>= 1) {                                // the 16 lanes of a column, fixed order
-    s += __shfl_xor(s, d, 64);
-    r += __shfl_xor(r, d, 64);
-    a1 += __shfl_xor(a1, d, 64);
-  }
-  if (kq == 0 && x < p.Xpad) {
-    part[(int64_t)blockIdx.y * p.Xpad + x] = s;
-    part[(int64_t)(gridDim.y + blockIdx.y) * p.Xpad + x] = (double)r;
-    part[(int64_t)(2 * gridDim.y + blockIdx.y) * p.Xpad + x] = (double)a1;
+  for (int q = 0; q < 2; ++q) {
+#pragma unroll
+    for (int d = 8; d > 0; d >>= 1) {                              // the 16 lanes of a column, fixed order
+      s[q] += __shfl_xor(s[q], d, 64);
+      r[q] += __shfl_xor(r[q], d, 64);
+      a1[q] += __shfl_xor(a1[q], d, 64);
+    }
+    if (kq == 0 && x < p.Xpad) {
+      part[((int64_t)(0 * gridDim.y + blockIdx.y) * 2 + q) * p.Xpad + x] = s[q];
+      part[((int64_t)(1 * gridDim.y + blockIdx.y) * 2 + q) * p.Xpad + x] = (double)r[q];
+      part[((int64_t)(2 * gridDim.y + blockIdx.y) * 2 + q) * p.Xpad + x] = (double)a1[q];
+    }
   }
 }
 
@@ -281,10 +304,10 @@ __global__ __launch_bounds__(256) void split_kc_kernel(const SplitArgs p, const 
     if (x < p.X && 8 * g < p.K) {
       const hf4* src = reinterpret_cast<const hf4*>(X + hdecomp(x, p.ng, p.dim, p.stride) + hkoff(p, 8 * g));
       const hf4 v0 = src[0], v1 = src[1];
-      const float c = cused ? cused[x] : 0.f;
+      const float c0 = cused ? cused[x] : 0.f, c1 = (cused && p.period == 2) ? cused[(int64_t)p.Xpad + x] : c0;   // (k even / odd)
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        const float xv = ((j < 4 ? v0[j & 3] : v1[j & 3]) - c) * scale;
+        const float xv = ((j < 4 ? v0[j & 3] : v1[j & 3]) - ((j & 1) ? c1 : c0)) * scale;
         const _Float16 h = (_Float16)xv;
         a[j] = h;
         b[j] = (_Float16)(xv - (float)h);
@@ -330,15 +353,20 @@ __device__ __forceinline__ void hepilogue(const GettArgs& p, acc16 (&acc)[TA][TB
   // added here in double precision
   const float unscale = hdrA[1] * hdrB[1];
   const bool centred = meanA != nullptr;
-  const float* usedA = centred ? reinterpret_cast<const float*>(meanA + (int64_t)(3 * QAMD_GEMMH_NY + 1) * Mpad) : nullptr;
-  const float* usedB = centred ? reinterpret_cast<const float*>(meanB + (int64_t)(3 * QAMD_GEMMH_NY + 1) * Npad) : nullptr;
-  double bbar[TBW], bh[TBW];
+  const int np = p.pad_ == 2 ? 2 : 1;                      // centring constants per parity of k (GettArgs.pad_ = the operands' period)
+  const double Kp = (double)p.K / np;
+  const float* usedA = centred ? reinterpret_cast<const float*>(meanA + QAMD_GEMMH_USED0(Mpad)) : nullptr;
+  const float* usedB = centred ? reinterpret_cast<const float*>(meanB + QAMD_GEMMH_USED0(Npad)) : nullptr;
+  double bbar[2][TBW], bh[2][TBW];
 #pragma unroll
-  for (int j = 0; j < TBW; ++j) {
-    const int g = n0 + col0 + 32 * j + l31;
-    bbar[j] = centred ? meanB[g] * (double)p.K : 0.0;
-    bh[j] = centred ? (double)usedB[g] * (double)p.K : 0.0;
-  }
+  for (int q = 0; q < 2; ++q)
+#pragma unroll
+    for (int j = 0; j < TBW; ++j) {
+      const int g = n0 + col0 + 32 * j + l31;
+      const bool on = centred && q < np;
+      bbar[q][j] = on ? meanB[(int64_t)q * Npad + g] * Kp : 0.0;
+      bh[q][j] = on ? (double)usedB[(int64_t)q * Npad + g] * Kp : 0.0;
+    }
   if constexpr (DOT) {
     // (a tile's epilogue has the CU to itself -- one workgroup per CU --, so T's values are requested a whole sub-tile row
     // block ahead of their use, with clamped addresses and 0 / 1 masks instead of branches: 64 loads in flight per lane)
@@ -374,9 +402,13 @@ __device__ __forceinline__ void hepilogue(const GettArgs& p, acc16 (&acc)[TA][TB
           dsum = __builtin_fmaf(acc[i][j][r], trow[j], dsum);
         }
         if (centred) {
-          const double abar = meanA[m0 + ml], ah = (double)usedA[m0 + ml], ad = abar - ah;
 #pragma unroll
-          for (int j = 0; j < TBW; ++j) dcorr += (ah * bbar[j] + ad * bh[j]) * (double)trow[j];
+          for (int q = 0; q < 2; ++q) {
+            if (q >= np) continue;
+            const double abar = meanA[(int64_t)q * Mpad + m0 + ml], ah = (double)usedA[(int64_t)q * Mpad + m0 + ml], ad = abar - ah;
+#pragma unroll
+            for (int j = 0; j < TBW; ++j) dcorr += (ah * bbar[q][j] + ad * bh[q][j]) * (double)trow[j];
+          }
         }
       }
     }
@@ -402,18 +434,22 @@ __device__ __forceinline__ void hepilogue(const GettArgs& p, acc16 (&acc)[TA][TB
       const int ml = row0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * kh;
       if (m0 + ml >= p.M) continue;
       const int64_t orow = offCm[ml];
-      double ah = 0.0, ad = 0.0;
+      double ah[2] = {0.0, 0.0}, ad[2] = {0.0, 0.0};
       if (centred) {
-        const double abar = meanA[m0 + ml];
-        ah = (double)usedA[m0 + ml];
-        ad = abar - ah;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          if (q >= np) continue;
+          const double abar = meanA[(int64_t)q * Mpad + m0 + ml];
+          ah[q] = (double)usedA[(int64_t)q * Mpad + m0 + ml];
+          ad[q] = abar - ah[q];
+        }
       }
 #pragma unroll
       for (int j = 0; j < TBW; ++j) {
         const int nl = col0 + 32 * j + l31;
         if (n0 + nl < p.N) {
           float v = acc[i][j][r] * alpha;
-          if (centred) v = (float)((double)v + (ah * bbar[j] + ad * bh[j]) * (double)strip);
+          if (centred) v = (float)((double)v + ((ah[0] * bbar[0][j] + ad[0] * bh[0][j]) + (ah[1] * bbar[1][j] + ad[1] * bh[1][j])) * (double)strip);
           C[orow + offCn[nl]] = v;
           vmax = fmaxf(vmax, fabsf(v));
         }
@@ -799,8 +835,8 @@ using namespace qamdh;
 // bytes of one operand's split images for free extent padded to ``xpad`` and K padded to ``kpad`` (a multiple of 32)
 extern "C" int64_t qamd_gemmh_image_bytes(int64_t xpad, int64_t kpad) { return 2 * (kpad / 8) * xpad * 16; }
 // bytes of one operand's column means (doubles) + the partial sums they are built from
-// (xpad means, 3 NY rows of partial sums, then xpad fp32 constants)
-extern "C" int64_t qamd_gemmh_mean_bytes(int64_t xpad) { return (3 * QAMD_GEMMH_NY + 1) * xpad * 8 + xpad * 4; }
+// (the centring block: QAMD_GEMMH_PART0 / USED0 above)
+extern "C" int64_t qamd_gemmh_mean_bytes(int64_t xpad) { return QAMD_GEMMH_USED0(xpad) * 8 + 2 * xpad * 4; }
 
 // absmax of a strided operand into 64 zeroed slots (callers without exponent slots)
 extern "C" int qamd_gemmh_absmax_launch(const SplitArgs* a, const void* X, void* slots, void* stream) {
@@ -818,8 +854,9 @@ extern "C" int qamd_gemmh_split_launch(const SplitArgs* a, const void* X, const 
                                        void* stream) {
   if (!a || !X || !hdr || !P || a->KG == 0 || a->KG % 4 || a->Xpad < a->X || ((uintptr_t)P & 15) || ((uintptr_t)mean & 7)) return -2;
   const unsigned gx = (a->Xpad + 255) / 256;
-  double* part = mean ? (double*)mean + a->Xpad : nullptr;
-  float* cused = mean ? reinterpret_cast<float*>((double*)mean + (int64_t)(3 * QAMD_GEMMH_NY + 1) * a->Xpad) : nullptr;
+  double* part = mean ? (double*)mean + QAMD_GEMMH_PART0(a->Xpad) : nullptr;
+  float* cused = mean ? reinterpret_cast<float*>((double*)mean + QAMD_GEMMH_USED0(a->Xpad)) : nullptr;
+  if (a->period == 2 && a->K % 2) return -2;
   // k-contiguous sources (16-byte loads along k, LDS-transposed stores): the innermost K group stride-1 in multiples of 8,
   // every other stride and the base pointer 16-byte aligned
   bool kc = ((uintptr_t)X & 15) == 0 && a->K % 8 == 0;

@@ -91,7 +91,8 @@ struct SplitArgs {
   int64_t sk;            // element stride of k in the source (nk <= 1)
   uint32_t X, Xpad;      // free extent, and padded to whole workgroup tiles
   uint32_t K, KG;        // contraction extent, and k-groups of 8 in the image (K rounded up to 32, / 8)
-  int32_t nk, pad2_;     // nk > 1: the contraction bundle in several groups (outermost first), k -> offset by decomposition
+  int32_t nk, period;    // nk > 1: the contraction bundle in several groups (outermost first), k -> offset by decomposition;
+                         // period 2: one centring constant per PARITY of k (an innermost K group of two: re / im interleaved); else 1
   uint32_t dim_k[QAMD_G];
   int64_t stride_k[QAMD_G];
 };

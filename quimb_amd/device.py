@@ -130,10 +130,10 @@ class HipDevice:
         o = getattr(self._rec_tls, "pins", None) or get_options()
         pick = lambda dev_value, opt_value: opt_value if dev_value is None else dev_value
         kernel = int(pick(self.force_kernel, o.pair_kernel))
-        if kernel == 0 and o.join_arith == "f16x3":
-            kernel = -7      # (opt-in: the planner puts the joins large enough for it on gemmh.hip, everything else as usual)
-        elif o.join_arith not in ("f32", "f16x3"):
-            raise ValueError(f"join_arith must be 'f32' or 'f16x3', got {o.join_arith!r}")
+        if kernel == 0 and o.join_arith != "f32":
+            # (opt-in: the planner puts the pairs large enough for it on gemmh.hip -- the k-outer joins, or with "-all" any
+            # operand layout --, everything else as usual)
+            kernel = -7 if o.join_arith == "f16x3" else -8
         return (kernel, int(pick(self.force_tile_cfg, o.tile_cfg)),
                 int(pick(self.force_split_k, o.split_k)), pick(self.micro_arena, o.micro_arena))
 

@@ -97,15 +97,9 @@ def _complex_gett(dev, spec, ka, kb, out):
     rdt = _REAL_OF[ka.dtype]
     kb2 = dev.empty(4 * kb.size, rdt)
     dev.complex_expand(kb2, kb._buf, kb.size, ka.dtype)
-    # (the 2 x 2 real blocks interleave re / im along K: columns of alternating sign that no per-column constant centres -- the
-    # opt-in split products (Options.join_arith = "f16x3") would run them uncentred, at an fp32 fma chain's accuracy where the
-    # fp32 kernels' blocked accumulation does better; complex pairs therefore always keep the fp32 kernels)
-    pins = getattr(getattr(dev, "_rec_tls", None), "pins", None) or get_options()
-    if getattr(pins, "join_arith", "f32") != "f32" and hasattr(dev, "pinned"):
-        with dev.pinned(pins.replace(join_arith="f32")):
-            dev.contract_pair(_complex_spec(spec), rdt, dev.as_real(ka._buf), kb2, dev.as_real(out._buf))
-    else:
-        dev.contract_pair(_complex_spec(spec), rdt, dev.as_real(ka._buf), kb2, dev.as_real(out._buf))
+    # (the 2 x 2 real blocks interleave re / im along K as an innermost K group of two: under the opt-in split products
+    # (Options.join_arith = "f16x3") the library centres such operands per PARITY of k -- csrc/gemmh.hip, SplitArgs.period)
+    dev.contract_pair(_complex_spec(spec), rdt, dev.as_real(ka._buf), kb2, dev.as_real(out._buf))
     if hasattr(dev, "release_temp"):
         dev.release_temp(kb2)
 

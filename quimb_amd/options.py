@@ -38,7 +38,7 @@ class Options:
     pair_kernel: int = 0            #: qamd_pair_plan.kernel on input: 0 auto, -1 tiled GETT, -2 no MFMA GEMM kernels   [QAMD_KERNEL]
     tile_cfg: int = -1              #: qamd_pair_plan.tile_cfg on input                                 [QAMD_TILE_CFG]
     split_k: int = 0                #: qamd_pair_plan.split_k on input                                  [QAMD_SPLIT_K]
-    join_arith: str = "f32"         #: arithmetic of the large fp32 GEMM-shaped joins: "f32" (fp32 MFMA, gemmk.hip) | "f16x3" (OPT-IN: split products on the f16 matrix pipe, fp32 accumulate, gemmh.hip: qamd_pair_plan.kernel = -7)  [QAMD_JOIN_ARITH]
+    join_arith: str = "f32"         #: arithmetic of the large fp32 GEMM-shaped joins: "f32" (fp32 MFMA, gemmk.hip) | "f16x3" (OPT-IN: the k-outer joins as split products on the f16 matrix pipe, fp32 accumulate, gemmh.hip: qamd_pair_plan.kernel = -7) | "f16x3-all" (OPT-IN: every large fp32 GEMM-shaped pair, any operand layout, complex pairs included: kernel = -8; on incoherent operands an fp32 chain's accuracy, not the blocked kernels')  [QAMD_JOIN_ARITH]
     # ---- execution ----------------------------------------------------------------------------------------------------
     lanes: bool = True              #: independent chains on their own HIP streams                      [QAMD_LANES]
     slice_graph: bool = True        #: slices replay one recorded hipGraph                              [QAMD_SLICE_GRAPH]
@@ -55,8 +55,8 @@ class Options:
     debug: bool = False             #: say on stderr why a recording was refused                        [QAMD_DEBUG]
 
     def __post_init__(self):
-        if self.join_arith not in ("f32", "f16x3"):
-            raise ValueError(f"join_arith must be 'f32' or 'f16x3', got {self.join_arith!r}")
+        if self.join_arith not in ("f32", "f16x3", "f16x3-all"):
+            raise ValueError(f"join_arith must be 'f32', 'f16x3' or 'f16x3-all', got {self.join_arith!r}")
 
     def replace(self, **kw):
         return dataclasses.replace(self, **kw)

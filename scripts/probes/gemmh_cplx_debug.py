@@ -9,7 +9,7 @@ for (K, M, N) in ((512, 384, 640), (512, 512, 512), (1024, 384, 640), (1296, 129
     b = (rng.uniform(-0.1, 1, (K, N)) + 1j * rng.uniform(-1, 0.1, (K, N))).astype(np.complex64)
     want = a.astype(np.complex128).T @ b.astype(np.complex128)
     dev.profile, dev.profile_min_mults = [], 0
-    with qa.exec_options(join_arith="f16x3"):
+    with qa.exec_options(join_arith="f16x3-all"):
         got = qa.to_numpy(qa.einsum("km,kn->mn", qa.asarray(a), qa.asarray(b)))
     names = [r[2] for r in dev.profile]; specs = [r[0] for r in dev.profile]
     dev.profile = None
@@ -19,7 +19,7 @@ for (K, M, N) in ((512, 384, 640), (512, 512, 512), (1024, 384, 640), (1296, 129
           "mean signed re", d.real.mean() / mx, "im", d.imag.mean() / mx, "max|C|", mx)
     # the same as two real problems through the real path
     ar, ai, br, bi = a.real.copy(), a.imag.copy(), b.real.copy(), b.imag.copy()
-    with qa.exec_options(join_arith="f16x3"):
+    with qa.exec_options(join_arith="f16x3-all"):
         rr = qa.to_numpy(qa.einsum("km,kn->mn", qa.asarray(ar), qa.asarray(br))).astype(np.float64)
         ii = qa.to_numpy(qa.einsum("km,kn->mn", qa.asarray(ai), qa.asarray(bi))).astype(np.float64)
     print("   real products separately: err of (ArBr - AiBi) vs fp64:", np.abs((rr - ii) - want.real).max() / mx)

@@ -649,7 +649,6 @@ def check_gemmh(seed=41, tiles=(None,)):
     names = []
     for tile in tiles:
         old_pin = (getattr(dev, "force_kernel", None), getattr(dev, "force_tile_cfg", None))
-        dev.force_kernel = -7
         dev.force_tile_cfg = None if tile is None else 16 * (int(tile) // 10) + int(tile) % 10
         if hasattr(dev, "_pairs"):
             dev._pairs.clear()
@@ -659,6 +658,11 @@ def check_gemmh(seed=41, tiles=(None,)):
                     lhs, out = eq.split("->")
                     ai, bi = lhs.split(",")
                     sa, sb = [dims[c] for c in ai], [dims[c] for c in bi]
+                    # plan input kernel = -7 ("f16x3"): the k-outer joins; -8 ("f16x3-all"): any operand layout
+                    pin = -7 if (ai[0] == "k" and bi[0] == "k") else -8
+                    dev.force_kernel = pin
+                    if hasattr(dev, "_pairs"):
+                        dev._pairs.clear()
                     if fill == "mostly positive":
                         a, b = rng.uniform(-0.1, 1.0, sa), rng.uniform(-0.1, 1.0, sb) * 3.7e4
                     elif fill == "signed":
@@ -679,7 +683,7 @@ def check_gemmh(seed=41, tiles=(None,)):
                         try:
                             got32 = qa.einsum(eq, qa.asarray(a), qa.asarray(b))
                         finally:
-                            dev.force_kernel = -7
+                            dev.force_kernel = pin
                         err32 = np.max(np.abs(got32.to_numpy().astype(np.float64) - want))
                         assert err <= 0.5 * err32, (eq, fill, err, err32)
                     if hasattr(dev, "describe_pair") and hasattr(dev, "compile_pair"):
@@ -687,6 +691,9 @@ def check_gemmh(seed=41, tiles=(None,)):
 
                         step = plan_pair(tuple(ai), tuple(sa), tuple(bi), tuple(sb), tuple(out), True)
                         names.append(dev.describe_pair(dev.compile_pair(step.spec, np.dtype("float32"))))
+            dev.force_kernel = -7
+            if hasattr(dev, "_pairs"):
+                dev._pairs.clear()
             if tile is not None:
                 # short k loops on a pinned tile (the floors K, M, N >= 256 are waived): two, three, four 32-k stages, padded k
                 for kk in (40, 64, 72, 96, 100, 128, 136):
@@ -701,6 +708,52 @@ def check_gemmh(seed=41, tiles=(None,)):
             if hasattr(dev, "_pairs"):
                 dev._pairs.clear()
     return names
+
+
+def check_gemmh_complex(seed=47):
+    """Complex pairs under ``join_arith = "f16x3-all"``: their 2 x 2 real blocks interleave re / im along K (an innermost K group of
+    two), so every column alternates between two populations with k -- the split pass centres them per PARITY of k
+    (SplitArgs.period = 2), and the product must beat the fp32 kernels' own accuracy on coherent fills as the real case
+    does.  Coherent (the benchmark's fill on both components), random-phase, and a ragged shape."""
+    rng = np.random.default_rng(seed)
+    dev = qa.default_device()
+    out = []
+    for (K, M, N), fill in (((512, 384, 640), "coherent"), ((1024, 384, 640), "coherent"), ((1296, 1296, 216), "coherent"),
+                            ((777, 300, 517), "coherent"), ((1024, 512, 512), "random phase")):
+        if fill == "coherent":
+            a = rng.uniform(-0.1, 1, (K, M)) + 1j * rng.uniform(-0.1, 1, (K, M))
+            b = rng.uniform(-0.1, 1, (K, N)) + 1j * rng.uniform(-1, 0.1, (K, N))
+        else:
+            a = rng.uniform(0.2, 1, (K, M)) * np.exp(2j * np.pi * rng.uniform(size=(K, M)))
+            b = rng.uniform(0.2, 1, (K, N)) * np.exp(2j * np.pi * rng.uniform(size=(K, N)))
+        a, b = a.astype(np.complex64), b.astype(np.complex64)
+        want = a.astype(np.complex128).T @ b.astype(np.complex128)
+        res = {}
+        for mode in ("f32", "f16x3-all"):
+            with qa.exec_options(join_arith=mode):
+                if hasattr(dev, "profile"):
+                    dev.profile, dev.profile_min_mults = [], 0
+                got = qa.einsum("km,kn->mn", qa.asarray(a), qa.asarray(b)).to_numpy()
+                names = [r[2] for r in dev.profile] if getattr(dev, "profile", None) is not None else []
+                if hasattr(dev, "profile"):
+                    dev.profile = None
+            # (the bar of an fp32 k-ordered chain, as check_gemmk / check_gemmh: with random phases the result is small against
+            # the magnitudes that were summed, and a chain of 2 K terms rounds like one -- the fp32 kernels' blocked
+            # accumulation does better there, the split products do better on coherent operands)
+            err = float(np.max(np.abs(got.astype(np.complex128) - want)))
+            bound = 1.5 * 2 * np.sqrt(2 * K) * 2.0**-24 * float(np.max(np.abs(a).astype(np.float64).T @ np.abs(b).astype(np.float64)))
+            assert got.shape == want.shape and err <= bound, ((K, M, N), fill, mode, err, bound)
+            res[mode] = err / float(np.max(np.abs(want)))
+            if mode == "f16x3-all" and names:
+                assert any(n.startswith("gemmh") for n in names), names
+        # (plain "f16x3" leaves complex pairs on the fp32 kernels: their real expansion is not a k-outer join)
+        with qa.exec_options(join_arith="f16x3"):
+            got7 = qa.einsum("km,kn->mn", qa.asarray(a), qa.asarray(b)).to_numpy()
+        assert float(np.max(np.abs(got7.astype(np.complex128) - want)) / np.max(np.abs(want))) == res["f32"]
+        if fill == "coherent" and (K, M, N) != (777, 300, 517):
+            assert res["f16x3-all"] <= 0.6 * res["f32"], ((K, M, N), res)
+        out.append(((K, M, N), fill, res))
+    return out
 
 
 def check_gemmh_tree(seed=43):

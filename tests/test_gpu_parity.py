@@ -286,6 +286,7 @@ def test_gemmh_split_products(hip):
     assert any(n.startswith("gemmh") and n.endswith("+ dot") for n in names), names
     assert any(n.startswith("gemmk_kernel") and n.endswith("+ dot") for n in names), names
     print("split products vs fp32 MFMA, rel. err of the closing scalar:", res)
+    print("complex pairs, max-norm err vs complex128 (fp32 kernels / split products):", checks.check_gemmh_complex())
 
 
 @pytest.mark.parametrize("dtype", ["float32", "float64", "complex64"])

@@ -135,7 +135,7 @@ def test_split_product_joins_are_opt_in():
     assert p.kernel == 7 and name == "gemmh8_kernel<4, 4> f16x3", name                    # 961 tiles of 256 x 256 on the eight-wave kernel
     mpad, npad, kpad = 31 * 256, 31 * 256, 7776
     img = lambda x: 2 * (kpad // 8) * x * 16       # both fp16 halves, 16 bytes per (k-group of 8, column)
-    means = lambda x: (3 * 32 + 1) * x * 8 + 4 * x     # a column's mean (double), 3 x 32 partial sums (doubles), the fp32 constant subtracted
+    means = lambda x: (2 + 6 * 32) * x * 8 + 2 * 4 * x   # per parity of k: a column's mean (double), 3 x 32 partial sums, the fp32 constant subtracted
     assert lib.qamd_pair_workspace_bytes(C.byref(p)) == 1024 + means(mpad) + means(npad) + img(mpad) + img(npad)
     assert lib.qamd_pair_dot_workspace_bytes(C.byref(p)) == (8 * 31 * 31 + 255) // 256 * 256 + lib.qamd_pair_workspace_bytes(C.byref(p))
     # without its workspace the call is refused before anything is launched (host logic: no device needed)
@@ -149,11 +149,17 @@ def test_split_product_joins_are_opt_in():
     name, p = _describe("km", (300, 7000), "kn", (300, 5000), "mn", pin=(-7, -1))         # K % 32 != 0: zero-padded images
     assert p.kernel == 7 and lib.qamd_pair_workspace_bytes(C.byref(p)) > 0
     # not covered -> the automatic choice, as if the pin were 0
-    # any operand layout is covered (the split pass gathers with the operands' own strides): k-contiguous operands, K in groups
+    # kernel = -8: any operand layout (the split pass gathers with the operands' own strides): k-contiguous operands, K in groups;
+    # kernel = -7 leaves those to their blocked fp32 kernels
     for args in (("mk", (2048, 512), "kn", (512, 2048), "mn"), ("km", (512, 2048), "nk", (2048, 512), "mn"),
                  ("mk", (2048, 512), "nk", (2048, 512), "nm"), ("muk", (2048, 24, 32), "kun", (32, 24, 2048), "mn")):
+        name8, p8 = _describe(*args, pin=(-8, -1))
+        assert p8.kernel == 7 and name8.startswith("gemmh"), (args, name8)
         name7, p7 = _describe(*args, pin=(-7, -1))
-        assert p7.kernel == 7 and name7.startswith("gemmh"), (args, name7)
+        name0, p0 = _describe(*args)
+        assert p7.kernel != 7 and (p7.kernel, name7) == (p0.kernel, name0), (args, name7, name0)
+    name8, p8 = _describe("km", (7776, 7776), "kn", (7776, 7776), "mn", pin=(-8, -1))
+    assert p8.kernel == 7 and name8 == "gemmh8_kernel<4, 4> f16x3"
     for args, kw in ((("km", (128, 4096), "kn", (128, 4096), "mn"), {}),                  # K < 256: not worth the split pass
                      (("km", (512, 2048), "kn", (512, 200), "mn"), {}),                   # N < 256
                      (("hvm", (6, 6, 46656), "hxvy", (6, 6, 6, 6), "mxy"), {}),           # big x small: the streaming kernels
@@ -170,6 +176,7 @@ def test_join_arith_option_pins_kernel_minus_seven():
 
     assert Options().join_arith == "f32"
     assert Options.from_env({"QAMD_JOIN_ARITH": "f16x3"}).join_arith == "f16x3"
+    assert Options(join_arith="f16x3-all").join_arith == "f16x3-all"
     with qa.exec_options(join_arith="f16x3") as o:
         assert o.join_arith == "f16x3" and qa.get_options().join_arith == "f16x3"
     assert qa.get_options().join_arith == "f32"
