@@ -74,7 +74,7 @@ typedef struct {
   int32_t dtype;     /* qamd_dtype                                       */
   int32_t nb, nm, nn, nk;
   int32_t conj_a, conj_b; /* complex only                                */
-  int32_t kernel;    /* filled by finalize: 0 tiled GETT, 1 streaming (big x small), 2 streaming with LDS-transposed stores, 4 few-rows x long-vector reduction (split_k slabs of workspace), 5 k-outer MFMA GETT (gemmk.hip: GEMM-shaped joins, fp32, both free bundles stride-1; tile_cfg = 16 ta + tb names the (64 ta) x (64 tb) workgroup tile; pinned on input with kernel = -5 and tile_cfg = 16 ta + tb), 6 fp64 MFMA GETT on an LDS-DMA ring (gemmd.hip: GEMM-shaped fp64 contractions with either operand free- or k-contiguous; tile_cfg = 16 ta + tb names the (32 ta) x (64 tb) workgroup tile, split_k the number of k slabs; pinned on input with kernel = -6 and tile_cfg = 16 ta + tb), 7 fp32 GEMM-shaped pairs (no batch bundle, K, M, N >= 256) as SPLIT PRODUCTS on the f16 matrix pipe (gemmh.hip, OPT-IN, never chosen automatically: kernel = -7 on input asks for it on the k-outer joins of kernel 5, kernel = -8 on every operand layout -- the operands are re-laid-out by a split pass; complex pairs' real expansions included --: every fp32 operand is scaled by a power of two and written as the sum of two fp16 numbers -- 2^-24 relative --, the three products a1 b1 + a1 b2 + a2 b1 are exact and accumulate in fp32; the workspace holds the operands' split images: qamd_pair_workspace_bytes).  ON INPUT: 0 automatic, -1 force 0, -2 automatic without kernels 5 / 6, -5 / -6 as above, -7 / -8 kernel 7 where it applies and the automatic choice elsewhere -- the library reads no environment variable, these fields are the only way to steer the choice */
+  int32_t kernel;    /* filled by finalize: 0 tiled GETT, 1 streaming (big x small), 2 streaming with LDS-transposed stores, 4 few-rows x long-vector reduction (split_k slabs of workspace), 5 k-outer MFMA GETT (gemmk.hip: GEMM-shaped joins, fp32, both free bundles stride-1; tile_cfg = 16 ta + tb names the (64 ta) x (64 tb) workgroup tile; pinned on input with kernel = -5 and tile_cfg = 16 ta + tb), 6 fp64 MFMA GETT on an LDS-DMA ring (gemmd.hip: GEMM-shaped fp64 contractions with either operand free- or k-contiguous; tile_cfg = 16 ta + tb names the (32 ta) x (64 tb) workgroup tile, split_k the number of k slabs; pinned on input with kernel = -6 and tile_cfg = 16 ta + tb), 7 fp32 GEMM-shaped pairs (no batch bundle, K, M, N >= 256) as SPLIT PRODUCTS on the f16 matrix pipe (gemmh.hip, OPT-IN, never chosen automatically: kernel = -7 on input asks for it exactly where the automatic choice would have been kernel 5, kernel = -8 on every operand layout -- the operands are re-laid-out by a split pass; complex pairs' real expansions included --: every fp32 operand is scaled by a power of two and written as the sum of two fp16 numbers -- 2^-24 relative --, the three products a1 b1 + a1 b2 + a2 b1 are exact and accumulate in fp32; the workspace holds the operands' split images: qamd_pair_workspace_bytes).  ON INPUT: 0 automatic, -1 force 0, -2 automatic without kernels 5 / 6, -5 / -6 as above, -7 / -8 kernel 7 where it applies and the automatic choice elsewhere -- the library reads no environment variable, these fields are the only way to steer the choice */
   int64_t dim_b[QAMD_MAX_GROUPS], sa_b[QAMD_MAX_GROUPS], sb_b[QAMD_MAX_GROUPS], sc_b[QAMD_MAX_GROUPS];
   int64_t dim_m[QAMD_MAX_GROUPS], sa_m[QAMD_MAX_GROUPS], sc_m[QAMD_MAX_GROUPS];
   int64_t dim_n[QAMD_MAX_GROUPS], sb_n[QAMD_MAX_GROUPS], sc_n[QAMD_MAX_GROUPS];

@@ -410,7 +410,11 @@ extern "C" int qamd_pair_plan_finalize(qamd_pair_plan* p, int64_t align_a, int64
     if (p->kernel == 0 && kern == 0 && p->tile_cfg < 0 && pin_kernel != -2) {
       int ta = 0, tb = 0;
       // kernel 7 (gemmh.hip): opt-in, the same shapes as kernel 5 with B == 1
-      if ((pin_kernel == -7 || pin_kernel == -8) && gemmh_config(p, d, pin_gemm, pin_kernel == -8, ta, tb)) {
+      // (-7 without a pinned tile: only where the DEFAULT choice would have been the chain kernel gemmk -- the claim of that mode is
+      // "never less accurate than the default")
+      int ka = 0, kb = 0;
+      const bool chain_default = pin_kernel != -7 || pin_gemm != 0 || gemmk_config(p, d, align_a, align_b, align_c, 0, ka, kb);
+      if ((pin_kernel == -7 || pin_kernel == -8) && chain_default && gemmh_config(p, d, pin_gemm, pin_kernel == -8, ta, tb)) {
         p->kernel = 7;
         p->tile_cfg = 16 * ta + tb;
         p->split_k = 1;

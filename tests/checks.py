@@ -658,8 +658,18 @@ def check_gemmh(seed=41, tiles=(None,)):
                     lhs, out = eq.split("->")
                     ai, bi = lhs.split(",")
                     sa, sb = [dims[c] for c in ai], [dims[c] for c in bi]
-                    # plan input kernel = -7 ("f16x3"): the k-outer joins; -8 ("f16x3-all"): any operand layout
-                    pin = -7 if (ai[0] == "k" and bi[0] == "k") else -8
+                    # plan input kernel = -7 ("f16x3"): the joins whose default kernel is gemmk (or any k-outer pair with a pinned
+                    # tile); -8 ("f16x3-all"): any operand layout
+                    pin = -8
+                    if ai[0] == "k" and bi[0] == "k" and hasattr(dev, "describe_pair"):
+                        from quimb_amd.pairwise import plan_pair
+
+                        dev.force_kernel = None
+                        if hasattr(dev, "_pairs"):
+                            dev._pairs.clear()
+                        st0 = plan_pair(tuple(ai), tuple(sa), tuple(bi), tuple(sb), tuple(out), True)
+                        if tile is not None or dev.describe_pair(dev.compile_pair(st0.spec, np.dtype("float32"))).startswith("gemmk"):
+                            pin = -7
                     dev.force_kernel = pin
                     if hasattr(dev, "_pairs"):
                         dev._pairs.clear()

@@ -146,7 +146,7 @@ def test_split_product_joins_are_opt_in():
     assert name in ("gemmh8_kernel<4, 2> f16x3", "gemmh8_kernel<2, 4> f16x3"), name
     name, p = _describe("km", (8192, 8192), "kn", (8192, 8192), "mn", pin=(-7, 16 * 4 + 4))
     assert name == "gemmh8_kernel<4, 4> f16x3"
-    name, p = _describe("km", (300, 7000), "kn", (300, 5000), "mn", pin=(-7, -1))         # K % 32 != 0: zero-padded images
+    name, p = _describe("km", (300, 7000), "kn", (300, 5000), "mn", pin=(-8, -1))         # K % 32 != 0: zero-padded images (not a gemmk join: -8)
     assert p.kernel == 7 and lib.qamd_pair_workspace_bytes(C.byref(p)) > 0
     # not covered -> the automatic choice, as if the pin were 0
     # kernel = -8: any operand layout (the split pass gathers with the operands' own strides): k-contiguous operands, K in groups;
@@ -160,6 +160,9 @@ def test_split_product_joins_are_opt_in():
         assert p7.kernel != 7 and (p7.kernel, name7) == (p0.kernel, name0), (args, name7, name0)
     name8, p8 = _describe("km", (7776, 7776), "kn", (7776, 7776), "mn", pin=(-8, -1))
     assert p8.kernel == 7 and name8 == "gemmh8_kernel<4, 4> f16x3"
+    # -7 is granted only where the default would have been the chain kernel gemmk
+    name7, p7 = _describe("km", (512, 512), "kn", (512, 512), "mn", pin=(-7, -1))         # 16 tiles: split-K kernels by default
+    assert p7.kernel != 7 and _describe("km", (512, 512), "kn", (512, 512), "mn", pin=(-8, -1))[1].kernel == 7
     for args, kw in ((("km", (128, 4096), "kn", (128, 4096), "mn"), {}),                  # K < 256: not worth the split pass
                      (("km", (512, 2048), "kn", (512, 200), "mn"), {}),                   # N < 256
                      (("hvm", (6, 6, 46656), "hxvy", (6, 6, 6, 6), "mxy"), {}),           # big x small: the streaming kernels
